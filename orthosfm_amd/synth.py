@@ -1,0 +1,255 @@
+"""Synthetic orthographic image sets for the parity tests and bench.py.
+
+Follows SURVEY.md section 8(d): a counter-based generator (splitmix64 ->
+uniform, Box-Muller -> normal) so every process derives identical inputs
+from (seed, stream, counter) without shared state.  The scene mirrors the
+reference testbench's synthetic datasets (src/testbench/dataset_generation.cpp:
+14-93: cameras on a ring, every landmark projected orthographically) and the
+descriptor statistics of MVE SIFT (unit L2, clamp 0.2, renormalise --
+src/mve/sfm/sift.cc:832-839) and SURF (signed, unit L2).
+
+This module is host-side input generation only; it computes nothing on the
+matching / bundle-adjustment path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+BASE_SEED = 0x05F30001
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    """One splitmix64 output per input counter (vectorised, uint64)."""
+    with np.errstate(over="ignore"):
+        z = (x.astype(np.uint64) + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        return z ^ (z >> np.uint64(31))
+
+
+def _stream_base(seed: int, stream: int) -> np.uint64:
+    s = splitmix64(np.array([seed & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64))[0]
+    t = splitmix64(np.array([(int(s) ^ (stream * 0xD1342543DE82EF95)) & 0xFFFFFFFFFFFFFFFF],
+                            dtype=np.uint64))[0]
+    return t
+
+
+def uniform(seed: int, stream: int, n: int, offset: int = 0) -> np.ndarray:
+    """n doubles in [0, 1) from counters offset..offset+n-1 of a stream."""
+    base = _stream_base(seed, stream)
+    with np.errstate(over="ignore"):
+        ctr = (np.arange(offset, offset + n, dtype=np.uint64) * np.uint64(0x2545F4914F6CDD1D)) ^ base
+    bits = splitmix64(ctr)
+    return (bits >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def normal(seed: int, stream: int, n: int, offset: int = 0) -> np.ndarray:
+    """n standard normals (Box-Muller on two uniforms per pair)."""
+    m = (n + 1) // 2
+    u = uniform(seed, stream, 2 * m, 2 * offset)
+    u1 = 1.0 - u[0::2]            # (0, 1]
+    u2 = u[1::2]
+    r = np.sqrt(-2.0 * np.log(u1))
+    z = np.empty(2 * m)
+    z[0::2] = r * np.cos(2.0 * np.pi * u2)
+    z[1::2] = r * np.sin(2.0 * np.pi * u2)
+    return z[:n]
+
+
+# ---------------------------------------------------------------------------
+# descriptors
+# ---------------------------------------------------------------------------
+
+def _unit_rows(x: np.ndarray) -> np.ndarray:
+    n = np.linalg.norm(x, axis=1, keepdims=True)
+    n[n == 0] = 1.0
+    return x / n
+
+
+def sift_like(g: np.ndarray) -> np.ndarray:
+    """|g| -> unit -> clamp 0.2 -> unit (float32, in [0, 1])."""
+    v = _unit_rows(np.abs(g))
+    v = np.minimum(v, 0.2)
+    return _unit_rows(v).astype(np.float32)
+
+
+def surf_like(g: np.ndarray) -> np.ndarray:
+    return _unit_rows(g).astype(np.float32)
+
+
+def quantize_sift(f: np.ndarray) -> np.ndarray:
+    """Host-side twin of exhaustive_matching.cc:17-27 for input generation
+    (the product quantiser is osfm_quantize_sift; the oracle one is
+    oracle_convert_sift).  float32 arithmetic throughout."""
+    v = np.clip(f.astype(np.float32), np.float32(0), np.float32(1))
+    v = np.floor(v * np.float32(255.0) + np.float32(0.5))
+    return v.astype(np.uint8).astype(np.uint16)
+
+
+def quantize_surf(f: np.ndarray) -> np.ndarray:
+    v = np.clip(f.astype(np.float32), np.float32(-1), np.float32(1)) * np.float32(127.0)
+    r = np.where(v > 0, np.floor(v + np.float32(0.5)), np.ceil(v - np.float32(0.5)))
+    return r.astype(np.int8).astype(np.int16)
+
+
+class ImageSet:
+    """V views of one synthetic scene.
+
+    sift[v]: (n_v, 128) uint16 in 0..255, surf[v]: (m_v, 64) int16 in -127..127,
+    landmark[v]: (n_v,) landmark id or -1 for a distractor, pos[v]: (n_v, 2)
+    pixel positions (float32) from the orthographic projection.
+    """
+
+    def __init__(self, sift, surf, landmark, pos, cams, points, width, height):
+        self.sift = sift
+        self.surf = surf
+        self.landmark = landmark
+        self.pos = pos
+        self.cams = cams
+        self.points = points
+        self.width = width
+        self.height = height
+
+    @property
+    def num_views(self):
+        return len(self.sift)
+
+
+def make_image_set(num_views: int, feats_per_view: int, *, seed: int = BASE_SEED,
+                   config_id: int = 2, n_surf: int = 0, visibility: float = 0.4,
+                   distractor_frac: float = 0.2, noise: float = 0.03,
+                   width: int = 2048, height: int = 2048) -> ImageSet:
+    """L landmarks in the ball |p| <= 0.5 with a base descriptor
+    each; view v sees a random subset; descriptor = unit(base + noise*N(0,1)),
+    quantised as A1; per-view feature order = descending random 'scale'."""
+    n_real = int(round(feats_per_view * (1.0 - distractor_frac)))
+    n_dis = feats_per_view - n_real
+    L = max(int(round(n_real / visibility)), n_real)
+    st = config_id << 32
+
+    # landmarks
+    d = normal(seed, st | 1, 3 * L).reshape(L, 3)
+    d = _unit_rows(d)
+    rad = 0.5 * np.cbrt(uniform(seed, st | 2, L))
+    points = d * rad[:, None]
+    base_sift = normal(seed, st | 3, 128 * L).reshape(L, 128)
+    base_sift_u = _unit_rows(np.minimum(_unit_rows(np.abs(base_sift)), 0.2))
+    base_surf = _unit_rows(normal(seed, st | 4, 64 * L).reshape(L, 64)) if n_surf else None
+
+    sift, surf, landmark, pos, cams = [], [], [], [], []
+    for v in range(num_views):
+        sv = st | (0x1000 + 16 * v)
+        # camera: phi on a ring, theta/rho in +-30 deg (dataset_generation.cpp:17-30)
+        ang = uniform(seed, sv | 0, 2)
+        phi = 2.0 * np.pi * v / num_views
+        theta = np.deg2rad(-30.0 + 60.0 * ang[0])
+        rho = np.deg2rad(-30.0 + 60.0 * ang[1])
+        cams.append((phi, theta, rho))
+        # visible subset: n_real landmarks with the smallest random keys
+        keys = uniform(seed, sv | 1, L)
+        vis = np.argsort(keys, kind="stable")[:n_real]
+        g = normal(seed, sv | 2, 128 * n_real).reshape(n_real, 128)
+        f_real = _unit_rows(np.abs(base_sift_u[vis] + noise * g))
+        f_real = _unit_rows(np.minimum(f_real, 0.2)).astype(np.float32)
+        f_dis = sift_like(normal(seed, sv | 3, 128 * n_dis).reshape(n_dis, 128))
+        f = np.concatenate([f_real, f_dis], axis=0)
+        lm = np.concatenate([vis, -np.ones(n_dis, dtype=np.int64)])
+        # descending random scale = a random permutation
+        order = np.argsort(uniform(seed, sv | 4, feats_per_view), kind="stable")
+        sift.append(quantize_sift(f[order]))
+        landmark.append(lm[order])
+        # positions
+        xy = project_euler(points[vis], phi, theta, rho, 0.0, 0.0, 1.0, width, height)
+        xy_d = uniform(seed, sv | 5, 2 * n_dis).reshape(n_dis, 2) * [width, height]
+        pos.append(np.concatenate([xy, xy_d], axis=0)[order].astype(np.float32))
+        if n_surf:
+            m_real = min(n_surf, n_real)
+            gs = normal(seed, sv | 6, 64 * m_real).reshape(m_real, 64)
+            fs = surf_like(base_surf[vis[:m_real]] + noise * gs)
+            fd = surf_like(normal(seed, sv | 7, 64 * (n_surf - m_real)).reshape(n_surf - m_real, 64))
+            o2 = np.argsort(uniform(seed, sv | 8, n_surf), kind="stable")
+            surf.append(quantize_surf(np.concatenate([fs, fd], axis=0)[o2]))
+        else:
+            surf.append(np.zeros((0, 64), dtype=np.int16))
+    return ImageSet(sift, surf, landmark, pos, cams, points, width, height)
+
+
+# ---------------------------------------------------------------------------
+# camera models used to PLACE synthetic observations (generation only)
+# ---------------------------------------------------------------------------
+
+def euler_matrix(phi, theta, rho):
+    """S = Rz(phi) * Rx(theta + pi/2) * Rz-form(rho); reference
+    OrthographicCamera.cpp:78-96 (getSphericalProjectionMatrix)."""
+    om = theta + 0.5 * np.pi
+    Ry = np.array([[np.cos(rho), -np.sin(rho), 0], [np.sin(rho), np.cos(rho), 0], [0, 0, 1.0]])
+    Rx = np.array([[1.0, 0, 0], [0, np.cos(om), -np.sin(om)], [0, np.sin(om), np.cos(om)]])
+    Rz = np.array([[np.cos(phi), -np.sin(phi), 0], [np.sin(phi), np.cos(phi), 0], [0, 0, 1.0]])
+    return (Rz @ Rx) @ Ry
+
+
+_T = np.array([[1.0, 0, 0], [0, 0, -1.0], [0, 1.0, 0]])
+
+
+def project_euler(p, phi, theta, rho, off_x, off_y, scale, width, height):
+    """OrthographicCamera::projectPointOntoImagePlane (OrthographicCamera.cpp:63-76)."""
+    S = euler_matrix(phi, theta, rho)
+    loc = (S.T @ _T @ p.T).T / scale
+    x = width * ((loc[:, 0] - off_x) / -2.0 + 0.5)
+    y = height * ((loc[:, 1] - off_y) / -2.0 + 0.5)
+    return np.stack([x, y], axis=1)
+
+
+def quat_rotate(q, v):
+    """Rotate rows of v by unit quaternion q = (x, y, z, w)."""
+    u = q[:3]
+    w = q[3]
+    t = 2.0 * np.cross(u, v)
+    return v + w * t + np.cross(u, t)
+
+
+def project_quat(p, q, off_x, off_y, scale, width, height):
+    """Pixel projection of the quaternion model (residual functor
+    OrthographicQuaternionReprojectorError.h:24-67 without the observation)."""
+    qi = np.array([-q[0], -q[1], -q[2], q[3]]) / np.dot(q, q)
+    loc = quat_rotate(qi, p)
+    x = width * (((loc[:, 0] / scale) - off_x) / -2.0 + 0.5)
+    y = height * (((loc[:, 1] / scale) - off_y) / -2.0 + 0.5)
+    return np.stack([x, y], axis=1)
+
+
+def euler_to_quat(phi, theta, rho):
+    """Quaternion (x, y, z, w) whose inverse rotation equals S^T * T, i.e. the
+    same world->local map as the Euler model, so both models can share scenes."""
+    R = (euler_matrix(phi, theta, rho).T @ _T).T     # local -> world
+    return mat_to_quat(R)
+
+
+def mat_to_quat(R):
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        w = 0.25 * s
+        x = (R[2, 1] - R[1, 2]) / s
+        y = (R[0, 2] - R[2, 0]) / s
+        z = (R[1, 0] - R[0, 1]) / s
+    elif R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
+        s = np.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2]) * 2
+        w = (R[2, 1] - R[1, 2]) / s
+        x = 0.25 * s
+        y = (R[0, 1] + R[1, 0]) / s
+        z = (R[0, 2] + R[2, 0]) / s
+    elif R[1, 1] > R[2, 2]:
+        s = np.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2]) * 2
+        w = (R[0, 2] - R[2, 0]) / s
+        x = (R[0, 1] + R[1, 0]) / s
+        y = 0.25 * s
+        z = (R[1, 2] + R[2, 1]) / s
+    else:
+        s = np.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1]) * 2
+        w = (R[1, 0] - R[0, 1]) / s
+        x = (R[0, 2] + R[2, 0]) / s
+        y = (R[1, 2] + R[2, 1]) / s
+        z = 0.25 * s
+    return np.array([x, y, z, w])

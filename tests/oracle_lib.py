@@ -1,0 +1,265 @@
+"""ctypes access to the CPU oracle (oracle/liboracle.so) and, when it was
+built, to the reference's own matcher (oracle/_ref/libref_match.so).
+
+Test infrastructure only: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by orthosfm_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libref_match.so")
+
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+_s16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def _load(path):
+    if not os.path.exists(path):
+        if path == ORACLE_SO:
+            build_oracle()
+        else:
+            return None
+    return C.CDLL(path)
+
+
+_oracle = None
+_ref = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        _oracle = _load(ORACLE_SO)
+    return _oracle
+
+
+def ref():
+    """The reference matcher, or None when oracle/_ref was not built."""
+    global _ref
+    if _ref is None:
+        _ref = _load(REF_SO)
+    return _ref
+
+
+def have_ref():
+    return ref() is not None
+
+
+def _u16(a):
+    return np.ascontiguousarray(a, dtype=np.uint16)
+
+
+def _s16(a):
+    return np.ascontiguousarray(a, dtype=np.int16)
+
+
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+class _Matcher:
+    """Same call surface for the oracle restatement and the reference shim."""
+
+    def __init__(self, lib, prefix):
+        self.lib = lib
+        self.p = prefix
+
+    def _f(self, name):
+        return getattr(self.lib, self.p + name)
+
+    def nn_find(self, q, el):
+        out = np.zeros(4, dtype=np.int32)
+        if el.dtype == np.uint16:
+            f = self._f("nn_find_u16")
+            f.argtypes = [_u16p, _u16p, C.c_int, C.c_int, _i32p]
+        else:
+            f = self._f("nn_find_s16")
+            f.argtypes = [_s16p, _s16p, C.c_int, C.c_int, _i32p]
+        f.restype = None
+        el = np.ascontiguousarray(el)
+        q = np.ascontiguousarray(q)
+        f(q, el if el.size else np.zeros(1, el.dtype), el.shape[0], q.shape[0], out)
+        return out
+
+    def twoway(self, s1, s2, lowe, dist=FLT_MAX):
+        n1, n2 = s1.shape[0], s2.shape[0]
+        dim = s1.shape[1] if s1.ndim == 2 else s2.shape[1]
+        m12 = np.full(max(n1, 1), -7, dtype=np.int32)
+        m21 = np.full(max(n2, 1), -7, dtype=np.int32)
+        if s1.dtype == np.uint16:
+            f = self._f("twoway_match_u16")
+            f.argtypes = [_u16p, C.c_int, _u16p, C.c_int, C.c_int, C.c_float, C.c_float, _i32p, _i32p]
+        else:
+            f = self._f("twoway_match_s16")
+            f.argtypes = [_s16p, C.c_int, _s16p, C.c_int, C.c_int, C.c_float, C.c_float, _i32p, _i32p]
+        f.restype = None
+        a = np.ascontiguousarray(s1).reshape(-1)
+        b = np.ascontiguousarray(s2).reshape(-1)
+        if a.size == 0:
+            a = np.zeros(1, s1.dtype)
+        if b.size == 0:
+            b = np.zeros(1, s2.dtype)
+        f(a, n1, b, n2, dim, lowe, dist, m12, m21)
+        return m12[:n1].copy(), m21[:n2].copy()
+
+    def remove_inconsistent(self, m12, m21):
+        a = np.ascontiguousarray(m12, dtype=np.int32).copy()
+        b = np.ascontiguousarray(m21, dtype=np.int32).copy()
+        f = self._f("remove_inconsistent")
+        f.argtypes = [_i32p, C.c_int, _i32p, C.c_int]
+        f.restype = None
+        aa = a if a.size else np.zeros(1, np.int32)
+        bb = b if b.size else np.zeros(1, np.int32)
+        f(aa, a.size, bb, b.size)
+        return aa[:a.size], bb[:b.size]
+
+    def count_consistent(self, m12, m21):
+        a = np.ascontiguousarray(m12, dtype=np.int32)
+        b = np.ascontiguousarray(m21, dtype=np.int32)
+        f = self._f("count_consistent")
+        f.argtypes = [_i32p, C.c_int, _i32p, C.c_int]
+        f.restype = C.c_int
+        aa = a if a.size else np.zeros(1, np.int32)
+        bb = b if b.size else np.zeros(1, np.int32)
+        return f(aa, a.size, bb, b.size)
+
+    def combine(self, s12, s21, u12, u21):
+        arrs = [np.ascontiguousarray(x, dtype=np.int32) for x in (s12, s21, u12, u21)]
+        n = [x.size for x in arrs]
+        arrs = [x if x.size else np.zeros(1, np.int32) for x in arrs]
+        o12 = np.zeros(max(n[0] + n[2], 1), dtype=np.int32)
+        o21 = np.zeros(max(n[1] + n[3], 1), dtype=np.int32)
+        f = self._f("combine_results")
+        f.argtypes = [_i32p, C.c_int, _i32p, C.c_int, _i32p, C.c_int, _i32p, C.c_int, _i32p, _i32p]
+        f.restype = None
+        f(arrs[0], n[0], arrs[1], n[1], arrs[2], n[2], arrs[3], n[3], o12, o21)
+        return o12[:n[0] + n[2]].copy(), o21[:n[1] + n[3]].copy()
+
+
+def oracle_matcher():
+    return _Matcher(oracle(), "oracle_")
+
+
+def ref_matcher():
+    r = ref()
+    return None if r is None else _Matcher(r, "ref_")
+
+
+# --- whole-view functions (A1, A7) -----------------------------------------
+
+def oracle_convert_sift(f):
+    f = np.ascontiguousarray(f, dtype=np.float32)
+    out = np.zeros(f.shape, dtype=np.uint16)
+    fn = oracle().oracle_convert_sift
+    fn.argtypes = [_f32p, C.c_int, _u16p]
+    fn.restype = None
+    if f.size:
+        fn(f.reshape(-1), f.shape[0], out.reshape(-1))
+    return out
+
+
+def oracle_convert_surf(f):
+    f = np.ascontiguousarray(f, dtype=np.float32)
+    out = np.zeros(f.shape, dtype=np.int16)
+    fn = oracle().oracle_convert_surf
+    fn.argtypes = [_f32p, C.c_int, _s16p]
+    fn.restype = None
+    if f.size:
+        fn(f.reshape(-1), f.shape[0], out.reshape(-1))
+    return out
+
+
+def _nz(a, dt):
+    a = np.ascontiguousarray(a, dtype=dt).reshape(-1)
+    return a if a.size else np.zeros(1, dt)
+
+
+def oracle_pairwise_match(sift1, surf1, sift2, surf2, sift_lowe=0.8, surf_lowe=0.7,
+                          sift_dist=FLT_MAX, surf_dist=FLT_MAX):
+    ns1, nu1, ns2, nu2 = sift1.shape[0], surf1.shape[0], sift2.shape[0], surf2.shape[0]
+    o12 = np.zeros(max(ns1 + nu1, 1), dtype=np.int32)
+    o21 = np.zeros(max(ns2 + nu2, 1), dtype=np.int32)
+    l12 = C.c_int(0)
+    l21 = C.c_int(0)
+    fn = oracle().oracle_pairwise_match
+    fn.argtypes = [_u16p, C.c_int, _s16p, C.c_int, _u16p, C.c_int, _s16p, C.c_int,
+                   C.c_float, C.c_float, C.c_float, C.c_float,
+                   _i32p, C.POINTER(C.c_int), _i32p, C.POINTER(C.c_int)]
+    fn.restype = None
+    fn(_nz(sift1, np.uint16), ns1, _nz(surf1, np.int16), nu1,
+       _nz(sift2, np.uint16), ns2, _nz(surf2, np.int16), nu2,
+       sift_lowe, sift_dist, surf_lowe, surf_dist, o12, C.byref(l12), o21, C.byref(l21))
+    return o12[:l12.value].copy(), o21[:l21.value].copy()
+
+
+def oracle_pairwise_match_lowres(sift1, surf1, sift2, surf2, num_features=500,
+                                 sift_lowe=0.8, surf_lowe=0.7,
+                                 sift_dist=FLT_MAX, surf_dist=FLT_MAX):
+    fn = oracle().oracle_pairwise_match_lowres
+    fn.argtypes = [_u16p, C.c_int, _s16p, C.c_int, _u16p, C.c_int, _s16p, C.c_int,
+                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]
+    fn.restype = C.c_int
+    return fn(_nz(sift1, np.uint16), sift1.shape[0], _nz(surf1, np.int16), surf1.shape[0],
+              _nz(sift2, np.uint16), sift2.shape[0], _nz(surf2, np.int16), surf2.shape[0],
+              sift_lowe, sift_dist, surf_lowe, surf_dist, num_features)
+
+
+class RefExhaustive:
+    """The reference's ExhaustiveMatching fed with FLOAT descriptors
+    (init() quantises them itself)."""
+
+    def __init__(self, views):
+        r = ref()
+        self.r = r
+        r.ref_matcher_create.restype = C.c_void_p
+        r.ref_matcher_create.argtypes = [C.c_int]
+        self.h = C.c_void_p(r.ref_matcher_create(len(views)))
+        r.ref_matcher_set_view.argtypes = [C.c_void_p, C.c_int, _f32p, C.c_int, _f32p, C.c_int]
+        r.ref_matcher_set_view.restype = None
+        self.sizes = []
+        for v, (sift, surf) in enumerate(views):
+            sift = np.ascontiguousarray(sift, dtype=np.float32)
+            surf = np.ascontiguousarray(surf, dtype=np.float32)
+            self.sizes.append((sift.shape[0], surf.shape[0]))
+            r.ref_matcher_set_view(self.h, v, _nz(sift, np.float32), sift.shape[0],
+                                   _nz(surf, np.float32), surf.shape[0])
+        r.ref_matcher_init.argtypes = [C.c_void_p]
+        r.ref_matcher_init.restype = None
+        r.ref_matcher_init(self.h)
+
+    def pairwise_match(self, v1, v2):
+        n1 = sum(self.sizes[v1])
+        n2 = sum(self.sizes[v2])
+        o12 = np.zeros(max(n1, 1), dtype=np.int32)
+        o21 = np.zeros(max(n2, 1), dtype=np.int32)
+        l12, l21 = C.c_int(0), C.c_int(0)
+        f = self.r.ref_matcher_pairwise_match
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, _i32p, C.POINTER(C.c_int), _i32p, C.POINTER(C.c_int)]
+        f.restype = None
+        f(self.h, v1, v2, o12, C.byref(l12), o21, C.byref(l21))
+        return o12[:l12.value].copy(), o21[:l21.value].copy()
+
+    def pairwise_match_lowres(self, v1, v2, n):
+        f = self.r.ref_matcher_pairwise_match_lowres
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        f.restype = C.c_int
+        return f(self.h, v1, v2, n)
+
+    def __del__(self):
+        try:
+            self.r.ref_matcher_destroy.argtypes = [C.c_void_p]
+            self.r.ref_matcher_destroy(self.h)
+        except Exception:
+            pass
