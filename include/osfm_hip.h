@@ -1,0 +1,286 @@
+/*
+ * osfm_hip.h -- C ABI of the MI355X (gfx950) backend for OrthoSfM's hot path:
+ *   (A) exhaustive pairwise descriptor matching  (src/mve/sfm, src/matching)
+ *   (B) orthographic bundle adjustment           (src/bundle_adjustment, src/algorithms)
+ *
+ * Plain C: pointers, sizes, POD structs; no C++/torch types.  Every entry
+ * point names the reference interface it replaces (paths relative to the
+ * OrthoSfM source tree).  All functions return OSFM_OK (0) or a negative
+ * osfm_status; osfm_last_error() returns a thread-local description.
+ * The library never hands out memory the caller must free and never falls
+ * back to a CPU implementation: without a usable gfx950 device every
+ * compute entry point fails with OSFM_E_DEVICE.
+ */
+#ifndef OSFM_HIP_H
+#define OSFM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSFM_API __attribute__((visibility("default")))
+
+typedef enum osfm_status {
+    OSFM_OK = 0,
+    OSFM_E_ARG = -1,       /* null / out-of-range argument (MVE throws std::invalid_argument) */
+    OSFM_E_DEVICE = -2,    /* no HIP device / HIP runtime error */
+    OSFM_E_RANGE = -3,     /* descriptor value outside the quantised range */
+    OSFM_E_CAPACITY = -4,  /* caller buffer too small; required size reported */
+    OSFM_E_STATE = -5,     /* call order violated (e.g. view not set) */
+    OSFM_E_NUMERIC = -6    /* BA: linear solve failed / non-finite values */
+} osfm_status;
+
+OSFM_API const char *osfm_last_error(void);
+OSFM_API int osfm_version(void);
+/* Number of visible HIP devices (0 when there is none). */
+OSFM_API int osfm_device_count(void);
+
+/* ====================================================================== */
+/* (A) Matching                                                            */
+/* ====================================================================== */
+
+/*
+ * Tunables of sfm::MatchingBase::Options (src/mve/sfm/matching_base.h:25-31)
+ * and sfm::bundler::Matching::Options (src/mve/sfm/bundler_matching.h:58-77),
+ * with the values the application hard-codes
+ * (src/matching/matching_mve.cpp:393-408).
+ */
+typedef struct osfm_match_options {
+    float sift_lowe_ratio;          /* 0.8f   matching_base.h:27 */
+    float sift_distance_threshold;  /* FLT_MAX                    */
+    float surf_lowe_ratio;          /* 0.7f   matching_base.h:29 */
+    float surf_distance_threshold;  /* FLT_MAX                    */
+    int32_t use_lowres_matching;    /* 1      matching_mve.cpp:400 */
+    int32_t num_lowres_features;    /* 500    bundler_matching.h:68 */
+    int32_t min_lowres_matches;     /* 5      bundler_matching.h:70 */
+    int32_t min_feature_matches;    /* 50     matching_mve.cpp:403 */
+    int32_t pairs_per_batch;        /* pairs resident in one launch group (0 = auto) */
+} osfm_match_options;
+
+OSFM_API int osfm_match_options_default(osfm_match_options *opts);
+
+typedef struct osfm_matcher osfm_matcher;
+
+/* Replaces the construction of an sfm::MatchingBase implementation
+ * (bundler::Matching::Matching, src/mve/sfm/bundler_matching.cc:27-42). */
+OSFM_API int osfm_match_create(int device, int num_views,
+    const osfm_match_options *opts, osfm_matcher **out);
+OSFM_API int osfm_match_destroy(osfm_matcher *m);
+
+/*
+ * Host quantisation of float descriptors, i.e. convert_descriptor of
+ * ExhaustiveMatching::init_sift / init_surf
+ * (src/mve/sfm/exhaustive_matching.cc:17-38, 76-112).
+ */
+OSFM_API int osfm_quantize_sift(const float *src, int n, uint16_t *dst);
+OSFM_API int osfm_quantize_surf(const float *src, int n, int16_t *dst);
+
+/*
+ * MatchingBase::init for one view (src/mve/sfm/matching_base.h:40,
+ * ExhaustiveMatching::init, exhaustive_matching.cc:55-74).  The _float
+ * variant takes Sift::Descriptor::data / Surf::Descriptor::data rows and
+ * quantises them like the reference; the plain variant takes the already
+ * quantised 16-bit lanes (0..255 / -127..127 [-128 accepted]).  Data is
+ * copied to the device; the caller keeps ownership of its buffers (the
+ * reference frees the float descriptors right after init,
+ * bundler_matching.cc:54-55).
+ */
+OSFM_API int osfm_match_set_view(osfm_matcher *m, int view,
+    const uint16_t *sift, int n_sift, const int16_t *surf, int n_surf);
+OSFM_API int osfm_match_set_view_float(osfm_matcher *m, int view,
+    const float *sift, int n_sift, const float *surf, int n_surf);
+OSFM_API int osfm_match_view_size(const osfm_matcher *m, int view,
+    int *n_sift, int *n_surf);
+
+/*
+ * MatchingBase::pairwise_match (matching_base.h:43-44;
+ * ExhaustiveMatching::pairwise_match, exhaustive_matching.cc:114-144):
+ * two-way SIFT + SURF matching, cross-check, combine.  m12 must hold
+ * n_sift+n_surf ints of view_1, m21 those of view_2; unsuccessful = -1.
+ * len12/len21 receive the lengths the reference's Result vectors would
+ * have (a descriptor type that view_1 lacks contributes an EMPTY list).
+ * Thread-safe (the reference calls it from an OpenMP loop).
+ */
+OSFM_API int osfm_match_pair(osfm_matcher *m, int view_1, int view_2,
+    int32_t *m12, int32_t *len12, int32_t *m21, int32_t *len21);
+
+/* MatchingBase::pairwise_match_lowres (matching_base.h:51-52;
+ * exhaustive_matching.cc:146-180). */
+OSFM_API int osfm_match_pair_lowres(osfm_matcher *m, int view_1, int view_2,
+    int num_features, int32_t *count);
+
+/*
+ * sfm::Matching::twoway_match<T> (src/mve/sfm/matching.h:148-159) on the
+ * stored descriptors of one type (0 = SIFT/unsigned short, 1 = SURF/short),
+ * optionally restricted to the first num_features descriptors of each view
+ * (0 = all): the two one-way lists BEFORE remove_inconsistent_matches.
+ * m12 holds n1 ints, m21 n2 ints.
+ */
+OSFM_API int osfm_match_twoway(osfm_matcher *m, int view_1, int view_2,
+    int descriptor_type, int num_features, int32_t *m12, int32_t *m21);
+
+typedef struct osfm_pair {
+    int32_t view_1;
+    int32_t view_2;
+} osfm_pair;
+
+enum {
+    OSFM_PAIR_MATCHED = 0,          /* survived both gates */
+    OSFM_PAIR_REJECTED_LOWRES = 1,  /* bundler_matching.cc:146-158 */
+    OSFM_PAIR_REJECTED_COUNT = 2,   /* bundler_matching.cc:163-172 */
+    OSFM_PAIR_SKIPPED_EMPTY = 3     /* a view without features, :96-99 */
+};
+
+typedef struct osfm_pair_result {
+    int32_t status;          /* OSFM_PAIR_* */
+    int32_t lowres_matches;  /* -1 when the low-res gate did not apply */
+    int32_t num_matches;     /* count_consistent_matches of the full match */
+    int32_t reserved;
+    int64_t offset;          /* first correspondence in `corr` (pairs of ints) */
+} osfm_pair_result;
+
+/*
+ * Batched form of bundler::Matching::compute up to (not including) the
+ * RANSAC stage (src/mve/sfm/bundler_matching.cc:58-192): low-res gate,
+ * pairwise_match, count_consistent_matches, threshold, and the ordered
+ * (feature_1, feature_2) correspondence list of bundler_matching.cc:176-192.
+ * Results are returned in INPUT order (deterministic, unlike the
+ * reference's thread-completion order).  corr receives 2 ints per
+ * correspondence; if more than `capacity` correspondences are produced the
+ * call fails with OSFM_E_CAPACITY and *total holds the required count.
+ */
+OSFM_API int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs,
+    int num_pairs, osfm_pair_result *results, int32_t *corr,
+    int64_t capacity, int64_t *total);
+
+/* (view_1 > view_2) of linear pair index i, bundler_matching.cc:92-93. */
+OSFM_API int osfm_pair_from_index(int64_t index, int32_t *view_1, int32_t *view_2);
+
+/* Statistics of the most recent osfm_match_all / osfm_match_pair call on
+ * this matcher, for bench.py's live roofline: device time of the dominant
+ * kernel (HIP events on the launch stream) and its launch count. */
+typedef struct osfm_match_stats {
+    double tile_kernel_ms;     /* sum over launches of the score-tile kernel */
+    int32_t tile_kernel_launches;
+    int32_t exact_scan_queries;  /* queries re-done by the wrap-exact kernel */
+    int64_t mac_count;           /* sum of n1*n2*D over the launches */
+    int64_t algorithmic_bytes;   /* descriptors read once + results written */
+} osfm_match_stats;
+OSFM_API int osfm_match_get_stats(const osfm_matcher *m, osfm_match_stats *out);
+
+/* ====================================================================== */
+/* (B) Bundle adjustment                                                   */
+/* ====================================================================== */
+
+enum {
+    OSFM_BA_MODEL_QUATERNION = 0,  /* solver 0: OrthoQuaternionCamera */
+    OSFM_BA_MODEL_EULER = 1        /* solvers 1-3: OrthographicCamera */
+};
+
+/*
+ * Flattened form of the arguments of orthosfm::runBundleAdjustment
+ * (src/bundle_adjustment/bundle_adjustment.h:18-20): cameras and tracks
+ * become structure-of-arrays.
+ *
+ * cam_params: num_cameras x 7 doubles.
+ *   QUATERNION: (qx, qy, qz, qw, offsetX, offsetY, scale)  -- Eigen coeff
+ *     order, OrthoQuaternionCamera.h:83-86
+ *   EULER:      (phi, theta, roll, offsetX, offsetY, scale, unused)
+ *     -- OrthographicCamera.h:122-127
+ * cam_const: num_cameras x 7 bytes, non-zero = parameter block constant
+ *   (camera fixed or per-block flag; OrthoQuaternionRecoAlgorithm.cpp:141-145,
+ *   OrthographicReconstructionAlgorithm.cpp:170-176).  For QUATERNION the
+ *   first byte covers the whole 4-vector rotation block.
+ * points: num_points x 4 homogeneous (Track::m_point, track.h:103), in/out.
+ * obs_*: one entry per residual block in the order of
+ *   bundle_adjustment.cpp:103-123; obs_point MUST be non-decreasing
+ *   (observations of a track are contiguous).
+ */
+typedef struct osfm_ba_problem {
+    int32_t model;
+    int32_t num_cameras;
+    int32_t num_points;
+    int32_t num_observations;
+    double *cam_params;
+    const uint8_t *cam_const;
+    const int32_t *img_width;
+    const int32_t *img_height;
+    double *points;
+    const double *obs_xy;
+    const int32_t *obs_camera;
+    const int32_t *obs_point;
+} osfm_ba_problem;
+
+/* Solver settings of bundle_adjustment.cpp:61-64,126-133 plus the Ceres
+ * defaults the reference leaves untouched. */
+typedef struct osfm_ba_options {
+    double huber_delta;               /* 1.0   HuberLoss(1.0) */
+    double function_tolerance;        /* 1e-6  */
+    double gradient_tolerance;        /* 1e-10 */
+    double parameter_tolerance;       /* 1e-10 */
+    int32_t max_num_iterations;       /* 100   */
+    int32_t optimize_points;          /* runBundleAdjustment's optimizePoints */
+    double initial_trust_region_radius;  /* 1e4  */
+    double max_trust_region_radius;      /* 1e16 */
+    double min_trust_region_radius;      /* 1e-32 */
+    double min_relative_decrease;        /* 1e-3 */
+    double min_lm_diagonal;              /* 1e-6 */
+    double max_lm_diagonal;              /* 1e32 */
+    int32_t jacobi_scaling;              /* 1 */
+    int32_t max_consecutive_invalid_steps;  /* 5 */
+    int32_t device;
+    int32_t verbose;
+} osfm_ba_options;
+
+enum {
+    OSFM_BA_CONVERGENCE_FUNCTION = 1,
+    OSFM_BA_CONVERGENCE_GRADIENT = 2,
+    OSFM_BA_CONVERGENCE_PARAMETER = 3,
+    OSFM_BA_CONVERGENCE_TRUST_REGION = 4,
+    OSFM_BA_NO_CONVERGENCE = 5,       /* max iterations */
+    OSFM_BA_FAILURE = 6
+};
+
+typedef struct osfm_ba_summary {
+    double initial_cost;
+    double final_cost;
+    int32_t num_iterations;           /* LM iterations incl. rejected, like Ceres' iteration count */
+    int32_t num_successful_steps;
+    int32_t num_unsuccessful_steps;
+    int32_t termination;              /* OSFM_BA_* */
+    double mean_point_change;         /* bundle_adjustment.cpp:150-160 printout */
+    double max_point_change;
+    double solve_ms;                  /* device+host wall time of the LM loop */
+    double linearize_kernel_ms;       /* summed device time of the linearise/Schur kernel */
+    int32_t linearize_launches;
+    int32_t reserved;
+} osfm_ba_summary;
+
+OSFM_API int osfm_ba_options_default(osfm_ba_options *opts);
+
+/* ceres::Solve on the problem runBundleAdjustment builds
+ * (bundle_adjustment.cpp:61-145): cam_params and points updated in place. */
+OSFM_API int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *o,
+    osfm_ba_summary *s);
+
+/* Batched ReconstructionAlgorithm::evaluateReprojectionError
+ * (OrthoQuaternionRecoAlgorithm.cpp:175-194,
+ * OrthographicReconstructionAlgorithm.cpp:204-223): err[k] = ||r_k||_2 in
+ * pixels; residuals (2 per observation) may be NULL. */
+OSFM_API int osfm_ba_reprojection_errors(const osfm_ba_problem *p, int device,
+    double *err, double *residuals);
+
+/* triangulateOrthographicTracks (src/triangulation/triangulation.cpp:44-93)
+ * as called from runBundleAdjustment (bundle_adjustment.cpp:77-83):
+ * points[j] = least-squares ray intersection over the track's observations,
+ * point_valid[j] = 0 when fewer than two rays. */
+OSFM_API int osfm_ba_triangulate(const osfm_ba_problem *p, int device,
+    uint8_t *point_valid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSFM_HIP_H */

@@ -1,0 +1,144 @@
+"""ctypes binding of the C ABI in include/osfm_hip.h (libosfm_hip.so).
+
+There is no fallback: if the HIP library is not built the import of this
+module raises, and every compute entry point raises OsfmError when the
+library reports an error (e.g. no gfx950 device).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libosfm_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(hipcc --offload-arch=gfx950). orthosfm_amd has no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+
+class OsfmError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"osfm status {status}: {msg}")
+        self.status = status
+
+
+OK, E_ARG, E_DEVICE, E_RANGE, E_CAPACITY, E_STATE, E_NUMERIC = 0, -1, -2, -3, -4, -5, -6
+PAIR_MATCHED, PAIR_REJECTED_LOWRES, PAIR_REJECTED_COUNT, PAIR_SKIPPED_EMPTY = 0, 1, 2, 3
+
+
+class MatchOptions(C.Structure):
+    _fields_ = [("sift_lowe_ratio", C.c_float), ("sift_distance_threshold", C.c_float),
+                ("surf_lowe_ratio", C.c_float), ("surf_distance_threshold", C.c_float),
+                ("use_lowres_matching", C.c_int32), ("num_lowres_features", C.c_int32),
+                ("min_lowres_matches", C.c_int32), ("min_feature_matches", C.c_int32),
+                ("pairs_per_batch", C.c_int32)]
+
+
+class Pair(C.Structure):
+    _fields_ = [("view_1", C.c_int32), ("view_2", C.c_int32)]
+
+
+class PairResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("lowres_matches", C.c_int32),
+                ("num_matches", C.c_int32), ("reserved", C.c_int32), ("offset", C.c_int64)]
+
+
+class MatchStats(C.Structure):
+    _fields_ = [("tile_kernel_ms", C.c_double), ("tile_kernel_launches", C.c_int32),
+                ("exact_scan_queries", C.c_int32), ("mac_count", C.c_int64),
+                ("algorithmic_bytes", C.c_int64)]
+
+
+class BaProblem(C.Structure):
+    _fields_ = [("model", C.c_int32), ("num_cameras", C.c_int32), ("num_points", C.c_int32),
+                ("num_observations", C.c_int32),
+                ("cam_params", C.c_void_p), ("cam_const", C.c_void_p),
+                ("img_width", C.c_void_p), ("img_height", C.c_void_p),
+                ("points", C.c_void_p), ("obs_xy", C.c_void_p),
+                ("obs_camera", C.c_void_p), ("obs_point", C.c_void_p)]
+
+
+class BaOptions(C.Structure):
+    _fields_ = [("huber_delta", C.c_double), ("function_tolerance", C.c_double),
+                ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("max_num_iterations", C.c_int32), ("optimize_points", C.c_int32),
+                ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+                ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
+                ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+                ("jacobi_scaling", C.c_int32), ("max_consecutive_invalid_steps", C.c_int32),
+                ("device", C.c_int32), ("verbose", C.c_int32)]
+
+
+class BaSummary(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("num_iterations", C.c_int32), ("num_successful_steps", C.c_int32),
+                ("num_unsuccessful_steps", C.c_int32), ("termination", C.c_int32),
+                ("mean_point_change", C.c_double), ("max_point_change", C.c_double),
+                ("solve_ms", C.c_double), ("linearize_kernel_ms", C.c_double),
+                ("linearize_launches", C.c_int32), ("reserved", C.c_int32)]
+
+
+# every symbol include/osfm_hip.h declares (checked by tests/test_capi_symbols.py)
+EXPORTS = [
+    "osfm_last_error", "osfm_version", "osfm_device_count",
+    "osfm_match_options_default", "osfm_match_create", "osfm_match_destroy",
+    "osfm_quantize_sift", "osfm_quantize_surf",
+    "osfm_match_set_view", "osfm_match_set_view_float", "osfm_match_view_size",
+    "osfm_match_pair", "osfm_match_pair_lowres", "osfm_match_twoway", "osfm_match_all",
+    "osfm_pair_from_index", "osfm_match_get_stats",
+    "osfm_ba_options_default", "osfm_ba_solve", "osfm_ba_reprojection_errors",
+    "osfm_ba_triangulate",
+]
+
+lib.osfm_last_error.restype = C.c_char_p
+lib.osfm_version.restype = C.c_int
+lib.osfm_device_count.restype = C.c_int
+
+
+def last_error() -> str:
+    return lib.osfm_last_error().decode()
+
+
+def check(status):
+    if status != OK:
+        raise OsfmError(status, last_error())
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype)) if a is not None and a.size else None
+
+
+def device_count() -> int:
+    return lib.osfm_device_count()
+
+
+def default_match_options() -> MatchOptions:
+    o = MatchOptions()
+    check(lib.osfm_match_options_default(C.byref(o)))
+    return o
+
+
+def quantize_sift(f: np.ndarray) -> np.ndarray:
+    f = np.ascontiguousarray(f, dtype=np.float32).reshape(-1, 128)
+    out = np.zeros(f.shape, dtype=np.uint16)
+    check(lib.osfm_quantize_sift(_ptr(f, C.c_float), f.shape[0], _ptr(out, C.c_uint16)))
+    return out
+
+
+def quantize_surf(f: np.ndarray) -> np.ndarray:
+    f = np.ascontiguousarray(f, dtype=np.float32).reshape(-1, 64)
+    out = np.zeros(f.shape, dtype=np.int16)
+    check(lib.osfm_quantize_surf(_ptr(f, C.c_float), f.shape[0], _ptr(out, C.c_int16)))
+    return out
+
+
+def pair_from_index(i: int):
+    a, b = C.c_int32(), C.c_int32()
+    check(lib.osfm_pair_from_index(C.c_int64(i), C.byref(a), C.byref(b)))
+    return a.value, b.value

@@ -1,0 +1,698 @@
+// C-ABI implementation of the matching path (include/osfm_hip.h, section A).
+// Host orchestration only: every inner product, reduction, ratio test,
+// cross-check and compaction runs in the kernels of match_kernels.hip.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "match_kernels.h"
+#include "osfm_common.h"
+
+namespace osfm {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+namespace {
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct ViewData {
+    bool set = false;
+    int ns = 0, nu = 0;
+    int ns_pad = 0, nu_pad = 0;
+    DeviceBuffer sift, sift_corr, surf, surf_corr;
+    int surf_norm2_max = 0;
+};
+
+// Host twin of matching.h:126-127,138-143 for every (d1, d2): the smallest
+// (even) d1 that the float ratio test rejects for a given d2.
+void build_lowe_table(float lowe, bool is_signed, std::vector<int32_t> *tab)
+{
+    const volatile float sq = lowe * lowe;     // MATH_POW2 in float
+    const float sq_lowe = sq;
+    const int dmax = is_signed ? 32258 : 65534;
+    tab->assign(32768, 0x7fffffff);
+    for (int d2 = 0; d2 <= dmax; d2 += 2) {
+        // float(d1)/float(d2) is monotone in d1: binary search on even d1
+        int lo = 0, hi = dmax / 2 + 1;   // in units of 2; hi = "never rejected"
+        while (lo < hi) {
+            const int mid = (lo + hi) / 2;
+            const float ratio = static_cast<float>(2 * mid) / static_cast<float>(d2);
+            if (ratio > sq_lowe) hi = mid; else lo = mid + 1;
+        }
+        (*tab)[d2 / 2] = lo > dmax / 2 ? 0x7fffffff : 2 * lo;
+    }
+}
+
+int max_d1_for(float dist_thres, bool is_signed)
+{
+    const volatile float sq = dist_thres * dist_thres;
+    const float sq_dist = sq;
+    const int dmax = is_signed ? 32258 : 65534;
+    int best = -1;
+    // largest d with !(float(d) > sq_dist); monotone
+    int lo = 0, hi = dmax;
+    if (!(static_cast<float>(0) > sq_dist)) {
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) / 2;
+            if (static_cast<float>(mid) > sq_dist) hi = mid - 1; else lo = mid;
+        }
+        best = lo;
+    }
+    return best;
+}
+
+}  // namespace
+}  // namespace osfm
+
+using namespace osfm;
+
+struct osfm_matcher {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    osfm_match_options opts;
+    std::vector<ViewData> views;
+    DeviceBuffer lowe_sift, lowe_surf;
+    LoweTable tab_sift, tab_surf;
+    std::mutex mu;
+
+    // scratch (grow-only)
+    DeviceBuffer d_problems[2], rowparts, colparts, out, keep, mark_off[2], counts[2];
+    DeviceBuffer exact_items, exact_count, stage_in, flags;
+    DeviceBuffer d_m12_off, d_len12, d_corr_off, d_keep_pair, d_corr;
+    hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+
+    osfm_match_stats stats;
+};
+
+namespace {
+
+struct PairPlan {
+    int v1, v2;
+    int ns1, nu1, ns2, nu2;      // (possibly low-res limited) sizes used
+    bool has_sift, has_surf;     // problems generated
+    int64_t off12, off21;        // into the combined output buffer (ints)
+    int len12, len21;
+    int prob_index[2];           // index into the per-type problem list or -1
+};
+
+struct BatchResult {
+    std::vector<PairPlan> plans;
+    std::vector<int32_t> counts;     // mutual matches per pair (sift + surf)
+    int64_t out_ints = 0;
+};
+
+int check_view(const osfm_matcher *m, int v, const char *what)
+{
+    if (v < 0 || v >= (int)m->views.size()) {
+        set_error("%s: view id %d out of range [0, %zu)", what, v, m->views.size());
+        return OSFM_E_ARG;
+    }
+    if (!m->views[v].set) {
+        set_error("%s: view %d has not been set", what, v);
+        return OSFM_E_STATE;
+    }
+    return OSFM_OK;
+}
+
+// Runs one batch of pairs through the device pipeline.
+//   lowres_limit > 0 : pairwise_match_lowres semantics (SIFT if view_1 has
+//                      SIFT, else SURF; first `limit` descriptors; count only)
+//   lowres_limit == 0: pairwise_match semantics (both types, cross-check
+//                      applied, combined lists left in m->out)
+struct BatchMode {
+    int limit = 0;            // > 0: only the first `limit` descriptors of each view
+    bool lowres = false;      // pairwise_match_lowres: SIFT if view_1 has SIFT, else SURF
+    bool apply = true;        // remove_inconsistent_matches + combine offsets
+    int type_mask = 3;        // bit 0: SIFT, bit 1: SURF
+};
+
+int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const BatchMode &mode,
+    BatchResult *res)
+{
+    const int lowres_limit = mode.limit;
+    res->plans.assign(num_pairs, PairPlan());
+    res->counts.assign(num_pairs, 0);
+    std::vector<MatchProblem> probs[2];
+    std::vector<int64_t> mark_off[2];
+    int64_t out_ints = 0, rowpart_recs = 0, colpart_recs = 0, keep_bytes = 0, total_queries = 0;
+    int total_blocks[2] = {0, 0}, max_n[2] = {0, 0};
+    int64_t macs = 0, alg_bytes = 0;
+
+    for (int p = 0; p < num_pairs; ++p) {
+        PairPlan &pl = res->plans[p];
+        pl.v1 = pairs[p].view_1; pl.v2 = pairs[p].view_2;
+        OSFM_RETURN_IF(check_view(m, pl.v1, "match"));
+        OSFM_RETURN_IF(check_view(m, pl.v2, "match"));
+        const ViewData &a = m->views[pl.v1], &b = m->views[pl.v2];
+        pl.ns1 = a.ns; pl.nu1 = a.nu; pl.ns2 = b.ns; pl.nu2 = b.nu;
+        pl.has_sift = a.ns > 0 && (mode.type_mask & 1);
+        pl.has_surf = a.nu > 0 && (mode.type_mask & 2);
+        // exhaustive_matching.cc:153-177: SIFT takes precedence
+        if (mode.lowres && pl.has_sift) pl.has_surf = false;
+        if (lowres_limit > 0) {
+            pl.ns1 = std::min(pl.ns1, lowres_limit); pl.ns2 = std::min(pl.ns2, lowres_limit);
+            pl.nu1 = std::min(pl.nu1, lowres_limit); pl.nu2 = std::min(pl.nu2, lowres_limit);
+        }
+        const int e1 = pl.has_sift ? pl.ns1 : 0;      // sift entries on side 1 / 2
+        const int e2 = pl.has_sift ? pl.ns2 : 0;
+        pl.len12 = e1 + (pl.has_surf ? pl.nu1 : 0);
+        pl.len21 = e2 + (pl.has_surf ? pl.nu2 : 0);
+        pl.off12 = out_ints; out_ints += round_up(pl.len12, 4);
+        pl.off21 = out_ints; out_ints += round_up(pl.len21, 4);
+        pl.prob_index[0] = pl.prob_index[1] = -1;
+        for (int type = 0; type < 2; ++type) {
+            if (type == 0 ? !pl.has_sift : !pl.has_surf) continue;
+            MatchProblem pr;
+            memset(&pr, 0, sizeof(pr));
+            pr.n1 = type == 0 ? pl.ns1 : pl.nu1;
+            pr.n2 = type == 0 ? pl.ns2 : pl.nu2;
+            pr.A = (type == 0 ? a.sift : a.surf).as<int8_t>();
+            pr.B = (type == 0 ? b.sift : b.surf).as<int8_t>();
+            pr.corrA = (type == 0 ? a.sift_corr : a.surf_corr).as<int32_t>();
+            pr.corrB = (type == 0 ? b.sift_corr : b.surf_corr).as<int32_t>();
+            const bool empty = pr.n1 == 0 || pr.n2 == 0;
+            pr.nrb = empty ? 0 : (pr.n1 + kRowsPerBlock - 1) / kRowsPerBlock;
+            pr.nseg = empty ? 0 : (pr.n2 + kSegCols - 1) / kSegCols;
+            pr.n2stride = round_up(pr.n2, 64);
+            pr.block_start = total_blocks[type];
+            total_blocks[type] += pr.nrb * pr.nseg;
+            pr.rowpart_off = rowpart_recs;
+            rowpart_recs += (int64_t)pr.nseg * pr.nrb * kRowsPerBlock;
+            pr.colpart_off = colpart_recs;
+            colpart_recs += (int64_t)pr.nrb * pr.n2stride;
+            // placed by offset into m->out after allocation (store offsets now)
+            pr.m12 = reinterpret_cast<int32_t *>(pl.off12 + (type == 0 ? 0 : e1));
+            pr.m21 = reinterpret_cast<int32_t *>(pl.off21 + (type == 0 ? 0 : e2));
+            // combine_results offsets (matching.cc:74-86) -- SURF entries only
+            pr.out_off12 = (type == 1 && mode.apply) ? e2 : 0;
+            pr.out_off21 = (type == 1 && mode.apply) ? e1 : 0;
+            if (type == 1) {
+                // exactness of the int32 fast path needs every 16-bit lane sum
+                // in range: guaranteed when |q|^2 * |c|^2 <= 32767^2
+                const long long bound = (long long)a.surf_norm2_max * (long long)b.surf_norm2_max;
+                pr.force_exact = bound > 32767LL * 32767LL ? 1 : 0;
+            }
+            pl.prob_index[type] = (int)probs[type].size();
+            mark_off[type].push_back(keep_bytes); keep_bytes += round_up(pr.n1, 16);
+            mark_off[type].push_back(keep_bytes); keep_bytes += round_up(pr.n2, 16);
+            max_n[type] = std::max(max_n[type], std::max(pr.n1, pr.n2));
+            total_queries += pr.n1 + pr.n2;
+            probs[type].push_back(pr);
+            if (!empty) {
+                const int dim = type == 0 ? 128 : 64;
+                macs += (int64_t)pr.n1 * pr.n2 * dim;
+                alg_bytes += (int64_t)(pr.n1 + pr.n2) * (dim + 4);
+            }
+        }
+    }
+    res->out_ints = out_ints;
+
+    // --- scratch ---------------------------------------------------------
+    OSFM_RETURN_IF(m->out.reserve((size_t)std::max<int64_t>(out_ints, 4) * 4));
+    OSFM_RETURN_IF(m->rowparts.reserve((size_t)std::max<int64_t>(rowpart_recs, 1) * sizeof(RowPart)));
+    OSFM_RETURN_IF(m->colparts.reserve((size_t)std::max<int64_t>(colpart_recs, 1) * sizeof(ColPart)));
+    OSFM_RETURN_IF(m->keep.reserve((size_t)std::max<int64_t>(keep_bytes, 16)));
+    OSFM_RETURN_IF(m->exact_items.reserve((size_t)std::max<int64_t>(total_queries, 1) * sizeof(ExactItem)));
+    OSFM_RETURN_IF(m->exact_count.reserve(16));
+    hipStream_t s = m->stream;
+    int32_t *d_out = m->out.as<int32_t>();
+    OSFM_HIP_CHECK(hipMemsetAsync(d_out, 0xff, (size_t)std::max<int64_t>(out_ints, 4) * 4, s));
+
+    OSFM_HIP_CHECK(hipMemsetAsync(m->exact_count.ptr, 0, 16, s));
+    bool timed[2] = {false, false};
+    for (int type = 0; type < 2; ++type) {
+        const int np = (int)probs[type].size();
+        if (np == 0) continue;
+        for (auto &pr : probs[type]) {
+            pr.m12 = d_out + reinterpret_cast<intptr_t>(pr.m12);
+            pr.m21 = d_out + reinterpret_cast<intptr_t>(pr.m21);
+        }
+        OSFM_RETURN_IF(m->d_problems[type].reserve(np * sizeof(MatchProblem)));
+        OSFM_RETURN_IF(m->mark_off[type].reserve(np * 2 * sizeof(int64_t)));
+        OSFM_RETURN_IF(m->counts[type].reserve(np * sizeof(int32_t)));
+        OSFM_HIP_CHECK(hipMemcpyAsync(m->d_problems[type].ptr, probs[type].data(),
+            np * sizeof(MatchProblem), hipMemcpyHostToDevice, s));
+        OSFM_HIP_CHECK(hipMemcpyAsync(m->mark_off[type].ptr, mark_off[type].data(),
+            np * 2 * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        OSFM_HIP_CHECK(hipMemsetAsync(m->counts[type].ptr, 0, np * sizeof(int32_t), s));
+        const MatchProblem *dp = m->d_problems[type].as<MatchProblem>();
+        const LoweTable tab = type == 0 ? m->tab_sift : m->tab_surf;
+        const int ecap = (int)std::min<int64_t>(total_queries, 0x7fffffff);
+        int32_t *ecount = m->exact_count.as<int32_t>() + type;
+
+        if (total_blocks[type] > 0) { OSFM_HIP_CHECK(hipEventRecord(m->ev[type][0], s)); timed[type] = true; }
+        launch_match_tiles(type == 0 ? 8 : 4, dp, np, total_blocks[type],
+            m->rowparts.as<RowPart>(), m->colparts.as<ColPart>(), s);
+        if (timed[type]) OSFM_HIP_CHECK(hipEventRecord(m->ev[type][1], s));
+        launch_match_finish(dp, np, max_n[type], m->rowparts.as<RowPart>(),
+            m->colparts.as<ColPart>(), tab, 0, m->exact_items.as<ExactItem>(), ecount, ecap, s);
+        launch_exact_scan(type == 0 ? 128 : 64, dp, m->exact_items.as<ExactItem>(), ecount, ecap,
+            tab, s);
+        launch_cross_check_mark(dp, np, max_n[type], m->keep.as<uint8_t>(), m->keep.as<uint8_t>(),
+            m->mark_off[type].as<int64_t>(), m->counts[type].as<int32_t>(), s);
+        if (mode.apply)
+            launch_cross_check_apply(dp, np, max_n[type], m->keep.as<uint8_t>(),
+                m->keep.as<uint8_t>(), m->mark_off[type].as<int64_t>(), s);
+        OSFM_HIP_CHECK(hipGetLastError());
+    }
+
+    // --- counts back -------------------------------------------------------
+    std::vector<int32_t> hc[2];
+    int32_t hexact[4] = {0, 0, 0, 0};
+    for (int type = 0; type < 2; ++type) {
+        hc[type].resize(probs[type].size());
+        if (!hc[type].empty())
+            OSFM_HIP_CHECK(hipMemcpyAsync(hc[type].data(), m->counts[type].ptr,
+                hc[type].size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    }
+    OSFM_HIP_CHECK(hipMemcpyAsync(hexact, m->exact_count.ptr, 16, hipMemcpyDeviceToHost, s));
+    OSFM_HIP_CHECK(hipStreamSynchronize(s));
+    for (int p = 0; p < num_pairs; ++p) {
+        int c = 0;
+        for (int type = 0; type < 2; ++type)
+            if (res->plans[p].prob_index[type] >= 0) c += hc[type][res->plans[p].prob_index[type]];
+        res->counts[p] = c;
+    }
+    for (int type = 0; type < 2; ++type) {
+        if (!timed[type]) continue;
+        float ms = 0.f;
+        OSFM_HIP_CHECK(hipEventElapsedTime(&ms, m->ev[type][0], m->ev[type][1]));
+        m->stats.tile_kernel_ms += ms;
+        m->stats.tile_kernel_launches += 1;
+    }
+    m->stats.exact_scan_queries += hexact[0] + hexact[1];
+    m->stats.mac_count += macs;
+    m->stats.algorithmic_bytes += alg_bytes;
+    return OSFM_OK;
+}
+
+int upload_view(osfm_matcher *m, int view, const uint16_t *sift, int n_sift, const int16_t *surf,
+    int n_surf)
+{
+    if (view < 0 || view >= (int)m->views.size()) {
+        set_error("set_view: view id %d out of range", view);
+        return OSFM_E_ARG;
+    }
+    if (n_sift < 0 || n_surf < 0 || (n_sift > 0 && !sift) || (n_surf > 0 && !surf)) {
+        set_error("set_view: null descriptors / negative count");
+        return OSFM_E_ARG;
+    }
+    ViewData &v = m->views[view];
+    hipStream_t s = m->stream;
+    v.set = false;
+    v.ns = n_sift; v.nu = n_surf;
+    v.ns_pad = round_up(std::max(n_sift, 1), kRowsPerBlock);
+    v.nu_pad = round_up(std::max(n_surf, 1), kRowsPerBlock);
+    OSFM_RETURN_IF(v.sift.reserve((size_t)v.ns_pad * 128));
+    OSFM_RETURN_IF(v.sift_corr.reserve((size_t)v.ns_pad * 4));
+    OSFM_RETURN_IF(v.surf.reserve((size_t)v.nu_pad * 64));
+    OSFM_RETURN_IF(v.surf_corr.reserve((size_t)v.nu_pad * 4));
+    const size_t b_sift = (size_t)n_sift * 128 * 2, b_surf = (size_t)n_surf * 64 * 2;
+    OSFM_RETURN_IF(m->stage_in.reserve(std::max<size_t>(b_sift + b_surf, 16)));
+    OSFM_RETURN_IF(m->flags.reserve(16));
+    OSFM_HIP_CHECK(hipMemsetAsync(m->flags.ptr, 0, 16, s));
+    char *stage = m->stage_in.as<char>();
+    if (b_sift) OSFM_HIP_CHECK(hipMemcpyAsync(stage, sift, b_sift, hipMemcpyHostToDevice, s));
+    if (b_surf) OSFM_HIP_CHECK(hipMemcpyAsync(stage + b_sift, surf, b_surf, hipMemcpyHostToDevice, s));
+    int32_t *flags = m->flags.as<int32_t>();
+    launch_prepare_sift(reinterpret_cast<const uint16_t *>(stage), n_sift, v.ns_pad,
+        v.sift.as<int8_t>(), v.sift_corr.as<int32_t>(), flags + 0, s);
+    launch_prepare_surf(reinterpret_cast<const int16_t *>(stage + b_sift), n_surf, v.nu_pad,
+        v.surf.as<int8_t>(), v.surf_corr.as<int32_t>(), flags + 1, flags + 0, s);
+    OSFM_HIP_CHECK(hipGetLastError());
+    int32_t h[4];
+    OSFM_HIP_CHECK(hipMemcpyAsync(h, flags, 16, hipMemcpyDeviceToHost, s));
+    OSFM_HIP_CHECK(hipStreamSynchronize(s));
+    if (h[0]) {
+        set_error("set_view: descriptor value outside the quantised range "
+                  "(SIFT 0..255, SURF -128..127) in view %d", view);
+        return OSFM_E_RANGE;
+    }
+    v.surf_norm2_max = h[1];
+    v.set = true;
+    return OSFM_OK;
+}
+
+void reset_stats(osfm_matcher *m) { memset(&m->stats, 0, sizeof(m->stats)); }
+
+}  // namespace
+
+extern "C" {
+
+const char *osfm_last_error(void) { return g_last_error.c_str(); }
+int osfm_version(void) { return 100; }
+
+int osfm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int osfm_match_options_default(osfm_match_options *o)
+{
+    if (!o) { set_error("options_default: null"); return OSFM_E_ARG; }
+    o->sift_lowe_ratio = 0.8f;
+    o->sift_distance_threshold = FLT_MAX;
+    o->surf_lowe_ratio = 0.7f;
+    o->surf_distance_threshold = FLT_MAX;
+    o->use_lowres_matching = 1;
+    o->num_lowres_features = 500;
+    o->min_lowres_matches = 5;
+    o->min_feature_matches = 50;
+    o->pairs_per_batch = 0;
+    return OSFM_OK;
+}
+
+int osfm_match_create(int device, int num_views, const osfm_match_options *opts, osfm_matcher **out)
+{
+    if (!out || num_views < 0) { set_error("match_create: bad arguments"); return OSFM_E_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("match_create: no HIP device available (this backend has no CPU fallback)");
+        return OSFM_E_DEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        set_error("match_create: device %d out of range [0,%d)", device, ndev);
+        return OSFM_E_ARG;
+    }
+    OSFM_HIP_CHECK(hipSetDevice(device));
+    osfm_matcher *m = new osfm_matcher();
+    m->device = device;
+    if (opts) m->opts = *opts; else osfm_match_options_default(&m->opts);
+    m->views.resize(num_views);
+    reset_stats(m);
+    OSFM_HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) OSFM_HIP_CHECK(hipEventCreate(&m->ev[i][j]));
+    std::vector<int32_t> t;
+    build_lowe_table(m->opts.sift_lowe_ratio, false, &t);
+    OSFM_RETURN_IF(m->lowe_sift.reserve(t.size() * 4));
+    OSFM_HIP_CHECK(hipMemcpy(m->lowe_sift.ptr, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    build_lowe_table(m->opts.surf_lowe_ratio, true, &t);
+    OSFM_RETURN_IF(m->lowe_surf.reserve(t.size() * 4));
+    OSFM_HIP_CHECK(hipMemcpy(m->lowe_surf.ptr, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    m->tab_sift.reject_from = m->lowe_sift.as<int32_t>();
+    m->tab_sift.max_d1 = max_d1_for(m->opts.sift_distance_threshold, false);
+    m->tab_sift.is_signed = 0;
+    m->tab_surf.reject_from = m->lowe_surf.as<int32_t>();
+    m->tab_surf.max_d1 = max_d1_for(m->opts.surf_distance_threshold, true);
+    m->tab_surf.is_signed = 1;
+    *out = m;
+    return OSFM_OK;
+}
+
+int osfm_match_destroy(osfm_matcher *m)
+{
+    if (!m) return OSFM_OK;
+    (void)hipSetDevice(m->device);
+    (void)hipStreamSynchronize(m->stream);
+    for (auto &v : m->views) { v.sift.release(); v.sift_corr.release(); v.surf.release(); v.surf_corr.release(); }
+    DeviceBuffer *bufs[] = {&m->lowe_sift, &m->lowe_surf, &m->d_problems[0], &m->d_problems[1],
+        &m->rowparts, &m->colparts, &m->out, &m->keep, &m->mark_off[0], &m->mark_off[1],
+        &m->counts[0], &m->counts[1], &m->exact_items, &m->exact_count, &m->stage_in, &m->flags,
+        &m->d_m12_off, &m->d_len12, &m->d_corr_off, &m->d_keep_pair, &m->d_corr};
+    for (auto *b : bufs) b->release();
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            if (m->ev[i][j]) (void)hipEventDestroy(m->ev[i][j]);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+    return OSFM_OK;
+}
+
+// exhaustive_matching.cc:17-27 with math::clamp / math::round in float.
+int osfm_quantize_sift(const float *src, int n, uint16_t *dst)
+{
+    if (n < 0 || (n > 0 && (!src || !dst))) { set_error("quantize_sift: bad arguments"); return OSFM_E_ARG; }
+    for (size_t i = 0; i < (size_t)n * 128; ++i) {
+        float v = src[i];
+        v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+        v *= 255.0f;
+        v = v > 0.0f ? floorf(v + 0.5f) : ceilf(v - 0.5f);
+        dst[i] = (uint16_t)(unsigned char)v;
+    }
+    return OSFM_OK;
+}
+
+// exhaustive_matching.cc:29-38.
+int osfm_quantize_surf(const float *src, int n, int16_t *dst)
+{
+    if (n < 0 || (n > 0 && (!src || !dst))) { set_error("quantize_surf: bad arguments"); return OSFM_E_ARG; }
+    for (size_t i = 0; i < (size_t)n * 64; ++i) {
+        float v = src[i];
+        v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);
+        v *= 127.0f;
+        v = v > 0.0f ? floorf(v + 0.5f) : ceilf(v - 0.5f);
+        dst[i] = (int16_t)(signed char)v;
+    }
+    return OSFM_OK;
+}
+
+int osfm_match_set_view(osfm_matcher *m, int view, const uint16_t *sift, int n_sift,
+    const int16_t *surf, int n_surf)
+{
+    if (!m) { set_error("set_view: null matcher"); return OSFM_E_ARG; }
+    std::lock_guard<std::mutex> lock(m->mu);
+    OSFM_HIP_CHECK(hipSetDevice(m->device));
+    return upload_view(m, view, sift, n_sift, surf, n_surf);
+}
+
+int osfm_match_set_view_float(osfm_matcher *m, int view, const float *sift, int n_sift,
+    const float *surf, int n_surf)
+{
+    if (!m) { set_error("set_view_float: null matcher"); return OSFM_E_ARG; }
+    if (n_sift < 0 || n_surf < 0) { set_error("set_view_float: negative count"); return OSFM_E_ARG; }
+    std::vector<uint16_t> qs((size_t)n_sift * 128);
+    std::vector<int16_t> qu((size_t)n_surf * 64);
+    OSFM_RETURN_IF(osfm_quantize_sift(sift, n_sift, qs.data()));
+    OSFM_RETURN_IF(osfm_quantize_surf(surf, n_surf, qu.data()));
+    return osfm_match_set_view(m, view, qs.data(), n_sift, qu.data(), n_surf);
+}
+
+int osfm_match_view_size(const osfm_matcher *m, int view, int *n_sift, int *n_surf)
+{
+    if (!m) { set_error("view_size: null matcher"); return OSFM_E_ARG; }
+    OSFM_RETURN_IF(check_view(m, view, "view_size"));
+    if (n_sift) *n_sift = m->views[view].ns;
+    if (n_surf) *n_surf = m->views[view].nu;
+    return OSFM_OK;
+}
+
+int osfm_match_pair(osfm_matcher *m, int view_1, int view_2, int32_t *m12, int32_t *len12,
+    int32_t *m21, int32_t *len21)
+{
+    if (!m || !m12 || !m21) { set_error("match_pair: null argument"); return OSFM_E_ARG; }
+    std::lock_guard<std::mutex> lock(m->mu);
+    OSFM_HIP_CHECK(hipSetDevice(m->device));
+    reset_stats(m);
+    osfm_pair pr = {view_1, view_2};
+    BatchResult res;
+    OSFM_RETURN_IF(run_batch(m, &pr, 1, BatchMode(), &res));
+    const PairPlan &pl = res.plans[0];
+    const int32_t *d_out = m->out.as<int32_t>();
+    if (pl.len12) OSFM_HIP_CHECK(hipMemcpy(m12, d_out + pl.off12, (size_t)pl.len12 * 4, hipMemcpyDeviceToHost));
+    if (pl.len21) OSFM_HIP_CHECK(hipMemcpy(m21, d_out + pl.off21, (size_t)pl.len21 * 4, hipMemcpyDeviceToHost));
+    if (len12) *len12 = pl.len12;
+    if (len21) *len21 = pl.len21;
+    return OSFM_OK;
+}
+
+int osfm_match_pair_lowres(osfm_matcher *m, int view_1, int view_2, int num_features, int32_t *count)
+{
+    if (!m || !count) { set_error("match_pair_lowres: null argument"); return OSFM_E_ARG; }
+    if (num_features <= 0) { *count = 0; return OSFM_OK; }
+    std::lock_guard<std::mutex> lock(m->mu);
+    OSFM_HIP_CHECK(hipSetDevice(m->device));
+    reset_stats(m);
+    osfm_pair pr = {view_1, view_2};
+    BatchResult res;
+    BatchMode mode;
+    mode.limit = num_features; mode.lowres = true; mode.apply = false;
+    OSFM_RETURN_IF(run_batch(m, &pr, 1, mode, &res));
+    *count = res.counts[0];
+    return OSFM_OK;
+}
+
+int osfm_match_twoway(osfm_matcher *m, int view_1, int view_2, int descriptor_type, int num_features,
+    int32_t *m12, int32_t *m21)
+{
+    if (!m || !m12 || !m21 || (descriptor_type != 0 && descriptor_type != 1) || num_features < 0) {
+        set_error("match_twoway: bad argument");
+        return OSFM_E_ARG;
+    }
+    std::lock_guard<std::mutex> lock(m->mu);
+    OSFM_HIP_CHECK(hipSetDevice(m->device));
+    reset_stats(m);
+    osfm_pair pr = {view_1, view_2};
+    BatchResult res;
+    BatchMode mode;
+    mode.limit = num_features; mode.apply = false; mode.type_mask = 1 << descriptor_type;
+    OSFM_RETURN_IF(run_batch(m, &pr, 1, mode, &res));
+    const PairPlan &pl = res.plans[0];
+    // With an empty set 1 Matching::twoway_match yields matches_1_2 of size 0
+    // and matches_2_1 of size n2 filled with -1 (matching.h:121-124).
+    const ViewData &a = m->views[view_1], &b = m->views[view_2];
+    int n1 = descriptor_type == 0 ? a.ns : a.nu, n2 = descriptor_type == 0 ? b.ns : b.nu;
+    if (num_features > 0) { n1 = std::min(n1, num_features); n2 = std::min(n2, num_features); }
+    if (n1 == 0) { for (int i = 0; i < n2; ++i) m21[i] = -1; return OSFM_OK; }
+    const int32_t *d_out = m->out.as<int32_t>();
+    if (pl.len12) OSFM_HIP_CHECK(hipMemcpy(m12, d_out + pl.off12, (size_t)pl.len12 * 4, hipMemcpyDeviceToHost));
+    if (pl.len21) OSFM_HIP_CHECK(hipMemcpy(m21, d_out + pl.off21, (size_t)pl.len21 * 4, hipMemcpyDeviceToHost));
+    return OSFM_OK;
+}
+
+int osfm_pair_from_index(int64_t index, int32_t *view_1, int32_t *view_2)
+{
+    if (index < 0 || !view_1 || !view_2) { set_error("pair_from_index: bad arguments"); return OSFM_E_ARG; }
+    // bundler_matching.cc:92-93
+    const int a = (int)(0.5 + std::sqrt(0.25 + 2.0 * (double)index));
+    *view_1 = a;
+    *view_2 = (int)index - a * (a - 1) / 2;
+    return OSFM_OK;
+}
+
+int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_pair_result *results,
+    int32_t *corr, int64_t capacity, int64_t *total)
+{
+    if (!m || (num_pairs > 0 && (!pairs || !results)) || num_pairs < 0 || capacity < 0 ||
+        (capacity > 0 && !corr)) {
+        set_error("match_all: bad arguments");
+        return OSFM_E_ARG;
+    }
+    std::lock_guard<std::mutex> lock(m->mu);
+    OSFM_HIP_CHECK(hipSetDevice(m->device));
+    reset_stats(m);
+    const osfm_match_options &o = m->opts;
+
+    // ---- classify (bundler_matching.cc:96-99, 146-158) ---------------------
+    std::vector<int> lowres_idx, full_idx;
+    for (int p = 0; p < num_pairs; ++p) {
+        OSFM_RETURN_IF(check_view(m, pairs[p].view_1, "match_all"));
+        OSFM_RETURN_IF(check_view(m, pairs[p].view_2, "match_all"));
+        const ViewData &a = m->views[pairs[p].view_1], &b = m->views[pairs[p].view_2];
+        osfm_pair_result &r = results[p];
+        r.status = OSFM_PAIR_MATCHED; r.lowres_matches = -1; r.num_matches = 0; r.reserved = 0; r.offset = 0;
+        const size_t np1 = (size_t)a.ns + a.nu, np2 = (size_t)b.ns + b.nu;
+        if (np1 == 0 || np2 == 0) { r.status = OSFM_PAIR_SKIPPED_EMPTY; continue; }
+        if (o.use_lowres_matching && np1 * np2 > 1000000) lowres_idx.push_back(p);
+        else full_idx.push_back(p);
+    }
+
+    // per-pair workspace estimate -> batch size
+    auto batch_size_for = [&](bool lowres) {
+        if (o.pairs_per_batch > 0) return o.pairs_per_batch;
+        return lowres ? 8192 : 256;
+    };
+
+    // ---- low-res gate -------------------------------------------------------
+    {
+        const int bs = batch_size_for(true);
+        std::vector<osfm_pair> chunk;
+        for (size_t start = 0; start < lowres_idx.size(); start += bs) {
+            const size_t end = std::min(lowres_idx.size(), start + bs);
+            chunk.clear();
+            for (size_t k = start; k < end; ++k) chunk.push_back(pairs[lowres_idx[k]]);
+            BatchResult res;
+            BatchMode mode;
+            mode.limit = o.num_lowres_features; mode.lowres = true; mode.apply = false;
+            OSFM_RETURN_IF(run_batch(m, chunk.data(), (int)chunk.size(), mode, &res));
+            for (size_t k = start; k < end; ++k) {
+                const int p = lowres_idx[k];
+                results[p].lowres_matches = res.counts[k - start];
+                if (res.counts[k - start] < o.min_lowres_matches)
+                    results[p].status = OSFM_PAIR_REJECTED_LOWRES;
+                else
+                    full_idx.push_back(p);
+            }
+        }
+        std::sort(full_idx.begin(), full_idx.end());
+    }
+
+    // ---- full matching + ordered correspondence lists -----------------------
+    const int min_matches = std::max(8, o.min_feature_matches);
+    int64_t written = 0;
+    bool overflow = false;
+    {
+        const int bs = batch_size_for(false);
+        std::vector<osfm_pair> chunk;
+        std::vector<int64_t> h_m12_off, h_corr_off;
+        std::vector<int32_t> h_len12;
+        std::vector<uint8_t> h_keep;
+        for (size_t start = 0; start < full_idx.size(); start += bs) {
+            const size_t end = std::min(full_idx.size(), start + bs);
+            const int n = (int)(end - start);
+            chunk.clear();
+            for (size_t k = start; k < end; ++k) chunk.push_back(pairs[full_idx[k]]);
+            BatchResult res;
+            OSFM_RETURN_IF(run_batch(m, chunk.data(), n, BatchMode(), &res));
+            h_m12_off.assign(n, 0); h_corr_off.assign(n, 0); h_len12.assign(n, 0); h_keep.assign(n, 0);
+            int64_t chunk_corr = 0;
+            for (int k = 0; k < n; ++k) {
+                const int p = full_idx[start + k];
+                osfm_pair_result &r = results[p];
+                r.num_matches = res.counts[k];
+                if (res.counts[k] < min_matches) { r.status = OSFM_PAIR_REJECTED_COUNT; continue; }
+                r.status = OSFM_PAIR_MATCHED;
+                r.offset = written + chunk_corr;
+                h_keep[k] = 1;
+                h_m12_off[k] = res.plans[k].off12;
+                h_len12[k] = res.plans[k].len12;
+                h_corr_off[k] = chunk_corr;
+                chunk_corr += res.counts[k];
+            }
+            if (written + chunk_corr > capacity) overflow = true;
+            if (!overflow && chunk_corr > 0) {
+                hipStream_t s = m->stream;
+                OSFM_RETURN_IF(m->d_m12_off.reserve(n * 8));
+                OSFM_RETURN_IF(m->d_corr_off.reserve(n * 8));
+                OSFM_RETURN_IF(m->d_len12.reserve(n * 4));
+                OSFM_RETURN_IF(m->d_keep_pair.reserve(n));
+                OSFM_RETURN_IF(m->d_corr.reserve((size_t)chunk_corr * 8));
+                OSFM_HIP_CHECK(hipMemcpyAsync(m->d_m12_off.ptr, h_m12_off.data(), n * 8, hipMemcpyHostToDevice, s));
+                OSFM_HIP_CHECK(hipMemcpyAsync(m->d_corr_off.ptr, h_corr_off.data(), n * 8, hipMemcpyHostToDevice, s));
+                OSFM_HIP_CHECK(hipMemcpyAsync(m->d_len12.ptr, h_len12.data(), n * 4, hipMemcpyHostToDevice, s));
+                OSFM_HIP_CHECK(hipMemcpyAsync(m->d_keep_pair.ptr, h_keep.data(), n, hipMemcpyHostToDevice, s));
+                launch_compact_pairs(n, m->out.as<int32_t>(), m->d_m12_off.as<int64_t>(),
+                    m->d_len12.as<int32_t>(), m->d_corr_off.as<int64_t>(), m->d_keep_pair.as<uint8_t>(),
+                    m->d_corr.as<int32_t>(), s);
+                OSFM_HIP_CHECK(hipGetLastError());
+                OSFM_HIP_CHECK(hipMemcpyAsync(corr + 2 * written, m->d_corr.ptr, (size_t)chunk_corr * 8,
+                    hipMemcpyDeviceToHost, s));
+                OSFM_HIP_CHECK(hipStreamSynchronize(s));
+            }
+            written += chunk_corr;
+        }
+    }
+    if (total) *total = written;
+    if (overflow) {
+        set_error("match_all: %lld correspondences need more than the given capacity %lld",
+            (long long)written, (long long)capacity);
+        return OSFM_E_CAPACITY;
+    }
+    return OSFM_OK;
+}
+
+int osfm_match_get_stats(const osfm_matcher *m, osfm_match_stats *out)
+{
+    if (!m || !out) { set_error("get_stats: null argument"); return OSFM_E_ARG; }
+    *out = m->stats;
+    return OSFM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+// Device-side data structures and launchers of the matching path (hot path A).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace osfm {
+
+constexpr int kRowsPerBlock = 256;     // rows of set 1 per workgroup (4 waves x 64)
+constexpr int kTileCols = 64;          // columns of set 2 per LDS tile
+constexpr int kSegCols = 8192;         // columns per workgroup (256 frag tiles -> 8 index bits)
+constexpr int kKeyNone = -(1 << 30);   // "no candidate" key
+
+// One two-way matching problem: rows = descriptors of set 1, columns = set 2.
+struct MatchProblem {
+    const int8_t *A;        // [n1 padded to 256][D] int8 (SIFT: value-128, SURF: value)
+    const int8_t *B;        // [n2 padded to 256][D]
+    const int32_t *corrA;   // per row: 128*sum(a') + 2^20 (SIFT) or 0 (SURF)
+    const int32_t *corrB;
+    int32_t n1, n2;         // true counts (already limited for low-res matching)
+    int32_t nrb, nseg;      // row blocks, column segments
+    int32_t n2stride;       // n2 rounded up to 64
+    int32_t block_start;    // first workgroup of this problem in the launch
+    int64_t rowpart_off;    // into RowPart[]: [nseg][nrb*256]
+    int64_t colpart_off;    // into ColPart[]: [nrb][n2stride]
+    int32_t *m12;           // [n1] result (set 1 -> set 2), device
+    int32_t *m21;           // [n2]
+    int32_t out_off12;      // combine_results offset added to valid m12 entries
+    int32_t out_off21;
+    int32_t force_exact;    // every query goes through the wrap-exact scan
+    int32_t pad_;
+};
+
+struct RowPart { int32_t ip_best, idx_best, ip_second, pad; };
+struct ColPart { int32_t key_best, key_second; };
+
+// Accept / reject tables and clamps of one descriptor type.
+struct LoweTable {
+    const int32_t *reject_from;  // [32768]: reject iff d1 >= reject_from[d2/2]
+    int32_t max_d1;              // reject iff d1 > max_d1 (distance threshold)
+    int32_t is_signed;           // SURF (short) vs SIFT (unsigned short)
+};
+
+// A query whose result must be recomputed with the reference's 16-bit
+// wrap-around arithmetic (nearest_neighbor.cc:75-84 and the T-typed state).
+struct ExactItem { int32_t problem; int32_t dir; int32_t query; };
+
+void launch_match_tiles(int ch, const MatchProblem *d_problems, int num_problems,
+    int total_blocks, RowPart *rowparts, ColPart *colparts, hipStream_t s);
+
+void launch_match_finish(const MatchProblem *d_problems, int num_problems,
+    int max_n, const RowPart *rowparts, const ColPart *colparts, LoweTable tab,
+    int force_exact, ExactItem *exact_items, int32_t *exact_count, int exact_cap,
+    hipStream_t s);
+
+void launch_exact_scan(int dim, const MatchProblem *d_problems,
+    const ExactItem *items, const int32_t *count, int exact_cap, LoweTable tab,
+    hipStream_t s);
+
+void launch_cross_check_mark(const MatchProblem *d_problems, int num_problems, int max_n,
+    uint8_t *keep12, uint8_t *keep21, const int64_t *mark_off, int32_t *counts, hipStream_t s);
+void launch_cross_check_apply(const MatchProblem *d_problems, int num_problems, int max_n,
+    const uint8_t *keep12, const uint8_t *keep21, const int64_t *mark_off, hipStream_t s);
+
+void launch_compact_pairs(int num_pairs, const int32_t *m12_all, const int64_t *m12_off,
+    const int32_t *len12, const int64_t *corr_off, const uint8_t *keep, int32_t *corr,
+    hipStream_t s);
+
+void launch_prepare_sift(const uint16_t *src, int n, int npad, int8_t *dst,
+    int32_t *corr, int32_t *range_err, hipStream_t s);
+void launch_prepare_surf(const int16_t *src, int n, int npad, int8_t *dst,
+    int32_t *corr, int32_t *norm2max, int32_t *range_err, hipStream_t s);
+
+}  // namespace osfm

@@ -1,0 +1,643 @@
+// Hand-written gfx950 kernels of the matching path (hot path A).
+//
+// What the reference does per view pair (src/mve/sfm/matching.h:114-159,
+// nearest_neighbor.cc:60-129,214-268): for every descriptor of set 1 scan all
+// descriptors of set 2, keep the largest / second largest integer inner
+// product (ties: later index wins; state starts at 0,0), turn them into
+// clamped squared distances, apply the Lowe ratio test; then the same with
+// the roles swapped (recomputing every inner product), then a cross-check.
+//
+// What this file does instead: the N1 x N2 score matrix S = A * B^T is a
+// dense int8 contraction (K = 128 or 64), so it is computed ONCE on the
+// matrix cores (v_mfma_i32_32x32x32_i8, exact in int32) and both directions
+// are reduced from the same accumulator tile while it is still in registers:
+// row-wise top-2 (set 1 -> set 2) is carried in VGPRs across column tiles,
+// column-wise top-2 (set 2 -> set 1) is reduced per tile and merged across
+// the workgroup through LDS.  The score matrix never exists in memory.
+//
+// SIFT values 0..255 do not fit int8: they are stored as a' = a - 128 and the
+// exact product is recovered as  sum(a*b) = sum(a'*b') + ra_i + cb_j  with
+// per-descriptor corrections ra = 128*sum(a') + 2^20 (the two 2^20 make up
+// 128*128*128).  ra enters through the MFMA C operand, cb through the key
+// construction, so the correction costs no extra instruction per element.
+#include "match_kernels.h"
+
+namespace osfm {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int med3i(int a, int b, int c)
+{
+    // lowers to v_med3_i32
+    return max(min(a, b), min(max(a, b), c));
+}
+
+// Bijective XCD-aware remap: consecutive logical blocks (which share the
+// column descriptors of one pair) land on the same XCD / L2.
+__device__ __forceinline__ int xcd_remap(int bid, int total)
+{
+    const int q = total >> 3, r = total & 7;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+// ---------------------------------------------------------------------------
+// Score-tile kernel.  CH = 16-byte chunks per descriptor (8: SIFT, 4: SURF).
+// Workgroup = 256 threads = 4 waves; wave w owns rows [64w, 64w+64) of its
+// row block as two 32-row MFMA fragments that stay in registers for the whole
+// kernel; the workgroup walks the columns of its segment in 64-column tiles
+// staged through LDS (double buffered, XOR-swizzled 16-B chunks so the
+// ds_read_b128 fragment reads are bank-conflict free).
+//
+// Key formats (int32, signed compare):
+//   row direction:  (ip << 8) | t        t = 32-column fragment index in segment
+//   col direction:  (x  << 5) | fr       x = ip - cb_j, fr = 16*rf + reg  (per lane)
+// Both preserve "later index wins on ties" because t / fr grow with the index.
+// ---------------------------------------------------------------------------
+template <int CH, bool MASK_COLS, bool MASK_ROWS>
+__device__ __forceinline__ void
+tile_epilogue(const v16i &acc, int cjt, int fr_base, bool col_valid, unsigned row_valid_bits,
+    v16i &rbest, v16i &rsec, int &cb, int &cs)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int x = acc[r];
+        int rk = (int)(((unsigned)x << 8) + (unsigned)cjt);
+        if (MASK_COLS) rk = col_valid ? rk : kKeyNone;
+        rsec[r] = med3i(rbest[r], rsec[r], rk);
+        rbest[r] = max(rbest[r], rk);
+        int ck = (int)(((unsigned)x << 5) | (unsigned)(fr_base + r));
+        if (MASK_ROWS) ck = ((row_valid_bits >> (fr_base + r)) & 1u) ? ck : kKeyNone;
+        cs = med3i(cb, cs, ck);
+        cb = max(cb, ck);
+    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(256, 2) void
+match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, int total_blocks,
+    RowPart *__restrict__ rowparts, ColPart *__restrict__ colparts)
+{
+    constexpr int D = CH * 16;
+    constexpr int KS = CH / 2;            // MFMA k-steps (K = 32 bytes each)
+    constexpr int RPB = 16 / CH;          // descriptor rows per 256-B LDS bank row
+    constexpr int TILE_BYTES = kTileCols * D;
+    constexpr int CHUNKS = kTileCols * CH;        // 16-B chunks per tile
+    constexpr int CPT = CHUNKS / 256;             // chunks per thread (2 or 1)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *bbuf = smem;                                              // [2][TILE_BYTES]
+    int *corrbuf = reinterpret_cast<int *>(smem + 2 * TILE_BYTES);  // [2][64]
+    ColPart *colbuf = reinterpret_cast<ColPart *>(smem + 2 * TILE_BYTES + 2 * 64 * 4);  // [2][4][64]
+
+    const int lin = xcd_remap(blockIdx.x, total_blocks);
+    // locate the problem: largest p with block_start <= lin
+    int lo = 0, hi = num_problems - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (problems[mid].block_start <= lin) lo = mid; else hi = mid - 1;
+    }
+    const MatchProblem &pd = problems[lo];
+    const int local = lin - pd.block_start;
+    const int nseg = pd.nseg;
+    const int rb = local / nseg;
+    const int seg = local - rb * nseg;
+    const int n1 = pd.n1, n2 = pd.n2;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int row0 = rb * kRowsPerBlock + wave * 64;
+
+    // --- resident A fragments and row corrections -------------------------
+    v4i a[2][KS];
+    v16i ra[2];
+#pragma unroll
+    for (int rf = 0; rf < 2; ++rf) {
+        const int8_t *arow = pd.A + (size_t)(row0 + rf * 32 + lr) * D;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            a[rf][ks] = *reinterpret_cast<const v4i *>(arow + (ks * 2 + lh) * 16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            ra[rf][r] = pd.corrA[row0 + rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+    }
+    unsigned row_valid_bits = 0;
+#pragma unroll
+    for (int fr = 0; fr < 32; ++fr) {
+        const int row = row0 + (fr >> 4) * 32 + (fr & 3) + 8 * ((fr >> 2) & 3) + 4 * lh;
+        row_valid_bits |= (row < n1 ? 1u : 0u) << fr;
+    }
+    const bool rows_partial = (rb * kRowsPerBlock + kRowsPerBlock > n1);
+
+    v16i rbest[2], rsec[2];
+#pragma unroll
+    for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { rbest[rf][r] = kKeyNone; rsec[rf][r] = kKeyNone; }
+
+    const int col_begin = seg * kSegCols;
+    const int col_lim = min(n2, col_begin + kSegCols);
+    const int ntiles = (col_lim - col_begin + kTileCols - 1) / kTileCols;
+
+    // --- B tile staging: LDS-DMA (global_load_lds, 16 B per lane) ------------
+    // The DMA writes LDS linearly (wave base + lane*16), so the XOR swizzle is
+    // applied to the per-lane SOURCE address: LDS chunk q holds chunk
+    // (q % CH) ^ swz(col) of column col = q / CH.
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    auto stage_tile = [&](int t, int buf) {
+        const int8_t *src = pd.B + (size_t)(col_begin + t * kTileCols) * D;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            const int q0 = (c * 4 + wave) * 64;           // first chunk of this wave-instruction
+            const int q = q0 + lane;
+            const int col = q / CH;
+            const int ch = (q % CH) ^ ((col / RPB) % CH);
+            __builtin_amdgcn_global_load_lds(
+                (glb_void *)(src + (size_t)col * D + ch * 16),
+                (lds_void *)(uintptr_t)(bbuf + buf * TILE_BYTES + q0 * 16), 16, 0, 0);
+        }
+        if (wave == 0)
+            __builtin_amdgcn_global_load_lds(
+                (glb_void *)(pd.corrB + col_begin + t * kTileCols + lane),
+                (lds_void *)(uintptr_t)(corrbuf + buf * 64), 4, 0, 0);
+    };
+
+    stage_tile(0, 0);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) stage_tile(t + 1, buf ^ 1);
+
+        const bool cols_partial = (col_begin + (t + 1) * kTileCols > n2);
+        int cbj[2];
+        int cb[2] = {kKeyNone, kKeyNone}, cs[2] = {kKeyNone, kKeyNone};
+#pragma unroll
+        for (int cf = 0; cf < 2; ++cf) {
+            // fragments of this 32-column group: KS k-steps
+            const int col = cf * 32 + lr;
+            const int swz = (col / RPB) % CH;
+            v4i b[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                b[ks] = *reinterpret_cast<const v4i *>(
+                    bbuf + buf * TILE_BYTES + col * D + (((ks * 2 + lh) ^ swz) * 16));
+            cbj[cf] = corrbuf[buf * 64 + col];
+            const int t32 = t * 2 + cf;
+            const int cjt = (int)(((unsigned)cbj[cf] << 8) + (unsigned)t32);
+            const bool col_valid = (col_begin + t * kTileCols + col) < n2;
+#pragma unroll
+            for (int rf = 0; rf < 2; ++rf) {
+                v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rf][0], b[0], ra[rf], 0, 0, 0);
+#pragma unroll
+                for (int ks = 1; ks < KS; ++ks)
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rf][ks], b[ks], acc, 0, 0, 0);
+                if (!cols_partial && !rows_partial)
+                    tile_epilogue<CH, false, false>(acc, cjt, rf * 16, col_valid, row_valid_bits,
+                        rbest[rf], rsec[rf], cb[cf], cs[cf]);
+                else
+                    tile_epilogue<CH, true, true>(acc, cjt, rf * 16, col_valid, row_valid_bits,
+                        rbest[rf], rsec[rf], cb[cf], cs[cf]);
+            }
+        }
+
+        // column direction: lane-local keys -> (ip << 8 | row in block), merge
+        // the two half-waves (same column, other rows), hand to LDS.
+        int kb[2], ksd[2];
+#pragma unroll
+        for (int cf = 0; cf < 2; ++cf) {
+            const int fr = cb[cf] & 31;
+            const int rowl = wave * 64 + (fr >> 4) * 32 + (fr & 3) + 8 * ((fr >> 2) & 3) + 4 * lh;
+            int k1 = (int)((unsigned)((cb[cf] >> 5) + cbj[cf]) << 8) | rowl;
+            int k2 = (int)((unsigned)((cs[cf] >> 5) + cbj[cf]) << 8);
+            k1 = cb[cf] == kKeyNone ? kKeyNone : k1;
+            k2 = cs[cf] == kKeyNone ? kKeyNone : k2;
+            const int o1 = __shfl_xor(k1, 32);
+            const int o2 = __shfl_xor(k2, 32);
+            kb[cf] = max(k1, o1);
+            ksd[cf] = max(min(k1, o1), max(k2, o2));
+        }
+        {
+            ColPart cp;
+            cp.key_best = lh ? kb[1] : kb[0];
+            cp.key_second = lh ? ksd[1] : ksd[0];
+            colbuf[(buf * 4 + wave) * 64 + lane] = cp;   // lane == column within tile
+        }
+
+        __syncthreads();
+
+        // one wave per tile (round robin) merges the four wave partials
+        if (wave == (t & 3)) {
+            int k1 = kKeyNone, k2 = kKeyNone;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const ColPart cp = colbuf[(buf * 4 + w) * 64 + lane];
+                // rows of wave w are above those of wave w-1: >= keeps the later row on ties
+                k2 = max(min(k1, cp.key_best), max(k2, cp.key_second));
+                k1 = max(k1, cp.key_best);
+            }
+            const int col = col_begin + t * kTileCols + lane;
+            if (col < pd.n2stride) {
+                ColPart out;
+                out.key_best = k1;
+                out.key_second = k2;
+                colparts[pd.colpart_off + (int64_t)rb * pd.n2stride + col] = out;
+            }
+        }
+    }
+
+    // --- row direction: reduce the 32 lanes of each half-wave --------------
+    RowPart *rp = rowparts + pd.rowpart_off + (int64_t)seg * ((int64_t)pd.nrb * kRowsPerBlock);
+#pragma unroll
+    for (int rf = 0; rf < 2; ++rf) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kbest = rbest[rf][r], ksec = rsec[rf][r];
+            // 64-bit composite: (ip, global column)
+            long long b1 = kbest == kKeyNone
+                ? (long long)LLONG_MIN
+                : ((long long)(kbest >> 8) << 32) | (unsigned)(col_begin + (kbest & 255) * 32 + lr);
+            int s1 = ksec == kKeyNone ? INT_MIN : (ksec >> 8);
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) {
+                const long long ob = __shfl_xor(b1, m);
+                const int os = __shfl_xor(s1, m);
+                const long long lo2 = b1 < ob ? b1 : ob;
+                const int lo_ip = lo2 == (long long)LLONG_MIN ? INT_MIN : (int)(lo2 >> 32);
+                s1 = max(max(s1, os), lo_ip);
+                b1 = b1 > ob ? b1 : ob;
+            }
+            if (lr == r) {
+                const int row = row0 + rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                RowPart out;
+                out.ip_best = b1 == (long long)LLONG_MIN ? INT_MIN : (int)(b1 >> 32);
+                out.idx_best = b1 == (long long)LLONG_MIN ? 0 : (int)(b1 & 0xffffffffLL);
+                out.ip_second = s1;
+                out.pad = 0;
+                rp[row] = out;
+            }
+        }
+    }
+}
+
+void launch_match_tiles(int ch, const MatchProblem *d_problems, int num_problems,
+    int total_blocks, RowPart *rowparts, ColPart *colparts, hipStream_t s)
+{
+    if (total_blocks <= 0) return;
+    const int d = ch * 16;
+    const size_t lds = 2 * (size_t)kTileCols * d + 2 * 64 * 4 + 2 * 4 * 64 * sizeof(ColPart);
+    if (ch == 8)
+        hipLaunchKernelGGL(match_tile_kernel<8>, dim3(total_blocks), dim3(256), lds, s,
+            d_problems, num_problems, total_blocks, rowparts, colparts);
+    else
+        hipLaunchKernelGGL(match_tile_kernel<4>, dim3(total_blocks), dim3(256), lds, s,
+            d_problems, num_problems, total_blocks, rowparts, colparts);
+}
+
+// ---------------------------------------------------------------------------
+// Finish: merge partials, apply the reference's clamps and ratio test.
+//   u16 (nearest_neighbor.cc:262-267): b = min(65025, ip); d = min(32767, 65025 - b) * 2
+//   s16 (nearest_neighbor.cc:234-237): b = clamp(ip, 0, 16129); d = 32258 - 2 b
+//   accept unless d1 > dist_thres^2 or float(d1)/float(d2) > lowe^2
+//   (matching.h:138-144) -- evaluated through a host-built integer table that
+//   encodes exactly those float operations for every (d1, d2).
+// The reference's state starts at (0, 0, idx 0): best = max(0, ip1),
+// second = max(0, ip2), index = idx1 if ip1 >= 0 else 0.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int
+accept_match(int ip1, int ip2, int idx1, const LoweTable &tab)
+{
+    int b = max(ip1, 0), s = max(ip2, 0);
+    const int idx = ip1 >= 0 ? idx1 : 0;
+    int d1, d2;
+    if (tab.is_signed) {
+        b = min(b, 16129); s = min(s, 16129);
+        d1 = 32258 - 2 * b; d2 = 32258 - 2 * s;
+    } else {
+        b = min(b, 65025); s = min(s, 65025);
+        d1 = min(32767, 65025 - b) * 2; d2 = min(32767, 65025 - s) * 2;
+    }
+    if (d1 > tab.max_d1) return -1;
+    if (d1 >= tab.reject_from[d2 >> 1]) return -1;
+    return idx;
+}
+
+__global__ void
+match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__restrict__ rowparts,
+    const ColPart *__restrict__ colparts, LoweTable tab, int force_exact,
+    ExactItem *__restrict__ exact_items, int32_t *__restrict__ exact_count, int exact_cap)
+{
+    const MatchProblem &pd = problems[blockIdx.y];
+    const int dir = blockIdx.z;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = dir == 0 ? pd.n1 : pd.n2;
+    if (q >= nq) return;
+    const int nc = dir == 0 ? pd.n2 : pd.n1;
+    int32_t *out = dir == 0 ? pd.m12 : pd.m21;
+    if (nc == 0) { out[q] = -1; return; }
+
+    int ip1 = INT_MIN, ip2 = INT_MIN, idx1 = 0;
+    if (dir == 0) {
+        const int64_t stride = (int64_t)pd.nrb * kRowsPerBlock;
+        for (int sgi = 0; sgi < pd.nseg; ++sgi) {
+            const RowPart p = rowparts[pd.rowpart_off + sgi * stride + q];
+            // later segment wins ties (its columns have larger indices)
+            ip2 = max(max(ip2, p.ip_second), min(ip1, p.ip_best));
+            if (p.ip_best >= ip1 && p.ip_best != INT_MIN) { ip1 = p.ip_best; idx1 = p.idx_best; }
+        }
+    } else {
+        for (int rb = 0; rb < pd.nrb; ++rb) {
+            const ColPart p = colparts[pd.colpart_off + (int64_t)rb * pd.n2stride + q];
+            const int pb = p.key_best == kKeyNone ? INT_MIN : (p.key_best >> 8);
+            const int ps = p.key_second == kKeyNone ? INT_MIN : (p.key_second >> 8);
+            ip2 = max(max(ip2, ps), min(ip1, pb));
+            if (pb >= ip1 && pb != INT_MIN) { ip1 = pb; idx1 = rb * kRowsPerBlock + (p.key_best & 255); }
+        }
+    }
+    const int limit = tab.is_signed ? 32767 : 65535;
+    if (force_exact || pd.force_exact || ip1 > limit) {
+        const int slot = atomicAdd(exact_count, 1);
+        if (slot < exact_cap) {
+            ExactItem it;
+            it.problem = blockIdx.y; it.dir = dir; it.query = q;
+            exact_items[slot] = it;
+        }
+    }
+    out[q] = accept_match(ip1, ip2, idx1, tab);
+}
+
+void launch_match_finish(const MatchProblem *d_problems, int num_problems, int max_n,
+    const RowPart *rowparts, const ColPart *colparts, LoweTable tab, int force_exact,
+    ExactItem *exact_items, int32_t *exact_count, int exact_cap, hipStream_t s)
+{
+    if (num_problems <= 0 || max_n <= 0) return;
+    dim3 grid((max_n + 255) / 256, num_problems, 2);
+    hipLaunchKernelGGL(match_finish_kernel, grid, dim3(256), 0, s, d_problems, rowparts, colparts,
+        tab, force_exact, exact_items, exact_count, exact_cap);
+}
+
+// ---------------------------------------------------------------------------
+// Wrap-exact scan: bit-for-bit emulation of the reference's SSE2 kernel for
+// the (rare) queries whose inner products leave the 16-bit range:
+// 8 lanes accumulate elements 8i+l modulo 2^16 (_mm_mullo_epi16 /
+// _mm_add_epi16, nearest_neighbor.cc:75-81), are read back as T, summed as
+// int (:82-84), compared against and stored into T-typed state (:87-101,
+// nearest_neighbor.h:50-56).  One wave per query: the 64 lanes evaluate 64
+// candidates, then the state is advanced through them in index order.
+// ---------------------------------------------------------------------------
+template <int DIM, bool SIGNED>
+__global__ __launch_bounds__(256) void
+exact_scan_kernel(const MatchProblem *__restrict__ problems, const ExactItem *__restrict__ items,
+    const int32_t *__restrict__ count, int exact_cap, LoweTable tab)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int n_items = min(*count, exact_cap);
+    for (int it = wave_global; it < n_items; it += nwaves) {
+        const ExactItem item = items[it];
+        const MatchProblem &pd = problems[item.problem];
+        const int8_t *Q = item.dir == 0 ? pd.A : pd.B;
+        const int8_t *C = item.dir == 0 ? pd.B : pd.A;
+        const int nc = item.dir == 0 ? pd.n2 : pd.n1;
+        int32_t *out = item.dir == 0 ? pd.m12 : pd.m21;
+        const int8_t *qrow = Q + (size_t)item.query * DIM;
+        int best = 0, second = 0, idx = 0;   // values as held in T-typed fields
+        for (int base = 0; base < nc; base += 64) {
+            const int j = base + lane;
+            int ip = 0;
+            if (j < nc) {
+                const int8_t *crow = C + (size_t)j * DIM;
+                unsigned lanes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int k = 0; k < DIM; k += 8) {
+#pragma unroll
+                    for (int l = 0; l < 8; ++l) {
+                        const int qa = SIGNED ? (int)qrow[k + l] : (int)qrow[k + l] + 128;
+                        const int ca = SIGNED ? (int)crow[k + l] : (int)crow[k + l] + 128;
+                        lanes[l] += (unsigned)(qa * ca);
+                    }
+                }
+#pragma unroll
+                for (int l = 0; l < 8; ++l)
+                    ip += SIGNED ? (int)(short)(lanes[l] & 0xffffu) : (int)(lanes[l] & 0xffffu);
+            }
+            const int cnt = min(64, nc - base);
+            for (int l = 0; l < cnt; ++l) {
+                const int v = __shfl(ip, l);
+                if (v >= second) {
+                    if (v >= best) {
+                        second = best;
+                        best = SIGNED ? (int)(short)v : (int)(unsigned short)v;
+                        idx = base + l;
+                    } else {
+                        second = SIGNED ? (int)(short)v : (int)(unsigned short)v;
+                    }
+                }
+            }
+        }
+        if (lane == 0) {
+            int d1, d2;
+            if (SIGNED) {
+                const int b = min(16129, max(0, best)), s2 = min(16129, max(0, second));
+                d1 = (int)(short)(32258 - 2 * b); d2 = (int)(short)(32258 - 2 * s2);
+            } else {
+                const int b = min(65025, best), s2 = min(65025, second);
+                d1 = min(32767, 65025 - b) * 2; d2 = min(32767, 65025 - s2) * 2;
+            }
+            int res = idx;
+            if (d1 > tab.max_d1) res = -1;
+            else if (d1 >= tab.reject_from[d2 >> 1]) res = -1;
+            out[item.query] = res;
+        }
+    }
+}
+
+void launch_exact_scan(int dim, const MatchProblem *d_problems, const ExactItem *items,
+    const int32_t *count, int exact_cap, LoweTable tab, hipStream_t s)
+{
+    if (exact_cap <= 0) return;
+    const dim3 grid(1024), block(256);
+    if (dim == 128)
+        hipLaunchKernelGGL((exact_scan_kernel<128, false>), grid, block, 0, s, d_problems, items,
+            count, exact_cap, tab);
+    else
+        hipLaunchKernelGGL((exact_scan_kernel<64, true>), grid, block, 0, s, d_problems, items,
+            count, exact_cap, tab);
+}
+
+// ---------------------------------------------------------------------------
+// Cross-check (Matching::remove_inconsistent_matches, matching.cc:18-36) and
+// mutual-match count (count_consistent_matches, :38-47).  Two phases because
+// both directions must be judged from the UNMODIFIED lists: phase 0 marks,
+// phase 1 applies (+ adds the combine_results offsets, matching.cc:74-86).
+// ---------------------------------------------------------------------------
+__global__ void
+cross_check_mark_kernel(const MatchProblem *__restrict__ problems, uint8_t *__restrict__ keep12,
+    uint8_t *__restrict__ keep21, const int64_t *__restrict__ mark_off, int32_t *__restrict__ counts)
+{
+    const MatchProblem &pd = problems[blockIdx.y];
+    const int dir = blockIdx.z;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = dir == 0 ? pd.n1 : pd.n2;
+    int ok = 0;
+    if (q < nq) {
+        const int32_t *mine = dir == 0 ? pd.m12 : pd.m21;
+        const int32_t *other = dir == 0 ? pd.m21 : pd.m12;
+        const int j = mine[q];
+        ok = (j >= 0 && other[j] == q) ? 1 : 0;
+        (dir == 0 ? keep12 : keep21)[mark_off[blockIdx.y * 2 + dir] + q] = (uint8_t)ok;
+    }
+    if (dir == 0 && counts) {
+        const unsigned long long bal = __ballot(ok);
+        if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counts[blockIdx.y], __popcll(bal));
+    }
+}
+
+__global__ void
+cross_check_apply_kernel(const MatchProblem *__restrict__ problems, const uint8_t *__restrict__ keep12,
+    const uint8_t *__restrict__ keep21, const int64_t *__restrict__ mark_off)
+{
+    const MatchProblem &pd = problems[blockIdx.y];
+    const int dir = blockIdx.z;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = dir == 0 ? pd.n1 : pd.n2;
+    if (q >= nq) return;
+    int32_t *mine = dir == 0 ? pd.m12 : pd.m21;
+    const uint8_t k = (dir == 0 ? keep12 : keep21)[mark_off[blockIdx.y * 2 + dir] + q];
+    const int off = dir == 0 ? pd.out_off12 : pd.out_off21;
+    mine[q] = k ? mine[q] + off : -1;
+}
+
+void launch_cross_check_mark(const MatchProblem *d_problems, int num_problems, int max_n,
+    uint8_t *keep12, uint8_t *keep21, const int64_t *mark_off, int32_t *counts, hipStream_t s)
+{
+    if (num_problems <= 0 || max_n <= 0) return;
+    dim3 grid((max_n + 255) / 256, num_problems, 2);
+    hipLaunchKernelGGL(cross_check_mark_kernel, grid, dim3(256), 0, s, d_problems, keep12, keep21,
+        mark_off, counts);
+}
+
+void launch_cross_check_apply(const MatchProblem *d_problems, int num_problems, int max_n,
+    const uint8_t *keep12, const uint8_t *keep21, const int64_t *mark_off, hipStream_t s)
+{
+    if (num_problems <= 0 || max_n <= 0) return;
+    dim3 grid((max_n + 255) / 256, num_problems, 2);
+    hipLaunchKernelGGL(cross_check_apply_kernel, grid, dim3(256), 0, s, d_problems, keep12, keep21,
+        mark_off);
+}
+
+// ---------------------------------------------------------------------------
+// Ordered compaction of the combined matches_1_2 list of each kept pair into
+// (feature_1, feature_2) correspondences (bundler_matching.cc:176-192).  One
+// workgroup per pair; order by feature_1 is preserved by a running prefix.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void
+compact_kernel(const int32_t *__restrict__ m12_all, const int64_t *__restrict__ m12_off,
+    const int32_t *__restrict__ len12, const int64_t *__restrict__ corr_off,
+    const uint8_t *__restrict__ keep, int32_t *__restrict__ corr)
+{
+    const int p = blockIdx.x;
+    if (!keep[p]) return;
+    const int32_t *m12 = m12_all + m12_off[p];
+    const int n = len12[p];
+    int32_t *dst = corr + 2 * corr_off[p];
+    __shared__ int wave_sum[4];
+    __shared__ int running;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + threadIdx.x;
+        const int j = i < n ? m12[i] : -1;
+        const unsigned long long bal = __ballot(j >= 0);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_sum[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wave_sum[w];
+        const int r0 = running;
+        if (j >= 0) {
+            const int pos = r0 + woff + before;
+            dst[2 * pos] = i;
+            dst[2 * pos + 1] = j;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) running = r0 + wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+        __syncthreads();
+    }
+}
+
+void launch_compact_pairs(int num_pairs, const int32_t *m12_all, const int64_t *m12_off,
+    const int32_t *len12, const int64_t *corr_off, const uint8_t *keep, int32_t *corr, hipStream_t s)
+{
+    if (num_pairs <= 0) return;
+    hipLaunchKernelGGL(compact_kernel, dim3(num_pairs), dim3(256), 0, s, m12_all, m12_off, len12,
+        corr_off, keep, corr);
+}
+
+// ---------------------------------------------------------------------------
+// View preparation: 16-bit lanes -> int8 storage + per-descriptor correction.
+// ---------------------------------------------------------------------------
+__global__ void
+prepare_sift_kernel(const uint16_t *__restrict__ src, int n, int npad, int8_t *__restrict__ dst,
+    int32_t *__restrict__ corr, int32_t *__restrict__ range_err)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= npad) return;
+    int sum = 0;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = lane * 2 + k;
+        int v = row < n ? (int)src[(size_t)row * 128 + e] : 128;   // pad rows: a' = 0
+        if (v > 255) { bad = true; v = 255; }
+        const int a = v - 128;
+        dst[(size_t)row * 128 + e] = (int8_t)a;
+        sum += a;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+    if (lane == 0) corr[row] = row < n ? 128 * sum + (1 << 20) : 0;
+    if (bad) atomicOr(range_err, 1);
+}
+
+__global__ void
+prepare_surf_kernel(const int16_t *__restrict__ src, int n, int npad, int8_t *__restrict__ dst,
+    int32_t *__restrict__ corr, int32_t *__restrict__ norm2max, int32_t *__restrict__ range_err)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= npad) return;
+    int v = row < n ? (int)src[(size_t)row * 64 + lane] : 0;
+    if (v > 127 || v < -128) { atomicOr(range_err, 1); v = 0; }
+    dst[(size_t)row * 64 + lane] = (int8_t)v;
+    int sq = v * v;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
+    if (lane == 0) {
+        corr[row] = 0;
+        atomicMax(norm2max, sq);
+    }
+}
+
+void launch_prepare_sift(const uint16_t *src, int n, int npad, int8_t *dst, int32_t *corr,
+    int32_t *range_err, hipStream_t s)
+{
+    if (npad <= 0) return;
+    hipLaunchKernelGGL(prepare_sift_kernel, dim3((npad + 3) / 4), dim3(256), 0, s, src, n, npad, dst,
+        corr, range_err);
+}
+
+void launch_prepare_surf(const int16_t *src, int n, int npad, int8_t *dst, int32_t *corr,
+    int32_t *norm2max, int32_t *range_err, hipStream_t s)
+{
+    if (npad <= 0) return;
+    hipLaunchKernelGGL(prepare_surf_kernel, dim3((npad + 3) / 4), dim3(256), 0, s, src, n, npad, dst,
+        corr, norm2max, range_err);
+}
+
+}  // namespace osfm

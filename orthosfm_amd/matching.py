@@ -1,0 +1,146 @@
+"""Host-side mirror of the reference's matcher plug-in interface on top of
+the C ABI: sfm::MatchingBase { init, pairwise_match, pairwise_match_lowres }
+(src/mve/sfm/matching_base.h:22-55) and the all-pairs driver
+sfm::bundler::Matching::compute (src/mve/sfm/bundler_matching.cc:58-136,
+up to the RANSAC stage).  Same names, argument meaning and error behaviour
+(exceptions for invalid arguments, -1 for unsuccessful matches).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import capi
+
+
+@dataclass
+class MatchResult:
+    """sfm::Matching::Result (src/mve/sfm/matching.h:56-62)."""
+    matches_1_2: np.ndarray
+    matches_2_1: np.ndarray
+
+
+@dataclass
+class TwoViewMatching:
+    """sfm::bundler::TwoViewMatching (bundler_common.h:118-125) before RANSAC."""
+    view_1_id: int
+    view_2_id: int
+    matches: np.ndarray          # (k, 2) int32 (feature in view 1, feature in view 2)
+    status: int = 0
+    lowres_matches: int = -1
+    num_matches: int = 0
+
+
+class HipExhaustiveMatching:
+    """Drop-in for sfm::ExhaustiveMatching (src/mve/sfm/exhaustive_matching.h:26-66)
+    backed by the gfx950 kernels."""
+
+    def __init__(self, num_views: int, device: int = 0, options: capi.MatchOptions | None = None):
+        self.opts = options if options is not None else capi.default_match_options()
+        self._h = C.c_void_p()
+        capi.check(capi.lib.osfm_match_create(device, num_views, C.byref(self.opts), C.byref(self._h)))
+        self.num_views = num_views
+
+    # --- MatchingBase::init ---------------------------------------------------
+    def init(self, viewports):
+        """viewports: sequence of (sift_float[n,128], surf_float[m,64]) -- the
+        FeatureSet::sift_descriptors / surf_descriptors data rows."""
+        if viewports is None:
+            raise ValueError("Viewports must not be null")   # bundler_matching.cc:47-48
+        for v, (sift, surf) in enumerate(viewports):
+            self.set_view_float(v, sift, surf)
+
+    def set_view_float(self, view, sift, surf):
+        sift = np.ascontiguousarray(sift, dtype=np.float32).reshape(-1, 128)
+        surf = np.ascontiguousarray(surf, dtype=np.float32).reshape(-1, 64)
+        capi.check(capi.lib.osfm_match_set_view_float(
+            self._h, view, capi._ptr(sift, C.c_float), sift.shape[0],
+            capi._ptr(surf, C.c_float), surf.shape[0]))
+
+    def set_view(self, view, sift_u16, surf_s16=None):
+        sift = np.ascontiguousarray(sift_u16, dtype=np.uint16).reshape(-1, 128)
+        surf = (np.zeros((0, 64), np.int16) if surf_s16 is None
+                else np.ascontiguousarray(surf_s16, dtype=np.int16).reshape(-1, 64))
+        capi.check(capi.lib.osfm_match_set_view(
+            self._h, view, capi._ptr(sift, C.c_uint16), sift.shape[0],
+            capi._ptr(surf, C.c_int16), surf.shape[0]))
+
+    def view_size(self, view):
+        a, b = C.c_int(), C.c_int()
+        capi.check(capi.lib.osfm_match_view_size(self._h, view, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # --- MatchingBase::pairwise_match -----------------------------------------
+    def pairwise_match(self, view_1_id, view_2_id) -> MatchResult:
+        n1 = sum(self.view_size(view_1_id))
+        n2 = sum(self.view_size(view_2_id))
+        m12 = np.full(max(n1, 1), -7, dtype=np.int32)
+        m21 = np.full(max(n2, 1), -7, dtype=np.int32)
+        l12, l21 = C.c_int32(), C.c_int32()
+        capi.check(capi.lib.osfm_match_pair(
+            self._h, view_1_id, view_2_id, capi._ptr(m12, C.c_int32), C.byref(l12),
+            capi._ptr(m21, C.c_int32), C.byref(l21)))
+        return MatchResult(m12[:l12.value].copy(), m21[:l21.value].copy())
+
+    # --- MatchingBase::pairwise_match_lowres ----------------------------------
+    def pairwise_match_lowres(self, view_1_id, view_2_id, num_features) -> int:
+        c = C.c_int32()
+        capi.check(capi.lib.osfm_match_pair_lowres(self._h, view_1_id, view_2_id, num_features, C.byref(c)))
+        return c.value
+
+    # --- Matching::twoway_match (matching.h:148-159), one descriptor type -------
+    def twoway_match(self, view_1_id, view_2_id, descriptor_type=0, num_features=0) -> MatchResult:
+        n1 = self.view_size(view_1_id)[descriptor_type]
+        n2 = self.view_size(view_2_id)[descriptor_type]
+        if num_features > 0:
+            n1, n2 = min(n1, num_features), min(n2, num_features)
+        m12 = np.full(max(n1, 1), -7, dtype=np.int32)
+        m21 = np.full(max(n2, 1), -7, dtype=np.int32)
+        capi.check(capi.lib.osfm_match_twoway(self._h, view_1_id, view_2_id, descriptor_type,
+                                              num_features, capi._ptr(m12, C.c_int32),
+                                              capi._ptr(m21, C.c_int32)))
+        return MatchResult(m12[:n1].copy(), m21[:n2].copy())
+
+    # --- bundler::Matching::compute (pre-RANSAC part), batched ----------------
+    def compute(self, pairs=None, capacity=None):
+        """Matches `pairs` (default: all V(V-1)/2 pairs in the reference's
+        triangular order, view_1 > view_2).  Returns one TwoViewMatching per
+        input pair, in input order."""
+        if pairs is None:
+            pairs = [capi.pair_from_index(i) for i in range(self.num_views * (self.num_views - 1) // 2)]
+        n = len(pairs)
+        arr = (capi.Pair * max(n, 1))()
+        for k, (a, b) in enumerate(pairs):
+            arr[k].view_1, arr[k].view_2 = a, b
+        res = (capi.PairResult * max(n, 1))()
+        if capacity is None:
+            capacity = sum(min(sum(self.view_size(a)), sum(self.view_size(b))) for a, b in pairs)
+        corr = np.zeros((max(capacity, 1), 2), dtype=np.int32)
+        total = C.c_int64()
+        capi.check(capi.lib.osfm_match_all(self._h, arr, n, res, capi._ptr(corr, C.c_int32),
+                                           C.c_int64(capacity), C.byref(total)))
+        out = []
+        for k, (a, b) in enumerate(pairs):
+            r = res[k]
+            m = (corr[r.offset:r.offset + r.num_matches].copy() if r.status == capi.PAIR_MATCHED
+                 else np.zeros((0, 2), np.int32))
+            out.append(TwoViewMatching(a, b, m, r.status, r.lowres_matches, r.num_matches))
+        return out
+
+    def stats(self) -> capi.MatchStats:
+        s = capi.MatchStats()
+        capi.check(capi.lib.osfm_match_get_stats(self._h, C.byref(s)))
+        return s
+
+    def close(self):
+        if self._h:
+            capi.lib.osfm_match_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,238 @@
+"""GPU parity tests of hot path A, through the C ABI (libosfm_hip.so).
+
+Every expected value is either a committed golden vector produced by the
+reference's own matcher (tests/golden) or the CPU oracle on the same seeded
+inputs.  Bit-exact: the path is integer work plus one float ratio test.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import match_cases
+import oracle_lib
+from orthosfm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def hm():
+    from orthosfm_amd import capi
+    from orthosfm_amd.matching import HipExhaustiveMatching
+    assert capi.device_count() >= 1, "no HIP device"
+    return HipExhaustiveMatching
+
+
+def _names(g):
+    return sorted({k.rsplit("/", 1)[0] for k in g.files})
+
+
+def test_golden_twoway_all_cases(hm):
+    """Matching::twoway_match / remove_inconsistent / count vs the reference's
+    outputs for every small + adversarial case (ties, zeros, n=0/1, NaN accept,
+    16-bit wrap, values >= 128, negative SURF products)."""
+    g = np.load(os.path.join(GOLD, "match_twoway.npz"))
+    names = _names(g)
+    assert len(names) >= 25
+    for k in names:
+        s1, s2, lowe = g[k + "/s1"], g[k + "/s2"], float(g[k + "/lowe"])
+        from orthosfm_amd import capi
+        o = capi.default_match_options()
+        is_u16 = k.startswith("u16")
+        if is_u16:
+            o.sift_lowe_ratio = lowe
+        else:
+            o.surf_lowe_ratio = lowe
+        m = hm(2, options=o)
+        if is_u16:
+            m.set_view(0, s1)
+            m.set_view(1, s2)
+        else:
+            m.set_view(0, np.zeros((0, 128), np.uint16), s1)
+            m.set_view(1, np.zeros((0, 128), np.uint16), s2)
+        t = 0 if is_u16 else 1
+        r = m.twoway_match(0, 1, t)
+        assert np.array_equal(r.matches_1_2, g[k + "/m12"]), k
+        assert np.array_equal(r.matches_2_1, g[k + "/m21"]), k
+        r = m.pairwise_match(0, 1)
+        if s1.shape[0] > 0:
+            assert np.array_equal(r.matches_1_2, g[k + "/c12"]), k
+            assert np.array_equal(r.matches_2_1, g[k + "/c21"]), k
+        else:   # view 1 has no descriptors: both lists are EMPTY (exhaustive_matching.cc:122,134)
+            assert r.matches_1_2.size == 0 and r.matches_2_1.size == 0, k
+        assert m.pairwise_match_lowres(0, 1, 100000) == (int(g[k + "/count"]) if s1.shape[0] else 0), k
+        m.close()
+
+
+def test_golden_exhaustive_views(hm):
+    """Float descriptors -> init (quantisation) -> pairwise_match /
+    pairwise_match_lowres with mixed SIFT/SURF counts, vs the reference."""
+    g = np.load(os.path.join(GOLD, "match_exhaustive.npz"))
+    views = []
+    v = 0
+    while f"view{v}/sift" in g.files:
+        views.append((g[f"view{v}/sift"], g[f"view{v}/surf"]))
+        v += 1
+    m = hm(len(views))
+    m.init(views)
+    for a in range(len(views)):
+        for b in range(len(views)):
+            if a == b:
+                continue
+            r = m.pairwise_match(a, b)
+            assert np.array_equal(r.matches_1_2, g[f"pair{a}_{b}/m12"]), (a, b)
+            assert np.array_equal(r.matches_2_1, g[f"pair{a}_{b}/m21"]), (a, b)
+            for nf in (40, 500):
+                assert m.pairwise_match_lowres(a, b, nf) == int(g[f"pair{a}_{b}/lowres{nf}"]), (a, b, nf)
+    m.close()
+
+
+@pytest.mark.parametrize("n1,n2,seed", [(300, 257, 1), (1000, 777, 2), (2500, 9000, 3), (8300, 700, 4)])
+def test_sift_vs_oracle_multi_block(hm, n1, n2, seed):
+    """Several row blocks / column segments / partial tiles, vs the oracle."""
+    s1, s2 = match_cases.sift_pair(n1, n2, min(n1, n2) // 2, 500 + seed)
+    om = oracle_lib.oracle_matcher()
+    e12, e21 = om.twoway(s1, s2, 0.8)
+    m = hm(2)
+    m.set_view(0, s1)
+    m.set_view(1, s2)
+    r = m.twoway_match(0, 1, 0)
+    assert np.array_equal(r.matches_1_2, e12)
+    assert np.array_equal(r.matches_2_1, e21)
+    c12, c21 = om.remove_inconsistent(e12, e21)
+    r = m.pairwise_match(0, 1)
+    assert np.array_equal(r.matches_1_2, c12) and np.array_equal(r.matches_2_1, c21)
+    assert m.stats().exact_scan_queries == 0
+    m.close()
+
+
+@pytest.mark.parametrize("n1,n2,seed", [(513, 300, 1), (2000, 3100, 2)])
+def test_surf_vs_oracle_multi_block(hm, n1, n2, seed):
+    u1, u2 = match_cases.surf_pair(n1, n2, min(n1, n2) // 2, 600 + seed)
+    om = oracle_lib.oracle_matcher()
+    e12, e21 = om.twoway(u1, u2, 0.7)
+    m = hm(2)
+    z = np.zeros((0, 128), np.uint16)
+    m.set_view(0, z, u1)
+    m.set_view(1, z, u2)
+    r = m.twoway_match(0, 1, 1)
+    assert np.array_equal(r.matches_1_2, e12) and np.array_equal(r.matches_2_1, e21)
+    m.close()
+
+
+def test_wrap_exact_path_large(hm):
+    """Un-normalised 0..255 data: most inner products exceed 65535, so the
+    reference's 16-bit lane wrap and truncated state decide every match;
+    the wrap-exact kernel must reproduce them."""
+    r = np.random.default_rng(5)
+    s1 = r.integers(0, 256, (600, 128)).astype(np.uint16)
+    s2 = r.integers(0, 256, (700, 128)).astype(np.uint16)
+    s1[::7] = (s1[::7] // 9)           # mix in rows that stay in range
+    om = oracle_lib.oracle_matcher()
+    e12, e21 = om.twoway(s1, s2, 0.8)
+    m = hm(2)
+    m.set_view(0, s1)
+    m.set_view(1, s2)
+    got = m.twoway_match(0, 1, 0)
+    assert np.array_equal(got.matches_1_2, e12) and np.array_equal(got.matches_2_1, e21)
+    assert m.stats().exact_scan_queries > 0
+    # SURF with un-normalised rows: the norm bound fails -> every query exact-scanned
+    u1 = r.integers(-127, 128, (300, 64)).astype(np.int16)
+    u2 = r.integers(-127, 128, (280, 64)).astype(np.int16)
+    e12, e21 = om.twoway(u1, u2, 0.7)
+    z = np.zeros((0, 128), np.uint16)
+    m.set_view(0, z, u1)
+    m.set_view(1, z, u2)
+    got = m.twoway_match(0, 1, 1)
+    assert np.array_equal(got.matches_1_2, e12) and np.array_equal(got.matches_2_1, e21)
+    m.close()
+
+
+def test_match_all_small_image_set(hm):
+    """bundler::Matching::compute up to RANSAC on a 6-view synthetic set:
+    low-res gate, thresholds and the ordered correspondence lists, each pair
+    checked against the oracle."""
+    from orthosfm_amd import capi
+    iset = synth.make_image_set(6, 1500, n_surf=200, config_id=9)
+    # make one view unrelated (distractors only) so some pairs get rejected
+    rr = np.random.default_rng(3)
+    iset.sift[5] = synth.quantize_sift(synth.sift_like(rr.standard_normal((1500, 128))))
+    iset.surf[5] = synth.quantize_surf(synth.surf_like(rr.standard_normal((200, 64))))
+    m = hm(6)
+    for v in range(6):
+        m.set_view(v, iset.sift[v], iset.surf[v])
+    out = m.compute()
+    assert len(out) == 15
+    statuses = set()
+    for tv in out:
+        a, b = tv.view_1_id, tv.view_2_id
+        assert a > b
+        low = oracle_lib.oracle_pairwise_match_lowres(iset.sift[a], iset.surf[a], iset.sift[b], iset.surf[b], 500)
+        assert tv.lowres_matches == low
+        if low < 5:
+            assert tv.status == capi.PAIR_REJECTED_LOWRES
+            statuses.add(tv.status)
+            continue
+        e12, e21 = oracle_lib.oracle_pairwise_match(iset.sift[a], iset.surf[a], iset.sift[b], iset.surf[b])
+        cnt = int((e12 >= 0).sum())
+        assert tv.num_matches == cnt
+        if cnt < 50:
+            assert tv.status == capi.PAIR_REJECTED_COUNT
+        else:
+            assert tv.status == capi.PAIR_MATCHED
+            idx = np.nonzero(e12 >= 0)[0]
+            exp = np.stack([idx, e12[idx]], axis=1).astype(np.int32)
+            assert np.array_equal(tv.matches, exp)
+        statuses.add(tv.status)
+    assert capi.PAIR_MATCHED in statuses and len(statuses) >= 2
+    m.close()
+
+
+def test_full_size_properties(hm):
+    """BASELINE-size views (20k features): properties that need no oracle --
+    swapping the views swaps the lists; the result is a mutual matching; the
+    planted landmark correspondences are recovered; matching a view with a
+    permuted copy of itself returns the permutation."""
+    iset = synth.make_image_set(2, 20000, config_id=2)
+    m = hm(3)
+    m.set_view(0, iset.sift[0])
+    m.set_view(1, iset.sift[1])
+    r01 = m.pairwise_match(0, 1)
+    r10 = m.pairwise_match(1, 0)
+    assert np.array_equal(r01.matches_1_2, r10.matches_2_1)
+    assert np.array_equal(r01.matches_2_1, r10.matches_1_2)
+    i = np.nonzero(r01.matches_1_2 >= 0)[0]
+    assert np.array_equal(r01.matches_2_1[r01.matches_1_2[i]], i)
+    # recovered correspondences agree with the planted landmarks
+    lm0, lm1 = iset.landmark[0], iset.landmark[1]
+    ok = lm0[i] == lm1[r01.matches_1_2[i]]
+    shared = np.intersect1d(lm0[lm0 >= 0], lm1[lm1 >= 0]).size
+    assert i.size > 0.5 * shared and ok.mean() > 0.99
+    # permutation round trip
+    perm = np.random.default_rng(1).permutation(20000)
+    m.set_view(2, iset.sift[0][perm])
+    r = m.pairwise_match(0, 2)
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(20000)
+    acc = r.matches_1_2 >= 0
+    assert acc.mean() > 0.95
+    assert np.array_equal(r.matches_1_2[acc], inv[acc])
+    m.close()
+
+
+def test_error_behaviour(hm):
+    from orthosfm_amd import capi
+    m = hm(2)
+    with pytest.raises(capi.OsfmError) as e:
+        m.pairwise_match(0, 1)          # views not set
+    assert e.value.status == capi.E_STATE
+    with pytest.raises(capi.OsfmError) as e:
+        m.set_view(5, np.zeros((1, 128), np.uint16))
+    assert e.value.status == capi.E_ARG
+    with pytest.raises(capi.OsfmError) as e:
+        m.set_view(0, np.full((3, 128), 300, np.uint16))
+    assert e.value.status == capi.E_RANGE
+    m.close()
