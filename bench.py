@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X backend (driver contract).
+
+One "step" = one pass of the hot path over one synthetic image set:
+  * matching: exhaustive pairwise matching (low-res gate, two-way SIFT match,
+    cross-check, thresholds, ordered correspondence lists) of ALL V(V-1)/2
+    pairs of a V-image set with ~20k SIFT features per image, descriptors
+    resident in HBM (BASELINE.json configs[1]: 50 images on 1 GPU);
+  * bundle adjustment (reported beside it): LM iterations/s of the global BA
+    of configs[3] (200 quaternion cameras, 100k tracks) -- see `ba` in the
+    JSON line.
+`value` = image pairs matched per second over all ranks (pairs are sharded
+across ranks with no data-path collective; the match lists are gathered to
+rank 0 over RCCL at the end of every step, inside the timed region).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+I8_MFMA_PEAK_TOPS = 5000.0      # dense int8 MFMA, MI355X_MICROARCH.md (2x the 2.5 PF bf16 figure)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--views", type=int, default=0, help="0 = 50 at N=1, grown with N so pairs per GPU stay ~1225")
+    ap.add_argument("--features", type=int, default=20000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = auto (about 15 s of CPU work)")
+    return ap.parse_args()
+
+
+def shard_pairs(pairs, rank, world):
+    """Static round-robin deal of the triangular pair list (work per pair is
+    N1*N2, known up front; equal-sized views -> equal work)."""
+    return pairs[rank::world]
+
+
+def cpu_baseline(iset, pairs, n_sample):
+    """Times the CPU oracle (bit-exact restatement of the reference matcher,
+    OpenMP over queries) on a bounded sample of the same workload."""
+    import oracle_lib
+    threads = oracle_lib.oracle().oracle_num_threads()
+    empty = np.zeros((0, 64), np.int16)
+    # calibrate on one quarter-size pair to pick the sample size
+    a, b = pairs[0]
+    t0 = time.perf_counter()
+    oracle_lib.oracle_pairwise_match(iset.sift[a][:5000], empty, iset.sift[b][:5000], empty)
+    t_quarter = time.perf_counter() - t0
+    est_pair = t_quarter * 16.0
+    if n_sample <= 0:
+        n_sample = int(max(1, min(len(pairs), round(15.0 / max(est_pair, 1e-3)))))
+    t0 = time.perf_counter()
+    for (a, b) in pairs[:n_sample]:
+        oracle_lib.oracle_pairwise_match(iset.sift[a], empty, iset.sift[b], empty)
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt, "unit": "pairs/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n_sample} full-size pairs ({iset.sift[0].shape[0]} x {iset.sift[0].shape[0]} SIFT, "
+                      f"two-way + cross-check) of the same image set, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    from orthosfm_amd import capi, synth
+    from orthosfm_amd.matching import HipExhaustiveMatching
+
+    if capi.device_count() < 1:
+        raise RuntimeError("bench.py: no HIP device (the backend has no CPU fallback)")
+
+    # weak scaling: the image set grows with the rank count so that every
+    # GPU keeps ~1225 pairs (50 views -> 1225; 71 -> 2485; 100 -> 4950; 141 -> 9870)
+    V = args.views
+    if V <= 0:
+        V = 50
+        while V * (V - 1) // 2 < 1225 * world:
+            V += 1
+    F = args.features
+    iset = synth.make_image_set(V, F, config_id=2)
+    all_pairs = [capi.pair_from_index(i) for i in range(V * (V - 1) // 2)]
+    my_pairs = shard_pairs(all_pairs, rank, world)
+
+    m = HipExhaustiveMatching(V, device=local_rank)
+    t0 = time.perf_counter()
+    for v in range(V):
+        m.set_view(v, iset.sift[v])
+    upload_s = time.perf_counter() - t0
+    capacity = F * max(len(my_pairs), 1)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        out = m.compute(my_pairs, capacity=capacity)
+        st = m.stats()
+        n_corr = sum(int(tv.num_matches) for tv in out if tv.status == capi.PAIR_MATCHED)
+        if world > 1:
+            # the only collective of the path: gather the match lists on rank 0
+            counts = torch.tensor([n_corr], dtype=torch.int64, device="cuda")
+            allc = [torch.zeros_like(counts) for _ in range(world)]
+            dist.all_gather(allc, counts)
+            mx = int(max(int(c.item()) for c in allc))
+            flat = np.concatenate([tv.matches.reshape(-1) for tv in out] + [np.zeros(0, np.int32)])
+            buf = torch.zeros(2 * mx, dtype=torch.int32, device="cuda")
+            buf[:flat.size] = torch.from_numpy(flat).cuda()
+            gathered = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
+            dist.gather(buf, gathered, dst=0)
+        return out, st, n_corr
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kern_ms, kern_launches, macs, n_corr = 0.0, 0, 0, 0
+    for _ in range(args.steps):
+        out, st, n_corr = step()
+        kern_ms += st.tile_kernel_ms
+        kern_launches += st.tile_kernel_launches
+        macs += st.mac_count
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        tot = torch.tensor([float(len(my_pairs))], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot)
+        total_pairs = int(tot.item())
+    else:
+        total_pairs = len(my_pairs)
+
+    ba = None
+    if not args.no_ba and rank == 0:
+        try:
+            from orthosfm_amd import ba as ba_mod
+            ba = ba_mod.bench_global_ba()
+        except Exception as e:       # BA reporting must never hide the matching line
+            ba = {"error": str(e)}
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = total_pairs * args.steps / dt
+        flops_per_launch = 2.0 * macs / max(kern_launches, 1)
+        avg_launch_s = kern_ms / max(kern_launches, 1) * 1e-3
+        achieved = flops_per_launch / max(avg_launch_s, 1e-12) / 1e12
+        statuses = [tv.status for tv in out]
+        line = {
+            "metric": "image-pairs matched/sec + BA iterations/sec (N images, M tracks) at 1/2/4/8 GPU",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "i8",
+            "data": "synthetic",
+            "config": {"workload": f"{V} orthographic images, {F} SIFT features/img, exhaustive matching "
+                                   f"({total_pairs} pairs, low-res gate + two-way + cross-check + lists)",
+                       "views": V, "features_per_view": F, "pairs": total_pairs,
+                       "sharding": f"pairs round-robin over {world} rank(s)"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_MFMA_PEAK_TOPS,
+                         "unit": "TFLOP/s", "frac": achieved / I8_MFMA_PEAK_TOPS, "traffic": None,
+                         "kernel": "match_tile_kernel<8>", "launches_per_step": kern_launches / args.steps,
+                         "avg_launch_ms": avg_launch_s * 1e3,
+                         "hbm_algorithmic_GBs": (st.algorithmic_bytes / max(st.tile_kernel_launches, 1))
+                                                / max(avg_launch_s, 1e-12) / 1e9},
+            "matched_pairs_rank0": int(sum(1 for s in statuses if s == capi.PAIR_MATCHED)),
+            "correspondences_rank0": int(n_corr),
+            "upload_s": upload_s,
+        }
+        if ba is not None:
+            line["ba"] = ba
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(iset, all_pairs, args.cpu_sample_pairs)
+        print(json.dumps(line))
+    m.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -74,13 +74,21 @@ typedef struct {
     int idx_1st, idx_2nd;
 } oracle_nn_result;
 
+/* 8 x 16-bit lanes with wrap-around, written with GCC vector extensions so
+ * the compiler emits the packed 16-bit multiply/add the semantics call for. */
+typedef uint16_t v8u16 __attribute__((vector_size(16), aligned(2)));
+typedef int16_t v8s16 __attribute__((vector_size(16), aligned(2)));
+
 static inline int
 ip_u16(const uint16_t *q, const uint16_t *c, int dim)
 {
-    uint16_t lane[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i + 8 <= dim; i += 8)
-        for (int l = 0; l < 8; ++l)
-            lane[l] = (uint16_t)(lane[l] + (uint16_t)((unsigned)q[i + l] * (unsigned)c[i + l]));
+    v8u16 lane = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i + 8 <= dim; i += 8) {
+        v8u16 a, b;
+        memcpy(&a, q + i, 16);
+        memcpy(&b, c + i, 16);
+        lane += a * b;                 /* per-lane mod 2^16 */
+    }
     int s = 0;
     for (int l = 0; l < 8; ++l) s += lane[l];
     return s;
@@ -89,10 +97,13 @@ ip_u16(const uint16_t *q, const uint16_t *c, int dim)
 static inline int
 ip_s16(const int16_t *q, const int16_t *c, int dim)
 {
-    uint16_t lane[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i + 8 <= dim; i += 8)
-        for (int l = 0; l < 8; ++l)
-            lane[l] = (uint16_t)(lane[l] + (uint16_t)((int)q[i + l] * (int)c[i + l]));
+    v8u16 lane = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i + 8 <= dim; i += 8) {
+        v8u16 a, b;
+        memcpy(&a, q + i, 16);
+        memcpy(&b, c + i, 16);
+        lane += a * b;                 /* low 16 bits of the signed product */
+    }
     int s = 0;
     for (int l = 0; l < 8; ++l) s += (int16_t)lane[l];
     return s;

@@ -122,7 +122,7 @@ def make_image_set(num_views: int, feats_per_view: int, *, seed: int = BASE_SEED
                    width: int = 2048, height: int = 2048) -> ImageSet:
     """L landmarks in the ball |p| <= 0.5 with a base descriptor
     each; view v sees a random subset; descriptor = unit(base + noise*N(0,1)),
-    quantised as A1; per-view feature order = descending random 'scale'."""
+    quantised as A1; per-view feature order = descending keypoint scale."""
     n_real = int(round(feats_per_view * (1.0 - distractor_frac)))
     n_dis = feats_per_view - n_real
     L = max(int(round(n_real / visibility)), n_real)
@@ -136,6 +136,10 @@ def make_image_set(num_views: int, feats_per_view: int, *, seed: int = BASE_SEED
     base_sift = normal(seed, st | 3, 128 * L).reshape(L, 128)
     base_sift_u = _unit_rows(np.minimum(_unit_rows(np.abs(base_sift)), 0.2))
     base_surf = _unit_rows(normal(seed, st | 4, 64 * L).reshape(L, 64)) if n_surf else None
+    # intrinsic keypoint scale of a landmark: MVE sorts features by scale,
+    # largest first (feature_set.cc:70), so the low-res prefix of two views
+    # holds largely the same landmarks
+    lm_scale = uniform(seed, st | 5, L)
 
     sift, surf, landmark, pos, cams = [], [], [], [], []
     for v in range(num_views):
@@ -155,8 +159,11 @@ def make_image_set(num_views: int, feats_per_view: int, *, seed: int = BASE_SEED
         f_dis = sift_like(normal(seed, sv | 3, 128 * n_dis).reshape(n_dis, 128))
         f = np.concatenate([f_real, f_dis], axis=0)
         lm = np.concatenate([vis, -np.ones(n_dis, dtype=np.int64)])
-        # descending random scale = a random permutation
-        order = np.argsort(uniform(seed, sv | 4, feats_per_view), kind="stable")
+        # per-view order: descending scale (landmark scale + detection jitter;
+        # distractors get a random scale)
+        jit = uniform(seed, sv | 4, feats_per_view)
+        sc = np.concatenate([lm_scale[vis] + 0.02 * (jit[:n_real] - 0.5), jit[n_real:]])
+        order = np.argsort(-sc, kind="stable")
         sift.append(quantize_sift(f[order]))
         landmark.append(lm[order])
         # positions
@@ -253,3 +260,124 @@ def mat_to_quat(R):
         y = (R[1, 2] + R[2, 1]) / s
         z = 0.25 * s
     return np.array([x, y, z, w])
+
+
+# ---------------------------------------------------------------------------
+# bundle-adjustment scenes
+# ---------------------------------------------------------------------------
+
+MODEL_QUATERNION = 0
+MODEL_EULER = 1
+
+
+class BaScene:
+    """Flattened BA problem (the arrays of osfm_ba_problem) plus ground truth."""
+
+    def __init__(self, model, cam_params, cam_const, img_w, img_h, points, obs_xy, obs_camera,
+                 obs_point, gt_cams, gt_points):
+        self.model = model
+        self.cam_params = cam_params
+        self.cam_const = cam_const
+        self.img_w = img_w
+        self.img_h = img_h
+        self.points = points
+        self.obs_xy = obs_xy
+        self.obs_camera = obs_camera
+        self.obs_point = obs_point
+        self.gt_cams = gt_cams
+        self.gt_points = gt_points
+
+    def copy(self):
+        return BaScene(self.model, self.cam_params.copy(), self.cam_const.copy(), self.img_w.copy(),
+                       self.img_h.copy(), self.points.copy(), self.obs_xy.copy(),
+                       self.obs_camera.copy(), self.obs_point.copy(), self.gt_cams.copy(),
+                       self.gt_points.copy())
+
+
+def _project(model, cam, p, w, h):
+    if model == MODEL_QUATERNION:
+        return project_quat(p, cam[:4], cam[4], cam[5], cam[6], w, h)
+    return project_euler(p, cam[0], cam[1], cam[2], cam[3], cam[4], cam[5], w, h)
+
+
+def make_ba_scene(model: int, num_cameras: int, num_points: int, *, seed: int = BASE_SEED,
+                  config_id: int = 4, min_len: int = 3, max_len: int = 12, noise_px: float = 0.5,
+                  rot_perturb_deg: float = 2.0, off_perturb: float = 0.01,
+                  point_perturb: float = 0.01, width: int = 2048, height: int = 2048,
+                  euler_free: int = 5) -> BaScene:
+    """C cameras on a ring (phi = 360 v / C, theta/rho in +-30 deg), M points
+    in the ball |p| <= 0.5, each seen by a contiguous arc of U{min_len..max_len}
+    cameras; observations = exact projection + N(0, noise_px) stored through
+    float32 (Feature::x/y are float, track.h:26-27).  Start = ground truth
+    perturbed (cameras by rot_perturb_deg / off_perturb, points by
+    point_perturb); camera 0 fixed; scale fixed (OrthoQuaternionCamera.h:89-91
+    / setDegreesOfFreedom(4), OrthographicCamera.cpp:195-207)."""
+    st = config_id << 32
+    C, M = num_cameras, num_points
+    ang = uniform(seed, st | 0x21, 2 * C).reshape(C, 2)
+    gt = np.zeros((C, 7))
+    for c in range(C):
+        phi = 2.0 * np.pi * c / C
+        theta = np.deg2rad(-30.0 + 60.0 * ang[c, 0])
+        rho = np.deg2rad(-30.0 + 60.0 * ang[c, 1])
+        if model == MODEL_QUATERNION:
+            gt[c, :4] = euler_to_quat(phi, theta, rho)
+            gt[c, 4:] = (0.0, 0.0, 1.0)
+        else:
+            gt[c, :6] = (phi, theta, rho, 0.0, 0.0, 1.0)
+    d = _unit_rows(normal(seed, st | 0x22, 3 * M).reshape(M, 3))
+    pts = d * (0.5 * np.cbrt(uniform(seed, st | 0x23, M)))[:, None]
+    ln = min_len + np.floor(uniform(seed, st | 0x24, M) * (max_len - min_len + 1)).astype(np.int64)
+    ln = np.minimum(ln, C)
+    first = np.floor(uniform(seed, st | 0x25, M) * C).astype(np.int64)
+    obs_point = np.repeat(np.arange(M), ln)
+    k_in = np.arange(obs_point.size) - np.repeat(np.cumsum(ln) - ln, ln)
+    obs_camera = (first[obs_point] + k_in) % C
+    O = obs_point.size
+    xy = np.zeros((O, 2))
+    for c in range(C):
+        sel = np.nonzero(obs_camera == c)[0]
+        if sel.size:
+            xy[sel] = _project(model, gt[c], pts[obs_point[sel]], width, height)
+    xy += noise_px * normal(seed, st | 0x26, 2 * O).reshape(O, 2)
+    xy = xy.astype(np.float32).astype(np.float64)
+
+    # perturbed start
+    cams = gt.copy()
+    pr = normal(seed, st | 0x27, 3 * C).reshape(C, 3)
+    po = normal(seed, st | 0x28, 2 * C).reshape(C, 2)
+    for c in range(1, C):
+        if model == MODEL_QUATERNION:
+            axis = pr[c] / np.linalg.norm(pr[c])
+            a = np.deg2rad(rot_perturb_deg)
+            dq = np.array([*(np.sin(a / 2) * axis), np.cos(a / 2)])
+            cams[c, :4] = quat_mul(dq, gt[c, :4])
+            cams[c, 4:6] = gt[c, 4:6] + off_perturb * po[c]
+        else:
+            cams[c, :3] = gt[c, :3] + np.deg2rad(rot_perturb_deg) * pr[c] / np.sqrt(3.0)
+            cams[c, 3:5] = gt[c, 3:5] + off_perturb * po[c]
+    P = np.ones((M, 4))
+    P[:, :3] = pts + point_perturb * normal(seed, st | 0x29, 3 * M).reshape(M, 3)
+
+    const = np.zeros((C, 7), dtype=np.uint8)
+    if model == MODEL_QUATERNION:
+        const[:, 6] = 1                      # m_fixScale = true
+    else:
+        free = [0, 1, 2, 3, 4][:euler_free] if euler_free <= 5 else [0, 1, 2, 3, 4, 5]
+        const[:, :] = 1
+        for s_ in free:
+            const[:, s_] = 0
+    const[0, :] = 1                          # camera 0 fixed (reconstruct.cpp:215)
+    wh = np.full(C, width, dtype=np.int32), np.full(C, height, dtype=np.int32)
+    return BaScene(model, cams, const, wh[0], wh[1], P, xy, obs_camera.astype(np.int32),
+                   obs_point.astype(np.int32), gt, pts)
+
+
+def quat_mul(a, b):
+    """Hamilton product of quaternions stored (x, y, z, w)."""
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by + ay * bw + az * bx - ax * bz,
+                     aw * bz + az * bw + ax * by - ay * bx,
+                     aw * bw - ax * bx - ay * by - az * bz])

@@ -263,3 +263,125 @@ class RefExhaustive:
             self.r.ref_matcher_destroy(self.h)
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------
+# bundle adjustment oracle (oracle/ba_oracle.c)
+# ---------------------------------------------------------------------------
+
+class OBaProblem(C.Structure):
+    _fields_ = [("model", C.c_int32), ("num_cameras", C.c_int32), ("num_points", C.c_int32),
+                ("num_observations", C.c_int32),
+                ("cam_params", C.c_void_p), ("cam_const", C.c_void_p),
+                ("img_width", C.c_void_p), ("img_height", C.c_void_p),
+                ("points", C.c_void_p), ("obs_xy", C.c_void_p),
+                ("obs_camera", C.c_void_p), ("obs_point", C.c_void_p)]
+
+
+class OBaOptions(C.Structure):
+    _fields_ = [("huber_delta", C.c_double), ("function_tolerance", C.c_double),
+                ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("max_num_iterations", C.c_int32), ("optimize_points", C.c_int32),
+                ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+                ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
+                ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+                ("jacobi_scaling", C.c_int32), ("max_consecutive_invalid_steps", C.c_int32),
+                ("device", C.c_int32), ("verbose", C.c_int32)]
+
+
+class OBaSummary(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("num_iterations", C.c_int32), ("num_successful_steps", C.c_int32),
+                ("num_unsuccessful_steps", C.c_int32), ("termination", C.c_int32),
+                ("mean_point_change", C.c_double), ("max_point_change", C.c_double),
+                ("solve_ms", C.c_double), ("linearize_kernel_ms", C.c_double),
+                ("linearize_launches", C.c_int32), ("reserved", C.c_int32)]
+
+
+def ba_default_options(**kw):
+    o = OBaOptions(1.0, 1e-6, 1e-10, 1e-10, 100, 1, 1e4, 1e16, 1e-32, 1e-3, 1e-6, 1e32, 1, 5, 0, 0)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def ba_problem_struct(scene, cls=OBaProblem):
+    """Struct over the scene's arrays (which must stay alive and contiguous)."""
+    for name, dt in (("cam_params", np.float64), ("points", np.float64), ("obs_xy", np.float64)):
+        a = getattr(scene, name)
+        assert a.dtype == dt and a.flags["C_CONTIGUOUS"], name
+    for name, dt in (("img_w", np.int32), ("img_h", np.int32), ("obs_camera", np.int32),
+                     ("obs_point", np.int32)):
+        a = getattr(scene, name)
+        assert a.dtype == dt and a.flags["C_CONTIGUOUS"], name
+    assert scene.cam_const.dtype == np.uint8 and scene.cam_const.flags["C_CONTIGUOUS"]
+    p = cls()
+    p.model = scene.model
+    p.num_cameras = scene.cam_params.shape[0]
+    p.num_points = scene.points.shape[0]
+    p.num_observations = scene.obs_camera.shape[0]
+    p.cam_params = scene.cam_params.ctypes.data
+    p.cam_const = scene.cam_const.ctypes.data
+    p.img_width = scene.img_w.ctypes.data
+    p.img_height = scene.img_h.ctypes.data
+    p.points = scene.points.ctypes.data
+    p.obs_xy = scene.obs_xy.ctypes.data
+    p.obs_camera = scene.obs_camera.ctypes.data
+    p.obs_point = scene.obs_point.ctypes.data
+    return p
+
+
+def oracle_ba_solve(scene, **opt_kw):
+    """Runs the oracle LM in place on scene.cam_params / scene.points."""
+    lib = oracle()
+    p = ba_problem_struct(scene)
+    o = ba_default_options(**opt_kw)
+    s = OBaSummary()
+    lib.oracle_ba_solve.argtypes = [C.POINTER(OBaProblem), C.POINTER(OBaOptions), C.POINTER(OBaSummary)]
+    lib.oracle_ba_solve.restype = C.c_int
+    rc = lib.oracle_ba_solve(C.byref(p), C.byref(o), C.byref(s))
+    assert rc == 0
+    return s
+
+
+def oracle_ba_residuals(scene):
+    lib = oracle()
+    p = ba_problem_struct(scene)
+    O = scene.obs_camera.shape[0]
+    res = np.zeros((O, 2))
+    err = np.zeros(O)
+    lib.oracle_ba_residuals.argtypes = [C.POINTER(OBaProblem), _f64p, _f64p]
+    lib.oracle_ba_residuals.restype = None
+    lib.oracle_ba_residuals(C.byref(p), res.reshape(-1), err)
+    return res, err
+
+
+def oracle_ba_jacobian(scene, k):
+    lib = oracle()
+    p = ba_problem_struct(scene)
+    r = np.zeros(2)
+    jc = np.zeros((2, 7))
+    jp = np.zeros((2, 4))
+    lib.oracle_ba_jacobian.argtypes = [C.POINTER(OBaProblem), C.c_int, _f64p, _f64p, _f64p]
+    lib.oracle_ba_jacobian.restype = None
+    lib.oracle_ba_jacobian(C.byref(p), k, r, jc.reshape(-1), jp.reshape(-1))
+    return r, jc, jp
+
+
+def oracle_ba_triangulate(scene):
+    lib = oracle()
+    p = ba_problem_struct(scene)
+    valid = np.zeros(scene.points.shape[0], dtype=np.uint8)
+    lib.oracle_ba_triangulate.argtypes = [C.POINTER(OBaProblem), np.ctypeslib.ndpointer(np.uint8)]
+    lib.oracle_ba_triangulate.restype = C.c_int
+    lib.oracle_ba_triangulate(C.byref(p), valid)
+    return valid
+
+
+def ba_cost(scene, huber=1.0):
+    """1/2 sum rho(|r|^2) with Huber(delta) per 2-D block, from oracle residuals."""
+    res, _ = oracle_ba_residuals(scene)
+    s = (res ** 2).sum(1)
+    b = huber * huber
+    rho = np.where(s > b, 2.0 * huber * np.sqrt(s) - b, s)
+    return 0.5 * rho.sum()
