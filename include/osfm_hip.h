@@ -253,10 +253,13 @@ typedef struct osfm_ba_summary {
     int32_t termination;              /* OSFM_BA_* */
     double mean_point_change;         /* bundle_adjustment.cpp:150-160 printout */
     double max_point_change;
-    double solve_ms;                  /* device+host wall time of the LM loop */
-    double linearize_kernel_ms;       /* summed device time of the linearise/Schur kernel */
-    int32_t linearize_launches;
-    int32_t reserved;
+    double solve_ms;                  /* device+host wall time of the whole call */
+    double point_pass_ms;             /* summed device time (HIP events) per kernel family */
+    double pair_pass_ms;
+    double cholesky_ms;
+    double back_pass_ms;
+    int32_t linearizations;           /* number of point/pair pass executions timed */
+    int32_t num_pair_entries;         /* observation pairs in the Schur complement lists */
 } osfm_ba_summary;
 
 OSFM_API int osfm_ba_options_default(osfm_ba_options *opts);

@@ -62,8 +62,9 @@ typedef struct {
 typedef struct {
     double initial_cost, final_cost;
     int32_t num_iterations, num_successful_steps, num_unsuccessful_steps, termination;
-    double mean_point_change, max_point_change, solve_ms, linearize_kernel_ms;
-    int32_t linearize_launches, reserved;
+    double mean_point_change, max_point_change, solve_ms;
+    double point_pass_ms, pair_pass_ms, cholesky_ms, back_pass_ms;
+    int32_t linearizations, num_pair_entries;
 } ba_summary;
 
 enum { MODEL_QUAT = 0, MODEL_EULER = 1 };

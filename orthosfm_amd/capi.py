@@ -80,8 +80,10 @@ class BaSummary(C.Structure):
                 ("num_iterations", C.c_int32), ("num_successful_steps", C.c_int32),
                 ("num_unsuccessful_steps", C.c_int32), ("termination", C.c_int32),
                 ("mean_point_change", C.c_double), ("max_point_change", C.c_double),
-                ("solve_ms", C.c_double), ("linearize_kernel_ms", C.c_double),
-                ("linearize_launches", C.c_int32), ("reserved", C.c_int32)]
+                ("solve_ms", C.c_double), ("point_pass_ms", C.c_double),
+                ("pair_pass_ms", C.c_double), ("cholesky_ms", C.c_double),
+                ("back_pass_ms", C.c_double),
+                ("linearizations", C.c_int32), ("num_pair_entries", C.c_int32)]
 
 
 # every symbol include/osfm_hip.h declares (checked by tests/test_capi_symbols.py)

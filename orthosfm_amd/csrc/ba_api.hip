@@ -1,0 +1,542 @@
+// C-ABI implementation of the bundle-adjustment path (include/osfm_hip.h,
+// section B): the Levenberg-Marquardt control loop of ceres::Solve as
+// configured by runBundleAdjustment (bundle_adjustment.cpp:126-145), driving
+// the kernels of ba_kernels.hip / ba_cholesky.hip.  The host only moves a few
+// scalars per iteration and takes the accept/reject decisions.
+//
+// Trust-region logic restated from the published Ceres 2.0/2.1 algorithm
+// (TrustRegionMinimizer, LevenbergMarquardtStrategy); see DESIGN.md for the
+// list of behaviours and the "parity unpinned" note.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "ba_kernels.h"
+#include "osfm_common.h"
+
+using namespace osfm;
+
+namespace {
+
+struct DevArray {
+    void *ptr = nullptr;
+    ~DevArray() { if (ptr) (void)hipFree(ptr); }
+    int alloc(size_t bytes)
+    {
+        if (ptr) { (void)hipFree(ptr); ptr = nullptr; }
+        OSFM_HIP_CHECK(hipMalloc(&ptr, std::max<size_t>(bytes, 16)));
+        return OSFM_OK;
+    }
+    template <typename T> T *as() const { return static_cast<T *>(ptr); }
+};
+
+template <typename T>
+int upload(DevArray &d, const T *src, size_t n, hipStream_t s)
+{
+    OSFM_RETURN_IF(d.alloc(n * sizeof(T)));
+    if (n) OSFM_HIP_CHECK(hipMemcpyAsync(d.ptr, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+    return OSFM_OK;
+}
+
+struct Layout {
+    std::vector<int32_t> cam_ldim, cam_off, pt_start;
+    std::vector<int8_t> colmap;
+    int nc = 0;
+};
+
+int validate_problem(const osfm_ba_problem *p, const char *what)
+{
+    if (!p) { set_error("%s: null problem", what); return OSFM_E_ARG; }
+    if (p->model != OSFM_BA_MODEL_QUATERNION && p->model != OSFM_BA_MODEL_EULER) {
+        set_error("%s: unknown camera model %d", what, p->model); return OSFM_E_ARG;
+    }
+    if (p->num_cameras < 0 || p->num_points < 0 || p->num_observations < 0) {
+        set_error("%s: negative size", what); return OSFM_E_ARG;
+    }
+    if ((p->num_cameras && (!p->cam_params || !p->cam_const || !p->img_width || !p->img_height)) ||
+        (p->num_points && !p->points) ||
+        (p->num_observations && (!p->obs_xy || !p->obs_camera || !p->obs_point))) {
+        set_error("%s: null array", what); return OSFM_E_ARG;
+    }
+    int prev = 0;
+    for (int k = 0; k < p->num_observations; ++k) {
+        const int c = p->obs_camera[k], j = p->obs_point[k];
+        if (c < 0 || c >= p->num_cameras || j < 0 || j >= p->num_points) {
+            set_error("%s: observation %d references camera %d / point %d out of range", what, k, c, j);
+            return OSFM_E_ARG;
+        }
+        if (j < prev) {
+            set_error("%s: obs_point must be non-decreasing (observation %d)", what, k);
+            return OSFM_E_ARG;
+        }
+        prev = j;
+    }
+    return OSFM_OK;
+}
+
+// Tangent layout of the camera blocks (which columns are free), following
+// SetupParameterBlocks (OrthoQuaternionRecoAlgorithm.cpp:121-148,
+// OrthographicReconstructionAlgorithm.cpp:148-178).
+void build_layout(const osfm_ba_problem *p, Layout *L)
+{
+    const int C = p->num_cameras, M = p->num_points, O = p->num_observations;
+    L->cam_ldim.assign(C + 1, 0); L->cam_off.assign(C + 1, 0); L->colmap.assign((size_t)6 * (C + 1), 0);
+    int tot = 0;
+    for (int c = 0; c < C; ++c) {
+        const uint8_t *cc = p->cam_const + 7 * c;
+        int n = 0;
+        int8_t *cm = L->colmap.data() + 6 * c;
+        if (p->model == OSFM_BA_MODEL_QUATERNION) {
+            if (!cc[0]) { cm[n++] = 0; cm[n++] = 1; cm[n++] = 2; }
+            for (int s = 4; s < 7; ++s) if (!cc[s]) cm[n++] = (int8_t)(s - 1);   // full cols 3,4,5
+        } else {
+            for (int s = 0; s < 6; ++s) if (!cc[s]) cm[n++] = (int8_t)s;
+        }
+        L->cam_ldim[c] = n; L->cam_off[c] = tot; tot += n;
+    }
+    L->nc = tot;
+    L->pt_start.assign(M + 2, 0);
+    for (int k = 0; k < O; ++k) L->pt_start[p->obs_point[k] + 1]++;
+    for (int j = 0; j < M; ++j) L->pt_start[j + 1] += L->pt_start[j];
+}
+
+struct PairLists {
+    std::vector<int32_t> c1, c2, start, ea, eb;
+};
+
+// Observation pairs (a, b) of one track grouped by camera pair (cam(a) >=
+// cam(b)); the diagonal pair (c, c) holds (a, a) for every observation of c.
+void build_pair_lists(const osfm_ba_problem *p, const Layout &L, bool with_points, PairLists *out)
+{
+    const int C = p->num_cameras, M = p->num_points;
+    std::vector<int32_t> count((size_t)C * C, 0);
+    auto active = [&](int c) { return L.cam_ldim[c] > 0; };
+    for (int j = 0; j < M; ++j) {
+        const int k0 = L.pt_start[j], k1 = L.pt_start[j + 1];
+        for (int a = k0; a < k1; ++a) {
+            const int ca = p->obs_camera[a];
+            if (!active(ca)) continue;
+            for (int b = with_points ? k0 : a; b < (with_points ? k1 : a + 1); ++b) {
+                const int cb = p->obs_camera[b];
+                if (!active(cb) || ca < cb) continue;
+                count[(size_t)ca * C + cb]++;
+            }
+        }
+    }
+    std::vector<int32_t> slot((size_t)C * C, -1);
+    out->c1.clear(); out->c2.clear(); out->start.clear();
+    int total = 0;
+    for (int a = 0; a < C; ++a)
+        for (int b = 0; b <= a; ++b) {
+            const int n = count[(size_t)a * C + b];
+            if (!n) continue;
+            slot[(size_t)a * C + b] = (int)out->c1.size();
+            out->c1.push_back(a); out->c2.push_back(b); out->start.push_back(total);
+            total += n;
+        }
+    out->start.push_back(total);
+    out->ea.assign(total, 0); out->eb.assign(total, 0);
+    std::vector<int32_t> fill(out->c1.size(), 0);
+    for (int j = 0; j < M; ++j) {
+        const int k0 = L.pt_start[j], k1 = L.pt_start[j + 1];
+        for (int a = k0; a < k1; ++a) {
+            const int ca = p->obs_camera[a];
+            if (!active(ca)) continue;
+            for (int b = with_points ? k0 : a; b < (with_points ? k1 : a + 1); ++b) {
+                const int cb = p->obs_camera[b];
+                if (!active(cb) || ca < cb) continue;
+                const int sidx = slot[(size_t)ca * C + cb];
+                const int pos = out->start[sidx] + fill[sidx]++;
+                out->ea[pos] = a; out->eb[pos] = b;
+            }
+        }
+    }
+}
+
+struct DeviceProblem {
+    DevArray cams[2], points[2], obs_xy, obs_cam, obs_pt, pt_start, img_w, img_h;
+    DevArray cam_ldim, cam_off, colmap, scale_c, scale_p;
+    BaDev dev;
+};
+
+int upload_problem(const osfm_ba_problem *p, const Layout &L, double huber, int pdim, hipStream_t s,
+    DeviceProblem *D)
+{
+    const int C = p->num_cameras, M = p->num_points, O = p->num_observations;
+    OSFM_RETURN_IF(upload(D->cams[0], p->cam_params, (size_t)7 * C, s));
+    OSFM_RETURN_IF(D->cams[1].alloc((size_t)7 * C * 8));
+    OSFM_RETURN_IF(upload(D->points[0], p->points, (size_t)4 * M, s));
+    OSFM_RETURN_IF(D->points[1].alloc((size_t)4 * M * 8));
+    OSFM_RETURN_IF(upload(D->obs_xy, p->obs_xy, (size_t)2 * O, s));
+    OSFM_RETURN_IF(upload(D->obs_cam, p->obs_camera, (size_t)O, s));
+    OSFM_RETURN_IF(upload(D->obs_pt, p->obs_point, (size_t)O, s));
+    OSFM_RETURN_IF(upload(D->pt_start, L.pt_start.data(), (size_t)M + 1, s));
+    OSFM_RETURN_IF(upload(D->img_w, p->img_width, (size_t)C, s));
+    OSFM_RETURN_IF(upload(D->img_h, p->img_height, (size_t)C, s));
+    OSFM_RETURN_IF(upload(D->cam_ldim, L.cam_ldim.data(), (size_t)C, s));
+    OSFM_RETURN_IF(upload(D->cam_off, L.cam_off.data(), (size_t)C, s));
+    OSFM_RETURN_IF(upload(D->colmap, L.colmap.data(), (size_t)6 * C, s));
+    std::vector<double> ones((size_t)std::max(L.nc, 3 * M) + 1, 1.0);
+    OSFM_RETURN_IF(upload(D->scale_c, ones.data(), (size_t)L.nc, s));
+    OSFM_RETURN_IF(upload(D->scale_p, ones.data(), (size_t)3 * M, s));
+    BaDev &d = D->dev;
+    d.model = p->model; d.C = C; d.M = M; d.O = O; d.nc = L.nc; d.pdim = pdim;
+    d.cams = D->cams[0].as<double>(); d.points = D->points[0].as<double>();
+    d.obs_xy = D->obs_xy.as<double>(); d.obs_cam = D->obs_cam.as<int32_t>(); d.obs_pt = D->obs_pt.as<int32_t>();
+    d.pt_start = D->pt_start.as<int32_t>(); d.img_w = D->img_w.as<int32_t>(); d.img_h = D->img_h.as<int32_t>();
+    d.cam_ldim = D->cam_ldim.as<int32_t>(); d.cam_off = D->cam_off.as<int32_t>();
+    d.cam_colmap = D->colmap.as<int8_t>();
+    d.scale_c = D->scale_c.as<double>(); d.scale_p = D->scale_p.as<double>();
+    d.huber = huber;
+    // the staging vectors above are locals: make sure the copies have landed
+    OSFM_HIP_CHECK(hipStreamSynchronize(s));
+    return OSFM_OK;
+}
+
+struct StreamGuard {
+    hipStream_t s = nullptr;
+    ~StreamGuard() { if (s) (void)hipStreamDestroy(s); }
+};
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+
+int select_device(int device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available (this backend has no CPU fallback)");
+        return OSFM_E_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range [0,%d)", device, ndev); return OSFM_E_ARG; }
+    OSFM_HIP_CHECK(hipSetDevice(device));
+    return OSFM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int osfm_ba_options_default(osfm_ba_options *o)
+{
+    if (!o) { set_error("ba_options_default: null"); return OSFM_E_ARG; }
+    o->huber_delta = 1.0;
+    o->function_tolerance = 1e-6;
+    o->gradient_tolerance = 1e-10;
+    o->parameter_tolerance = 1e-10;
+    o->max_num_iterations = 100;
+    o->optimize_points = 1;
+    o->initial_trust_region_radius = 1e4;
+    o->max_trust_region_radius = 1e16;
+    o->min_trust_region_radius = 1e-32;
+    o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->jacobi_scaling = 1;
+    o->max_consecutive_invalid_steps = 5;
+    o->device = 0;
+    o->verbose = 0;
+    return OSFM_OK;
+}
+
+int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_summary *sum)
+{
+    if (!sum) { set_error("ba_solve: null summary"); return OSFM_E_ARG; }
+    memset(sum, 0, sizeof(*sum));
+    OSFM_RETURN_IF(validate_problem(p, "ba_solve"));
+    osfm_ba_options o;
+    if (opt) o = *opt; else osfm_ba_options_default(&o);
+    OSFM_RETURN_IF(select_device(o.device));
+    const auto t_begin = std::chrono::steady_clock::now();
+
+    const int C = p->num_cameras, M = p->num_points;
+    Layout L;
+    build_layout(p, &L);
+    const int pdim = o.optimize_points ? 3 : 0;
+    const int nc = L.nc;
+    PairLists PL;
+    build_pair_lists(p, L, pdim != 0, &PL);
+    const int num_pairs = (int)PL.c1.size();
+    sum->num_pair_entries = (int)PL.ea.size();
+
+    StreamGuard sg;
+    OSFM_HIP_CHECK(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
+    hipStream_t s = sg.s;
+    EventPair ev[4];
+    for (auto &e : ev) { OSFM_HIP_CHECK(hipEventCreate(&e.a)); OSFM_HIP_CHECK(hipEventCreate(&e.b)); }
+
+    DeviceProblem D;
+    OSFM_RETURN_IF(upload_problem(p, L, o.huber_delta, pdim, s, &D));
+    BaDev &d = D.dev;
+
+    DevArray pair_c1, pair_c2, pair_start, entry_a, entry_b;
+    OSFM_RETURN_IF(upload(pair_c1, PL.c1.data(), PL.c1.size(), s));
+    OSFM_RETURN_IF(upload(pair_c2, PL.c2.data(), PL.c2.size(), s));
+    OSFM_RETURN_IF(upload(pair_start, PL.start.data(), PL.start.size(), s));
+    OSFM_RETURN_IF(upload(entry_a, PL.ea.data(), PL.ea.size(), s));
+    OSFM_RETURN_IF(upload(entry_b, PL.eb.data(), PL.eb.size(), s));
+    OSFM_HIP_CHECK(hipStreamSynchronize(s));
+
+    const int blocksM = std::max(1, (M + 255) / 256);
+    const int N = cholesky_padded_dim(std::max(nc, 1));
+    DevArray diag_c, diag_p, vinv, ge, S, S_init, Ldiag, y_c, partA, partB, partC, part_cam, gmax_cam, scalars, info;
+    OSFM_RETURN_IF(diag_c.alloc((size_t)nc * 8));
+    OSFM_RETURN_IF(diag_p.alloc((size_t)3 * M * 8));
+    OSFM_RETURN_IF(vinv.alloc((size_t)9 * M * 8));
+    OSFM_RETURN_IF(ge.alloc((size_t)3 * M * 8));
+    const size_t s_elems = (size_t)(N + 32) * N;
+    OSFM_RETURN_IF(S.alloc(s_elems * 8));
+    OSFM_RETURN_IF(S_init.alloc(s_elems * 8));
+    OSFM_RETURN_IF(Ldiag.alloc((size_t)N * 32 * 8));
+    OSFM_RETURN_IF(y_c.alloc((size_t)N * 8));
+    OSFM_RETURN_IF(partA.alloc((size_t)3 * blocksM * 8));
+    OSFM_RETURN_IF(partB.alloc((size_t)3 * blocksM * 8));
+    OSFM_RETURN_IF(partC.alloc((size_t)blocksM * 8));
+    OSFM_RETURN_IF(part_cam.alloc((size_t)2 * std::max(C, 1) * 8));
+    OSFM_RETURN_IF(gmax_cam.alloc((size_t)std::max(C, 1) * 8));
+    OSFM_RETURN_IF(scalars.alloc(16 * 8));
+    OSFM_RETURN_IF(info.alloc(16));
+    {   // S template: zeros with identity on the padding diagonal
+        std::vector<double> h(s_elems, 0.0);
+        for (int i = nc; i < N; ++i) h[(size_t)i * N + i] = 1.0;
+        OSFM_HIP_CHECK(hipMemcpyAsync(S_init.ptr, h.data(), s_elems * 8, hipMemcpyHostToDevice, s));
+        OSFM_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    OSFM_HIP_CHECK(hipMemsetAsync(gmax_cam.ptr, 0, (size_t)std::max(C, 1) * 8, s));
+
+    PointPassArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.min_diag = o.min_lm_diagonal; pa.max_diag = o.max_lm_diagonal;
+    pa.diag_p = diag_p.as<double>(); pa.vinv = vinv.as<double>(); pa.ge = ge.as<double>();
+    pa.scale_p_out = D.scale_p.as<double>(); pa.partials = partA.as<double>();
+    PairPassArgs qa;
+    memset(&qa, 0, sizeof(qa));
+    qa.min_diag = o.min_lm_diagonal; qa.max_diag = o.max_lm_diagonal;
+    qa.num_pairs = num_pairs;
+    qa.pair_c1 = pair_c1.as<int32_t>(); qa.pair_c2 = pair_c2.as<int32_t>(); qa.pair_start = pair_start.as<int32_t>();
+    qa.entry_a = entry_a.as<int32_t>(); qa.entry_b = entry_b.as<int32_t>();
+    qa.vinv = vinv.as<double>(); qa.ge = ge.as<double>();
+    qa.diag_c = diag_c.as<double>(); qa.scale_c_out = D.scale_c.as<double>();
+    qa.S = S.as<double>(); qa.ldS = N; qa.rhs = S.as<double>() + (size_t)N * N;
+
+    double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
+    bool reuse_diagonal = false;
+    int cur = 0;       // index of the current iterate in cams[] / points[]
+    double h_scal[16];
+    double t_point = 0, t_pair = 0, t_chol = 0, t_back = 0;
+    int n_lin = 0;
+
+    auto set_current = [&](int idx) {
+        cur = idx;
+        d.cams = D.cams[idx].as<double>();
+        d.points = D.points[idx].as<double>();
+    };
+
+    // Evaluates cost / gradient norm at the current iterate and prepares the
+    // normal equations for the current radius:
+    //   h_scal[0] = cost, [1] = gradient max norm (points), [2] = not-PD flag,
+    //   [3] = gradient max norm (cameras)
+    auto linearize = [&](bool new_point) -> int {
+        pa.mode = kPassNormal; pa.update_diag = reuse_diagonal ? 0 : 1; pa.want_gradient = new_point ? 1 : 0;
+        pa.radius = radius;
+        qa.mode = kPassNormal; qa.update_diag = pa.update_diag; qa.want_gradient = pa.want_gradient;
+        qa.radius = radius;
+        OSFM_HIP_CHECK(hipEventRecord(ev[0].a, s));
+        launch_point_pass(d, pa, blocksM, s);
+        OSFM_HIP_CHECK(hipEventRecord(ev[0].b, s));
+        OSFM_HIP_CHECK(hipMemcpyAsync(S.ptr, S_init.ptr, s_elems * 8, hipMemcpyDeviceToDevice, s));
+        OSFM_HIP_CHECK(hipEventRecord(ev[1].a, s));
+        launch_pair_pass(d, qa, s);
+        OSFM_HIP_CHECK(hipEventRecord(ev[1].b, s));
+        if (new_point) launch_cam_gradient(d, qa, gmax_cam.as<double>(), s);
+        launch_reduce(partA.as<double>(), blocksM, 3, 0x6u, scalars.as<double>(), nullptr, 0, 0, 0, s);
+        launch_max_reduce(gmax_cam.as<double>(), std::max(C, 1), scalars.as<double>() + 3, s);
+        OSFM_HIP_CHECK(hipGetLastError());
+        OSFM_HIP_CHECK(hipMemcpyAsync(h_scal, scalars.ptr, 4 * 8, hipMemcpyDeviceToHost, s));
+        OSFM_HIP_CHECK(hipStreamSynchronize(s));
+        float ms = 0.f;
+        OSFM_HIP_CHECK(hipEventElapsedTime(&ms, ev[0].a, ev[0].b)); t_point += ms;
+        OSFM_HIP_CHECK(hipEventElapsedTime(&ms, ev[1].a, ev[1].b)); t_pair += ms;
+        n_lin++;
+        return OSFM_OK;
+    };
+
+    // ---- iteration 0: Jacobi scaling from the unscaled column norms ---------
+    if (o.jacobi_scaling) {
+        pa.mode = kPassScaleInit; qa.mode = kPassScaleInit;
+        pa.radius = qa.radius = radius;
+        launch_point_pass(d, pa, blocksM, s);
+        launch_pair_pass(d, qa, s);
+        OSFM_HIP_CHECK(hipGetLastError());
+    }
+    OSFM_RETURN_IF(linearize(true));
+    double x_cost = h_scal[0];
+    double grad_max = std::max(h_scal[1], h_scal[3]);
+    sum->initial_cost = x_cost;
+    int iteration = 0, invalid_steps = 0, term = OSFM_BA_NO_CONVERGENCE;
+    bool last_successful = false, lin_failed = h_scal[2] != 0.0;
+    reuse_diagonal = true;
+
+    if (!std::isfinite(x_cost)) {
+        set_error("ba_solve: non-finite initial cost");
+        return OSFM_E_NUMERIC;
+    }
+    if (grad_max <= o.gradient_tolerance) term = OSFM_BA_CONVERGENCE_GRADIENT;
+    else for (;;) {
+        // FinalizeIterationAndCheckIfMinimizerCanContinue
+        if (iteration >= o.max_num_iterations) { term = OSFM_BA_NO_CONVERGENCE; break; }
+        if (last_successful && grad_max <= o.gradient_tolerance) { term = OSFM_BA_CONVERGENCE_GRADIENT; break; }
+        if (radius <= o.min_trust_region_radius) { term = OSFM_BA_CONVERGENCE_TRUST_REGION; break; }
+        iteration++;
+        last_successful = false;
+
+        // ---- solve the reduced system, back-substitute, evaluate candidate ----
+        bool step_valid = false;
+        double model_cost_change = 0.0, cand_cost = 0.0, step_norm = 0.0, x_norm = 0.0;
+        if (!lin_failed) {
+            const int nxt = cur ^ 1;
+            OSFM_HIP_CHECK(hipMemsetAsync(info.ptr, 0, 16, s));
+            OSFM_HIP_CHECK(hipEventRecord(ev[2].a, s));
+            if (nc > 0) launch_cholesky_solve(S.as<double>(), nc, Ldiag.as<double>(), y_c.as<double>(), info.as<int>(), s);
+            OSFM_HIP_CHECK(hipEventRecord(ev[2].b, s));
+            OSFM_HIP_CHECK(hipEventRecord(ev[3].a, s));
+            launch_cam_update(d, y_c.as<double>(), D.cams[nxt].as<double>(), part_cam.as<double>(), s);
+            BackPassArgs ba;
+            ba.y_c = y_c.as<double>(); ba.vinv = vinv.as<double>(); ba.ge = ge.as<double>();
+            ba.points_out = D.points[nxt].as<double>(); ba.partials = partB.as<double>();
+            launch_back_pass(d, ba, blocksM, s);
+            OSFM_HIP_CHECK(hipEventRecord(ev[3].b, s));
+            launch_cost_pass(d, D.cams[nxt].as<double>(), D.points[nxt].as<double>(), partC.as<double>(), blocksM, s);
+            // scalars: [0..2] back pass (mcc, |dx|^2, |x|^2), [3..4] cameras (|dx|^2, |x|^2), [5] candidate cost
+            launch_reduce(partB.as<double>(), blocksM, 3, 0u, scalars.as<double>(), part_cam.as<double>(), C, 2, 2, s);
+            launch_reduce(partC.as<double>(), blocksM, 1, 0u, scalars.as<double>() + 5, nullptr, 0, 0, 0, s);
+            OSFM_HIP_CHECK(hipGetLastError());
+            int h_info[4] = { 0, 0, 0, 0 };
+            OSFM_HIP_CHECK(hipMemcpyAsync(h_scal, scalars.ptr, 6 * 8, hipMemcpyDeviceToHost, s));
+            OSFM_HIP_CHECK(hipMemcpyAsync(h_info, info.ptr, 16, hipMemcpyDeviceToHost, s));
+            OSFM_HIP_CHECK(hipStreamSynchronize(s));
+            float ms = 0.f;
+            OSFM_HIP_CHECK(hipEventElapsedTime(&ms, ev[2].a, ev[2].b)); t_chol += ms;
+            OSFM_HIP_CHECK(hipEventElapsedTime(&ms, ev[3].a, ev[3].b)); t_back += ms;
+            model_cost_change = h_scal[0];
+            step_norm = std::sqrt(h_scal[1] + h_scal[3]);
+            x_norm = std::sqrt(h_scal[2] + h_scal[4]);
+            cand_cost = h_scal[5];
+            const bool solve_ok = h_info[0] == 0 && std::isfinite(model_cost_change) && std::isfinite(step_norm);
+            step_valid = solve_ok && model_cost_change > 0.0;
+        }
+        if (!step_valid) {
+            // HandleInvalidStep -> LevenbergMarquardtStrategy::StepIsInvalid
+            if (++invalid_steps >= o.max_consecutive_invalid_steps) { term = OSFM_BA_FAILURE; break; }
+            radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+            sum->num_unsuccessful_steps++;
+            OSFM_RETURN_IF(linearize(false));
+            lin_failed = h_scal[2] != 0.0;
+            continue;
+        }
+        invalid_steps = 0;
+        if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
+
+        // ParameterToleranceReached / FunctionToleranceReached
+        if (step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) { term = OSFM_BA_CONVERGENCE_PARAMETER; break; }
+        const double cost_change = x_cost - cand_cost;
+        if (std::fabs(cost_change) <= o.function_tolerance * x_cost) { term = OSFM_BA_CONVERGENCE_FUNCTION; break; }
+
+        const double relative_decrease = cost_change / model_cost_change;
+        if (relative_decrease > o.min_relative_decrease) {
+            // HandleSuccessfulStep + LevenbergMarquardtStrategy::StepAccepted
+            set_current(cur ^ 1);
+            radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * relative_decrease - 1.0, 3));
+            radius = std::min(o.max_trust_region_radius, radius);
+            decrease_factor = 2.0; reuse_diagonal = false;
+            sum->num_successful_steps++;
+            last_successful = true;
+            OSFM_RETURN_IF(linearize(true));
+            reuse_diagonal = true;
+            x_cost = h_scal[0];
+            grad_max = std::max(h_scal[1], h_scal[3]);
+        } else {
+            // LevenbergMarquardtStrategy::StepRejected
+            radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+            sum->num_unsuccessful_steps++;
+            OSFM_RETURN_IF(linearize(false));
+        }
+        lin_failed = h_scal[2] != 0.0;
+        if (o.verbose)
+            fprintf(stderr, "[osfm ba] it %d cost %.9e radius %.3e\n", iteration, x_cost, radius);
+    }
+
+    // ---- write back the current iterate --------------------------------------
+    std::vector<double> pts0((size_t)4 * M);
+    if (M) memcpy(pts0.data(), p->points, (size_t)4 * M * 8);
+    if (C) OSFM_HIP_CHECK(hipMemcpyAsync(p->cam_params, D.cams[cur].ptr, (size_t)7 * C * 8, hipMemcpyDeviceToHost, s));
+    if (M) OSFM_HIP_CHECK(hipMemcpyAsync(p->points, D.points[cur].ptr, (size_t)4 * M * 8, hipMemcpyDeviceToHost, s));
+    OSFM_HIP_CHECK(hipStreamSynchronize(s));
+    double mx = 0.0, acc = 0.0;
+    for (int j = 0; j < M; ++j) {       // bundle_adjustment.cpp:150-160
+        double dd = 0.0;
+        for (int i = 0; i < 4; ++i) { const double e = pts0[4 * j + i] - p->points[4 * j + i]; dd += e * e; }
+        dd = std::sqrt(dd); mx = std::max(mx, dd); acc += dd;
+    }
+    sum->mean_point_change = M ? acc / M : 0.0;
+    sum->max_point_change = mx;
+    sum->final_cost = x_cost;
+    sum->num_iterations = iteration;
+    sum->termination = term;
+    sum->point_pass_ms = t_point; sum->pair_pass_ms = t_pair; sum->cholesky_ms = t_chol; sum->back_pass_ms = t_back;
+    sum->linearizations = n_lin;
+    sum->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return OSFM_OK;
+}
+
+int osfm_ba_reprojection_errors(const osfm_ba_problem *p, int device, double *err, double *residuals)
+{
+    OSFM_RETURN_IF(validate_problem(p, "ba_reprojection_errors"));
+    if (!err && !residuals) { set_error("ba_reprojection_errors: no output"); return OSFM_E_ARG; }
+    OSFM_RETURN_IF(select_device(device));
+    StreamGuard sg;
+    OSFM_HIP_CHECK(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
+    Layout L;
+    build_layout(p, &L);
+    DeviceProblem D;
+    OSFM_RETURN_IF(upload_problem(p, L, 1.0, 3, sg.s, &D));
+    const int O = p->num_observations;
+    DevArray d_err, d_res;
+    OSFM_RETURN_IF(d_err.alloc((size_t)O * 8));
+    OSFM_RETURN_IF(d_res.alloc((size_t)2 * O * 8));
+    launch_reproj(D.dev, d_err.as<double>(), d_res.as<double>(), sg.s);
+    OSFM_HIP_CHECK(hipGetLastError());
+    if (err && O) OSFM_HIP_CHECK(hipMemcpyAsync(err, d_err.ptr, (size_t)O * 8, hipMemcpyDeviceToHost, sg.s));
+    if (residuals && O) OSFM_HIP_CHECK(hipMemcpyAsync(residuals, d_res.ptr, (size_t)2 * O * 8, hipMemcpyDeviceToHost, sg.s));
+    OSFM_HIP_CHECK(hipStreamSynchronize(sg.s));
+    return OSFM_OK;
+}
+
+int osfm_ba_triangulate(const osfm_ba_problem *p, int device, uint8_t *point_valid)
+{
+    OSFM_RETURN_IF(validate_problem(p, "ba_triangulate"));
+    OSFM_RETURN_IF(select_device(device));
+    StreamGuard sg;
+    OSFM_HIP_CHECK(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
+    Layout L;
+    build_layout(p, &L);
+    DeviceProblem D;
+    OSFM_RETURN_IF(upload_problem(p, L, 1.0, 3, sg.s, &D));
+    const int M = p->num_points;
+    DevArray d_valid;
+    OSFM_RETURN_IF(d_valid.alloc((size_t)std::max(M, 1)));
+    // points of tracks with fewer than two rays keep their input value
+    OSFM_HIP_CHECK(hipMemcpyAsync(D.points[1].ptr, D.points[0].ptr, (size_t)4 * M * 8, hipMemcpyDeviceToDevice, sg.s));
+    launch_triangulate(D.dev, D.points[1].as<double>(), d_valid.as<uint8_t>(), sg.s);
+    OSFM_HIP_CHECK(hipGetLastError());
+    if (M) OSFM_HIP_CHECK(hipMemcpyAsync(p->points, D.points[1].ptr, (size_t)4 * M * 8, hipMemcpyDeviceToHost, sg.s));
+    if (point_valid && M) OSFM_HIP_CHECK(hipMemcpyAsync(point_valid, d_valid.ptr, (size_t)M, hipMemcpyDeviceToHost, sg.s));
+    OSFM_HIP_CHECK(hipStreamSynchronize(sg.s));
+    return OSFM_OK;
+}
+
+}  // extern "C"

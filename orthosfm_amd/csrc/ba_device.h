@@ -1,0 +1,376 @@
+// Device math of the bundle-adjustment path (hot path B): the two
+// orthographic reprojection residuals with hand-derived analytic Jacobians,
+// the two manifold operations and small dense helpers.  All double precision.
+//
+// Reference formulas:
+//   quaternion model: src/algorithms/orthographic_quaternion/
+//       OrthographicQuaternionReprojectorError.h:24-67
+//   Euler model:      src/algorithms/orthographic/OrthographicReprojectionError.h:26-77
+//   manifolds: ceres::EigenQuaternionParameterization and
+//       ceres::HomogeneousVectorParameterization(4) as wired in
+//       OrthoQuaternionRecoAlgorithm.cpp:134-139 and bundle_adjustment.cpp:88-90
+//   robustifier: ceres::HuberLoss(1.0), bundle_adjustment.cpp:64
+// (The reference differentiates with ceres::AutoDiffCostFunction; the
+// expressions below are the closed-form derivatives of the same functors.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace osfm {
+
+enum { kModelQuat = 0, kModelEuler = 1 };
+
+struct BaDev {
+    int model, C, M, O, nc, pdim;
+    const double *cams;          // [C][7]
+    const double *points;        // [M][4]
+    const double *obs_xy;        // [O][2]
+    const int32_t *obs_cam;      // [O]
+    const int32_t *obs_pt;       // [O]
+    const int32_t *pt_start;     // [M+1]
+    const int32_t *img_w, *img_h;
+    const int32_t *cam_ldim;     // [C] tangent columns of the camera
+    const int32_t *cam_off;      // [C] offset into the camera tangent vector
+    const int8_t *cam_colmap;    // [C][6] tangent column -> full column (0..5)
+    const double *scale_c;       // [nc]  Jacobi column scaling
+    const double *scale_p;       // [3M]
+    double huber;
+};
+
+// Residual (uncorrected) and FULL tangent Jacobians of one observation:
+//   Jc[2][6]: QUAT  columns = (rot d0, d1, d2, offX, offY, scale)
+//             EULER columns = (phi, theta, rho, offX, offY, scale)
+//   JP[2][4]: w.r.t. the homogeneous point (ambient)
+struct ObsFull {
+    double r[2];
+    double Jc[2][6];
+    double JP[2][4];
+};
+
+__device__ __forceinline__ void cross3(const double a[3], const double b[3], double o[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// pixel residual from the local point l (shared tail of both functors)
+//   x_px = W * (((l.x / s) - offX) / (-2) + 0.5)
+__device__ __forceinline__ void pixel_residual(const double l[3], double offx, double offy, double s,
+    double W, double H, double ox, double oy, double r[2])
+{
+    r[0] = W * ((((l[0] / s) - offx) / (-2.0)) + 0.5) - ox;
+    r[1] = H * ((((l[1] / s) - offy) / (-2.0)) + 0.5) - oy;
+}
+
+__device__ __forceinline__ void
+eval_quat(const double *cam, const double *P, double W, double H, double ox, double oy, bool want_j,
+    ObsFull &e)
+{
+    const double qx = cam[0], qy = cam[1], qz = cam[2], qw = cam[3];
+    const double offx = cam[4], offy = cam[5], s = cam[6];
+    const double iw = 1.0 / P[3];
+    const double p[3] = { P[0] / P[3], P[1] / P[3], P[2] / P[3] };
+    const double n2 = qx * qx + qy * qy + qz * qz + qw * qw;
+    // q.inverse() = conj / |q|^2 ; Eigen rotates with v + w*(2 u x v) + u x (2 u x v)
+    const double a[3] = { -qx / n2, -qy / n2, -qz / n2 };
+    const double b = qw / n2;
+    double t[3];
+    cross3(a, p, t);
+    double t2[3] = { 2.0 * t[0], 2.0 * t[1], 2.0 * t[2] };
+    double at2[3];
+    cross3(a, t2, at2);
+    const double l[3] = { p[0] + b * t2[0] + at2[0], p[1] + b * t2[1] + at2[1], p[2] + b * t2[2] + at2[2] };
+    pixel_residual(l, offx, offy, s, W, H, ox, oy, e.r);
+    if (!want_j) return;
+
+    // d r / d l
+    const double gx = -W / (2.0 * s), gy = -H / (2.0 * s);
+    // R = d l / d p = I + 2 b [a]x + 2 [a]x [a]x   (rows 0,1 needed)
+    //   [a]x [a]x = a a^T - |a|^2 I
+    const double aa = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+    double R0[3], R1[3];
+    R0[0] = 1.0 + 2.0 * (a[0] * a[0] - aa);
+    R0[1] = 2.0 * (a[0] * a[1]) - 2.0 * b * a[2];
+    R0[2] = 2.0 * (a[0] * a[2]) + 2.0 * b * a[1];
+    R1[0] = 2.0 * (a[1] * a[0]) + 2.0 * b * a[2];
+    R1[1] = 1.0 + 2.0 * (a[1] * a[1] - aa);
+    R1[2] = 2.0 * (a[1] * a[2]) - 2.0 * b * a[0];
+    // point: d p / d P = [I / w | -p / w]
+    for (int k = 0; k < 3; ++k) { e.JP[0][k] = gx * R0[k] * iw; e.JP[1][k] = gy * R1[k] * iw; }
+    e.JP[0][3] = -gx * (R0[0] * p[0] + R0[1] * p[1] + R0[2] * p[2]) * iw;
+    e.JP[1][3] = -gy * (R1[0] * p[0] + R1[1] * p[1] + R1[2] * p[2]) * iw;
+
+    // d l / d a_k = 2 b (e_k x p) + 2 (e_k x t + a x (e_k x p)) ; d l / d b = 2 t
+    double dl_da[3][2];   // [k][component 0/1 of l]
+    for (int k = 0; k < 3; ++k) {
+        double ek[3] = { 0.0, 0.0, 0.0 };
+        ek[k] = 1.0;
+        double ekp[3], ekt[3], aekp[3];
+        cross3(ek, p, ekp);
+        cross3(ek, t, ekt);
+        cross3(a, ekp, aekp);
+        dl_da[k][0] = 2.0 * b * ekp[0] + 2.0 * (ekt[0] + aekp[0]);
+        dl_da[k][1] = 2.0 * b * ekp[1] + 2.0 * (ekt[1] + aekp[1]);
+    }
+    const double dl_db[2] = { 2.0 * t[0], 2.0 * t[1] };
+    // a_i = -u_i / n2 ; b = w / n2
+    const double u[3] = { qx, qy, qz };
+    const double in2 = 1.0 / n2, in4 = in2 * in2;
+    double Jq[2][4];       // d l_{0,1} / d (qx, qy, qz, qw)
+    for (int m = 0; m < 3; ++m) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            const double dai = (i == m ? -in2 : 0.0) + 2.0 * u[i] * u[m] * in4;
+            s0 += dl_da[i][0] * dai;
+            s1 += dl_da[i][1] * dai;
+        }
+        const double dbm = -2.0 * qw * u[m] * in4;
+        Jq[0][m] = s0 + dl_db[0] * dbm;
+        Jq[1][m] = s1 + dl_db[1] * dbm;
+    }
+    {
+        double s0 = 0.0, s1 = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            const double dai = 2.0 * u[i] * qw * in4;
+            s0 += dl_da[i][0] * dai;
+            s1 += dl_da[i][1] * dai;
+        }
+        const double dbw = in2 - 2.0 * qw * qw * in4;
+        Jq[0][3] = s0 + dl_db[0] * dbw;
+        Jq[1][3] = s1 + dl_db[1] * dbw;
+    }
+    // tangent of EigenQuaternionParameterization: 4x3 plus-Jacobian rows (x,y,z,w)
+    //   [ w  z -y ; -z  w  x ;  y -x  w ; -x -y -z ]
+    const double PJ[4][3] = { { qw, qz, -qy }, { -qz, qw, qx }, { qy, -qx, qw }, { -qx, -qy, -qz } };
+    for (int c = 0; c < 3; ++c) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int i = 0; i < 4; ++i) { s0 += Jq[0][i] * PJ[i][c]; s1 += Jq[1][i] * PJ[i][c]; }
+        e.Jc[0][c] = gx * s0;
+        e.Jc[1][c] = gy * s1;
+    }
+    e.Jc[0][3] = W / 2.0; e.Jc[1][3] = 0.0;       // offX
+    e.Jc[0][4] = 0.0;     e.Jc[1][4] = H / 2.0;   // offY
+    e.Jc[0][5] = W * l[0] / (2.0 * s * s);        // scale
+    e.Jc[1][5] = H * l[1] / (2.0 * s * s);
+}
+
+__device__ __forceinline__ void mat3_mul(const double A[3][3], const double B[3][3], double Cm[3][3])
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            Cm[i][j] = A[i][0] * B[0][j] + A[i][1] * B[1][j] + A[i][2] * B[2][j];
+}
+
+__device__ __forceinline__ void
+eval_euler(const double *cam, const double *P, double W, double H, double ox, double oy, bool want_j,
+    ObsFull &e)
+{
+    const double phi = cam[0], theta = cam[1], rho = cam[2];
+    const double offx = cam[3], offy = cam[4], s = cam[5];
+    const double om = theta + 1.57079632679489661923;     // M_PI_2
+    const double iw = 1.0 / P[3];
+    const double p[3] = { P[0] / P[3], P[1] / P[3], P[2] / P[3] };
+    double so, co, sr, cr, sp, cp;
+    sincos(om, &so, &co);
+    sincos(rho, &sr, &cr);
+    sincos(phi, &sp, &cp);
+    const double Rx[3][3] = { { 1, 0, 0 }, { 0, co, -so }, { 0, so, co } };
+    const double Ry[3][3] = { { cr, -sr, 0 }, { sr, cr, 0 }, { 0, 0, 1 } };
+    const double Rz[3][3] = { { cp, -sp, 0 }, { sp, cp, 0 }, { 0, 0, 1 } };
+    double A[3][3], S[3][3];
+    mat3_mul(Rz, Rx, A);
+    mat3_mul(A, Ry, S);
+    const double tp[3] = { p[0], -p[2], p[1] };            // T * p
+    double l[3];
+    for (int i = 0; i < 3; ++i) l[i] = S[0][i] * tp[0] + S[1][i] * tp[1] + S[2][i] * tp[2];
+    pixel_residual(l, offx, offy, s, W, H, ox, oy, e.r);
+    if (!want_j) return;
+    const double gx = -W / (2.0 * s), gy = -H / (2.0 * s);
+    // angle derivatives: d l / d angle = (dS/d angle)^T T p
+    const double dRx[3][3] = { { 0, 0, 0 }, { 0, -so, -co }, { 0, co, -so } };
+    const double dRy[3][3] = { { -sr, -cr, 0 }, { cr, -sr, 0 }, { 0, 0, 0 } };
+    const double dRz[3][3] = { { -sp, -cp, 0 }, { cp, -sp, 0 }, { 0, 0, 0 } };
+    double B1[3][3], dS[3][3];
+    // phi
+    mat3_mul(dRz, Rx, B1);
+    mat3_mul(B1, Ry, dS);
+    e.Jc[0][0] = gx * (dS[0][0] * tp[0] + dS[1][0] * tp[1] + dS[2][0] * tp[2]);
+    e.Jc[1][0] = gy * (dS[0][1] * tp[0] + dS[1][1] * tp[1] + dS[2][1] * tp[2]);
+    // theta
+    mat3_mul(Rz, dRx, B1);
+    mat3_mul(B1, Ry, dS);
+    e.Jc[0][1] = gx * (dS[0][0] * tp[0] + dS[1][0] * tp[1] + dS[2][0] * tp[2]);
+    e.Jc[1][1] = gy * (dS[0][1] * tp[0] + dS[1][1] * tp[1] + dS[2][1] * tp[2]);
+    // rho
+    mat3_mul(A, dRy, dS);
+    e.Jc[0][2] = gx * (dS[0][0] * tp[0] + dS[1][0] * tp[1] + dS[2][0] * tp[2]);
+    e.Jc[1][2] = gy * (dS[0][1] * tp[0] + dS[1][1] * tp[1] + dS[2][1] * tp[2]);
+    e.Jc[0][3] = W / 2.0; e.Jc[1][3] = 0.0;
+    e.Jc[0][4] = 0.0;     e.Jc[1][4] = H / 2.0;
+    e.Jc[0][5] = W * l[0] / (2.0 * s * s);
+    e.Jc[1][5] = H * l[1] / (2.0 * s * s);
+    // point: l = S^T T p ; d l_i / d p = row i of (S^T T):  (S^T T)[i][:] = (S[0][i], S[2][i], -S[1][i])
+    const double R0[3] = { S[0][0], S[2][0], -S[1][0] };
+    const double R1[3] = { S[0][1], S[2][1], -S[1][1] };
+    for (int k = 0; k < 3; ++k) { e.JP[0][k] = gx * R0[k] * iw; e.JP[1][k] = gy * R1[k] * iw; }
+    e.JP[0][3] = -gx * (R0[0] * p[0] + R0[1] * p[1] + R0[2] * p[2]) * iw;
+    e.JP[1][3] = -gy * (R1[0] * p[0] + R1[1] * p[1] + R1[2] * p[2]) * iw;
+}
+
+// internal::ComputeHouseholderVector for a 4-vector (ceres householder_vector.h)
+__device__ __forceinline__ void householder4(const double *x, double v[4], double &beta)
+{
+    const double sigma = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = 1.0;
+    beta = 0.0;
+    const double xp = x[3];
+    if (sigma <= 2.220446049250313e-16) {
+        if (xp < 0.0) beta = 2.0;
+        return;
+    }
+    const double mu = sqrt(xp * xp + sigma);
+    double vp = 1.0;
+    if (xp <= 0.0) vp = xp - mu; else vp = -sigma / (xp + mu);
+    beta = 2.0 * vp * vp / (sigma + vp * vp);
+    v[0] /= vp; v[1] /= vp; v[2] /= vp;
+}
+
+// HomogeneousVectorParameterization(4)::ComputeJacobian: J = |x| * 0.5 * H[:, 0:3]
+__device__ __forceinline__ void homog_jacobian(const double *x, double J[4][3])
+{
+    double v[4], beta;
+    householder4(x, v, beta);
+    const double xn = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+    for (int i = 0; i < 3; ++i) {
+        for (int r = 0; r < 4; ++r) J[r][i] = -0.5 * beta * v[i] * v[r];
+        J[i][i] += 0.5;
+    }
+    for (int r = 0; r < 4; ++r)
+        for (int i = 0; i < 3; ++i) J[r][i] *= xn;
+}
+
+// HomogeneousVectorParameterization(4)::Plus
+__device__ __forceinline__ void homog_plus(const double *x, const double *d, double *out)
+{
+    const double sq = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    if (sq == 0.0) { out[0] = x[0]; out[1] = x[1]; out[2] = x[2]; out[3] = x[3]; return; }
+    const double nd = sqrt(sq);
+    const double nd2 = 0.5 * nd;
+    const double sbd = sin(nd2) / nd2;
+    const double y[4] = { 0.5 * sbd * d[0], 0.5 * sbd * d[1], 0.5 * sbd * d[2], cos(nd2) };
+    double v[4], beta;
+    householder4(x, v, beta);
+    const double xn = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+    const double vy = v[0] * y[0] + v[1] * y[1] + v[2] * y[2] + v[3] * y[3];
+    for (int i = 0; i < 4; ++i) out[i] = xn * (y[i] - v[i] * (beta * vy));
+}
+
+// EigenQuaternionParameterization::Plus, storage (x, y, z, w)
+__device__ __forceinline__ void quat_plus(const double *x, const double *d, double *out)
+{
+    const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (nd > 0.0) {
+        const double sd = sin(nd) / nd;
+        const double dw = cos(nd), dx = sd * d[0], dy = sd * d[1], dz = sd * d[2];
+        const double xx = x[0], xy = x[1], xz = x[2], xw = x[3];
+        out[3] = dw * xw - dx * xx - dy * xy - dz * xz;
+        out[0] = dw * xx + dx * xw + dy * xz - dz * xy;
+        out[1] = dw * xy + dy * xw + dz * xx - dx * xz;
+        out[2] = dw * xz + dz * xw + dx * xy - dy * xx;
+    } else {
+        out[0] = x[0]; out[1] = x[1]; out[2] = x[2]; out[3] = x[3];
+    }
+}
+
+// One observation, ready for the normal equations: Huber-corrected residual,
+// camera tangent Jacobian restricted to the free columns (scaled), point
+// tangent Jacobian (scaled).  rho0 = robustified squared norm (cost = rho0/2).
+struct ObsLin {
+    double r[2];
+    double Jc[2][6];
+    double Jp[2][3];
+    double rho0;
+    int n;        // free camera columns
+    int off;      // offset of the camera in the tangent vector
+};
+
+__device__ __forceinline__ void
+linearize_obs(const BaDev &d, int k, const double *cams, const double *points, bool want_j, ObsLin &o)
+{
+    const int c = d.obs_cam[k], j = d.obs_pt[k];
+    const double *cam = cams + 7 * c;
+    const double *P = points + 4 * j;
+    ObsFull e;
+    if (d.model == kModelQuat)
+        eval_quat(cam, P, (double)d.img_w[c], (double)d.img_h[c], d.obs_xy[2 * k], d.obs_xy[2 * k + 1], want_j, e);
+    else
+        eval_euler(cam, P, (double)d.img_w[c], (double)d.img_h[c], d.obs_xy[2 * k], d.obs_xy[2 * k + 1], want_j, e);
+    const double s = e.r[0] * e.r[0] + e.r[1] * e.r[1];
+    const double a = d.huber, b = a * a;
+    double rho1 = 1.0;
+    if (s > b) {
+        const double rr = sqrt(s);
+        o.rho0 = 2.0 * a * rr - b;
+        rho1 = fmax(a / rr, 2.2250738585072014e-308);
+    } else {
+        o.rho0 = s;
+    }
+    const double sq = sqrt(rho1);
+    o.r[0] = sq * e.r[0];
+    o.r[1] = sq * e.r[1];
+    o.n = d.cam_ldim[c];
+    o.off = d.cam_off[c];
+    if (!want_j) return;
+    for (int t = 0; t < 6; ++t) {
+        if (t < o.n) {
+            const int f = d.cam_colmap[6 * c + t];
+            const double sc = sq * d.scale_c[o.off + t];
+            o.Jc[0][t] = sc * e.Jc[0][f];
+            o.Jc[1][t] = sc * e.Jc[1][f];
+        } else {
+            o.Jc[0][t] = 0.0;
+            o.Jc[1][t] = 0.0;
+        }
+    }
+    if (d.pdim) {
+        double HJ[4][3];
+        homog_jacobian(P, HJ);
+        for (int t = 0; t < 3; ++t) {
+            const double sc = sq * d.scale_p[3 * j + t];
+            o.Jp[0][t] = sc * (e.JP[0][0] * HJ[0][t] + e.JP[0][1] * HJ[1][t] + e.JP[0][2] * HJ[2][t] + e.JP[0][3] * HJ[3][t]);
+            o.Jp[1][t] = sc * (e.JP[1][0] * HJ[0][t] + e.JP[1][1] * HJ[1][t] + e.JP[1][2] * HJ[2][t] + e.JP[1][3] * HJ[3][t]);
+        }
+    } else {
+        for (int t = 0; t < 3; ++t) { o.Jp[0][t] = 0.0; o.Jp[1][t] = 0.0; }
+    }
+}
+
+// inverse of a symmetric positive definite 3x3 via Cholesky; false if not PD
+__device__ __forceinline__ bool inv3_spd(const double A[3][3], double inv[3][3])
+{
+    double l00 = A[0][0];
+    if (!(l00 > 0.0)) return false;
+    l00 = sqrt(l00);
+    const double l10 = A[1][0] / l00, l20 = A[2][0] / l00;
+    double l11 = A[1][1] - l10 * l10;
+    if (!(l11 > 0.0)) return false;
+    l11 = sqrt(l11);
+    const double l21 = (A[2][1] - l20 * l10) / l11;
+    double l22 = A[2][2] - l20 * l20 - l21 * l21;
+    if (!(l22 > 0.0)) return false;
+    l22 = sqrt(l22);
+    for (int c = 0; c < 3; ++c) {
+        const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;
+        const double y0 = e0 / l00;
+        const double y1 = (e1 - l10 * y0) / l11;
+        const double y2 = (e2 - l20 * y0 - l21 * y1) / l22;
+        const double x2 = y2 / l22;
+        const double x1 = (y1 - l21 * x2) / l11;
+        const double x0 = (y0 - l10 * x1 - l20 * x2) / l00;
+        inv[0][c] = x0; inv[1][c] = x1; inv[2][c] = x2;
+    }
+    return true;
+}
+
+}  // namespace osfm

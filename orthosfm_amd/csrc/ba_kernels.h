@@ -1,0 +1,59 @@
+// Launchers and argument blocks of the bundle-adjustment kernels.
+#pragma once
+#include "ba_device.h"
+
+namespace osfm {
+
+enum { kPassNormal = 0, kPassScaleInit = 1 };
+
+struct PointPassArgs {
+    int mode;                 // kPassScaleInit: only derive the Jacobi scaling
+    int update_diag;          // recompute the LM diagonal (reuse_diagonal == false)
+    int want_gradient;        // also reduce |Plus(x,-g) - x|_inf over the points
+    double radius, min_diag, max_diag;
+    double *diag_p;           // [3M] clamped diag(J^T J) of the point columns
+    double *vinv;             // [9M] (V_j + D^2)^-1
+    double *ge;               // [3M] Jp^T r
+    double *scale_p_out;      // [3M] (scale-init mode)
+    double *partials;         // [3][blocks]: cost, gradient max, not-PD flag
+};
+
+struct PairPassArgs {
+    int mode, update_diag, want_gradient;
+    double radius, min_diag, max_diag;
+    int num_pairs;
+    const int32_t *pair_c1, *pair_c2, *pair_start;   // [num_pairs], [num_pairs + 1]
+    const int32_t *entry_a, *entry_b;                // observation indices
+    const double *vinv, *ge;
+    double *diag_c;           // [nc]
+    double *scale_c_out;      // [nc] (scale-init mode)
+    double *S;                // [.][ldS] row-major, lower triangle blocks written
+    int ldS;
+    double *rhs;              // [nc]
+};
+
+struct BackPassArgs {
+    const double *y_c;        // [nc] solution of the reduced system
+    const double *vinv, *ge;
+    double *points_out;       // [M][4] candidate points
+    double *partials;         // [3][blocks]: model cost change, |dx|^2, |x|^2
+};
+
+void launch_point_pass(const BaDev &d, const PointPassArgs &a, int blocks, hipStream_t s);
+void launch_pair_pass(const BaDev &d, const PairPassArgs &a, hipStream_t s);
+void launch_cam_gradient(const BaDev &d, const PairPassArgs &a, double *gmax_out, hipStream_t s);
+void launch_cam_update(const BaDev &d, const double *y_c, double *cams_out, double *partials_cam, hipStream_t s);
+void launch_back_pass(const BaDev &d, const BackPassArgs &a, int blocks, hipStream_t s);
+void launch_cost_pass(const BaDev &d, const double *cams, const double *points, double *partials,
+    int blocks, hipStream_t s);
+void launch_reduce(const double *partials, int n, int num_slots, unsigned max_mask, double *out,
+    const double *extra, int extra_n, int extra_stride, int extra_slots, hipStream_t s);
+void launch_max_reduce(const double *v, int n, double *out, hipStream_t s);
+void launch_reproj(const BaDev &d, double *err, double *residuals, hipStream_t s);
+void launch_triangulate(const BaDev &d, double *points_out, uint8_t *valid, hipStream_t s);
+
+// dense Cholesky solve of the reduced camera system (ba_cholesky.hip)
+int cholesky_padded_dim(int n);
+void launch_cholesky_solve(double *A, int n, double *Ldiag, double *x, int *info, hipStream_t s);
+
+}  // namespace osfm

@@ -1,0 +1,600 @@
+// gfx950 kernels of the bundle-adjustment path (hot path B).
+//
+// One Levenberg-Marquardt iteration of the problem runBundleAdjustment builds
+// (src/bundle_adjustment/bundle_adjustment.cpp:61-145) with the Jacobian never
+// written to memory: every consumer re-derives the 2x(6+3) block of an
+// observation from (camera, point, pixel) in registers.
+//
+//   point_pass   thread per track   V_j = sum Jp^T Jp (+D^2) -> V_j^-1, g_j, cost
+//   pair_pass    wave per camera pair (c1 >= c2) that shares a track:
+//                S[c1][c2] = [c1==c2](sum Jc^T Jc + D^2) - sum Z_a W_b^T,
+//                rhs_c1    = sum Jc^T r - Z_a g_j          (Schur complement)
+//   (dense Cholesky of S: ba_api.hip)
+//   back_pass    thread per track   y_p = V^-1 (g - sum W^T y_c), candidate
+//                point = Plus(P, -scale*y_p), model cost change, step norms
+//   cost_pass    thread per track   cost at the candidate
+// All sums that cross threads use fixed-order two-level reductions (no
+// floating-point atomics): the solve is bit-reproducible run to run.
+#include "ba_kernels.h"
+
+namespace osfm {
+
+// ---- deterministic block reductions ---------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
+    return v;
+}
+
+// per-block partial -> partials[slot * gridDim.x + blockIdx.x]
+template <bool IS_MAX>
+__device__ __forceinline__ void block_partial(double v, double *partials, int slot, double *sh)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = IS_MAX ? wave_max(v) : wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sh[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = IS_MAX ? fmax(t, sh[w]) : t + sh[w];
+        partials[(size_t)slot * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// point pass
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void
+ba_point_pass_kernel(BaDev d, PointPassArgs a)
+{
+    __shared__ double sh[4];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double cost = 0.0, gmax = 0.0;
+    int bad = 0;
+    if (j < d.M) {
+        const int k0 = d.pt_start[j], k1 = d.pt_start[j + 1];
+        double V[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } }, g[3] = { 0, 0, 0 };
+        for (int k = k0; k < k1; ++k) {
+            ObsLin o;
+            linearize_obs(d, k, d.cams, d.points, d.pdim != 0, o);
+            cost += 0.5 * o.rho0;
+            if (d.pdim) {
+                for (int x = 0; x < 3; ++x) {
+                    g[x] += o.Jp[0][x] * o.r[0] + o.Jp[1][x] * o.r[1];
+                    for (int y = 0; y <= x; ++y) V[x][y] += o.Jp[0][x] * o.Jp[0][y] + o.Jp[1][x] * o.Jp[1][y];
+                }
+            }
+        }
+        if (d.pdim) {
+            V[0][1] = V[1][0]; V[0][2] = V[2][0]; V[1][2] = V[2][1];
+            if (a.mode == kPassScaleInit) {
+                // Jacobi scaling, computed once from the unscaled column norms
+                // (TrustRegionMinimizer::EvaluateGradientAndJacobian, iteration 0)
+                for (int x = 0; x < 3; ++x) a.scale_p_out[3 * j + x] = 1.0 / (1.0 + sqrt(V[x][x]));
+            } else {
+                if (a.update_diag)
+                    for (int x = 0; x < 3; ++x)
+                        a.diag_p[3 * j + x] = fmin(fmax(V[x][x], a.min_diag), a.max_diag);
+                for (int x = 0; x < 3; ++x) V[x][x] += a.diag_p[3 * j + x] / a.radius;
+                double Vi[3][3];
+                if (k1 > k0) {
+                    if (!inv3_spd(V, Vi)) bad = 1;
+                } else {
+                    for (int x = 0; x < 3; ++x)
+                        for (int y = 0; y < 3; ++y) Vi[x][y] = x == y ? 1.0 / V[x][x] : 0.0;
+                }
+                for (int x = 0; x < 3; ++x) {
+                    a.ge[3 * j + x] = g[x];
+                    for (int y = 0; y < 3; ++y) a.vinv[9 * j + 3 * x + y] = bad ? 0.0 : Vi[x][y];
+                }
+                if (a.want_gradient) {
+                    // |Plus(x, -g) - x|_inf with the UNSCALED gradient g / scale
+                    double dl[3], out[4];
+                    for (int x = 0; x < 3; ++x) dl[x] = -g[x] / d.scale_p[3 * j + x];
+                    homog_plus(d.points + 4 * j, dl, out);
+                    for (int x = 0; x < 4; ++x) gmax = fmax(gmax, fabs(d.points[4 * j + x] - out[x]));
+                }
+            }
+        }
+    }
+    block_partial<false>(cost, a.partials, 0, sh);
+    block_partial<true>(gmax, a.partials, 1, sh);
+    block_partial<true>((double)bad, a.partials, 2, sh);
+}
+
+void launch_point_pass(const BaDev &d, const PointPassArgs &a, int blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_point_pass_kernel, dim3(blocks), dim3(256), 0, s, d, a);
+}
+
+// ---------------------------------------------------------------------------
+// pair pass: one wave per camera pair
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void
+ba_pair_pass_kernel(BaDev d, PairPassArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int pi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (pi >= a.num_pairs) return;
+    const int c1 = a.pair_c1[pi], c2 = a.pair_c2[pi];
+    const int e0 = a.pair_start[pi], e1 = a.pair_start[pi + 1];
+    const int n1 = d.cam_ldim[c1], n2 = d.cam_ldim[c2];
+    const int o1 = d.cam_off[c1], o2 = d.cam_off[c2];
+    const bool diag_pair = c1 == c2;
+    if (a.mode == kPassScaleInit && !diag_pair) return;
+
+    double acc[6][6];      // - sum Z_a W_b^T  (+ sum Jc^T Jc on the diagonal pair)
+    double U[6];           // diagonal of sum Jc^T Jc (for the LM diagonal)
+    double rhs[6];
+#pragma unroll
+    for (int x = 0; x < 6; ++x) {
+        U[x] = 0.0; rhs[x] = 0.0;
+#pragma unroll
+        for (int y = 0; y < 6; ++y) acc[x][y] = 0.0;
+    }
+    for (int e = e0 + lane; e < e1; e += 64) {
+        const int ka = a.entry_a[e], kb = a.entry_b[e];
+        ObsLin oa;
+        linearize_obs(d, ka, d.cams, d.points, true, oa);
+        if (ka == kb) {
+#pragma unroll
+            for (int x = 0; x < 6; ++x) {
+                rhs[x] += oa.Jc[0][x] * oa.r[0] + oa.Jc[1][x] * oa.r[1];
+                U[x] += oa.Jc[0][x] * oa.Jc[0][x] + oa.Jc[1][x] * oa.Jc[1][x];
+#pragma unroll
+                for (int y = 0; y < 6; ++y) acc[x][y] += oa.Jc[0][x] * oa.Jc[0][y] + oa.Jc[1][x] * oa.Jc[1][y];
+            }
+        }
+        if (d.pdim && a.mode != kPassScaleInit) {
+            const int j = d.obs_pt[ka];
+            const double *Vi = a.vinv + 9 * j;
+            double Z[6][3];
+#pragma unroll
+            for (int x = 0; x < 6; ++x) {
+                double W[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) W[t] = oa.Jc[0][x] * oa.Jp[0][t] + oa.Jc[1][x] * oa.Jp[1][t];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) Z[x][t] = W[0] * Vi[t] + W[1] * Vi[3 + t] + W[2] * Vi[6 + t];
+            }
+            if (ka == kb) {
+                const double *g = a.ge + 3 * j;
+#pragma unroll
+                for (int x = 0; x < 6; ++x) rhs[x] -= Z[x][0] * g[0] + Z[x][1] * g[1] + Z[x][2] * g[2];
+            }
+            ObsLin ob;
+            if (ka == kb) ob = oa; else linearize_obs(d, kb, d.cams, d.points, true, ob);
+#pragma unroll
+            for (int y = 0; y < 6; ++y) {
+                double W2[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) W2[t] = ob.Jc[0][y] * ob.Jp[0][t] + ob.Jc[1][y] * ob.Jp[1][t];
+#pragma unroll
+                for (int x = 0; x < 6; ++x) acc[x][y] -= Z[x][0] * W2[0] + Z[x][1] * W2[1] + Z[x][2] * W2[2];
+            }
+        }
+    }
+    // fixed-order wave reduction
+#pragma unroll
+    for (int x = 0; x < 6; ++x) {
+        U[x] = wave_sum(U[x]);
+        rhs[x] = wave_sum(rhs[x]);
+#pragma unroll
+        for (int y = 0; y < 6; ++y) acc[x][y] = wave_sum(acc[x][y]);
+    }
+    if (lane != 0) return;
+    if (a.mode == kPassScaleInit) {
+        if (diag_pair)
+            for (int x = 0; x < n1; ++x) a.scale_c_out[o1 + x] = 1.0 / (1.0 + sqrt(U[x]));
+        return;
+    }
+    if (diag_pair) {
+        for (int x = 0; x < n1; ++x) {
+            if (a.update_diag) a.diag_c[o1 + x] = fmin(fmax(U[x], a.min_diag), a.max_diag);
+            acc[x][x] += a.diag_c[o1 + x] / a.radius;
+        }
+        for (int x = 0; x < n1; ++x) a.rhs[o1 + x] = rhs[x];
+    }
+    for (int x = 0; x < n1; ++x)
+        for (int y = 0; y < n2; ++y) a.S[(size_t)(o1 + x) * a.ldS + (o2 + y)] = acc[x][y];
+}
+
+void launch_pair_pass(const BaDev &d, const PairPassArgs &a, hipStream_t s)
+{
+    if (a.num_pairs <= 0) return;
+    const int blocks = (a.num_pairs + 3) / 4;
+    hipLaunchKernelGGL(ba_pair_pass_kernel, dim3(blocks), dim3(256), 0, s, d, a);
+}
+
+// Camera part of the gradient-norm test: g_c = sum_a Jc_a^T r_a (unscaled),
+// |Plus(x, -g) - x|_inf per camera.  One wave per camera over its diagonal
+// pair list (entries with a == b).
+__global__ __launch_bounds__(256) void
+ba_cam_gradient_kernel(BaDev d, PairPassArgs a, double *gmax_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int pi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (pi >= a.num_pairs) return;
+    const int c1 = a.pair_c1[pi], c2 = a.pair_c2[pi];
+    if (c1 != c2) return;
+    const int e0 = a.pair_start[pi], e1 = a.pair_start[pi + 1];
+    const int n1 = d.cam_ldim[c1], o1 = d.cam_off[c1];
+    double g[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int e = e0 + lane; e < e1; e += 64) {
+        const int ka = a.entry_a[e];
+        if (ka != a.entry_b[e]) continue;
+        ObsLin oa;
+        linearize_obs(d, ka, d.cams, d.points, true, oa);
+#pragma unroll
+        for (int x = 0; x < 6; ++x) g[x] += oa.Jc[0][x] * oa.r[0] + oa.Jc[1][x] * oa.r[1];
+    }
+#pragma unroll
+    for (int x = 0; x < 6; ++x) g[x] = wave_sum(g[x]);
+    if (lane != 0) return;
+    double dl[6];
+    for (int x = 0; x < 6; ++x) dl[x] = x < n1 ? -g[x] / d.scale_c[o1 + x] : 0.0;
+    const double *cam = d.cams + 7 * c1;
+    double out[7];
+    for (int i = 0; i < 7; ++i) out[i] = cam[i];
+    int t = 0;
+    if (d.model == kModelQuat && n1 > 0 && d.cam_colmap[6 * c1] == 0) { quat_plus(cam, dl, out); t = 3; }
+    for (; t < n1; ++t) {
+        const int f = d.cam_colmap[6 * c1 + t];
+        const int slot = d.model == kModelQuat ? f + 1 : f;     // full col 3,4,5 -> slots 4,5,6
+        out[slot] = cam[slot] + dl[t];
+    }
+    double gm = 0.0;
+    for (int i = 0; i < 7; ++i) gm = fmax(gm, fabs(cam[i] - out[i]));
+    gmax_out[c1] = gm;
+}
+
+void launch_cam_gradient(const BaDev &d, const PairPassArgs &a, double *gmax_out, hipStream_t s)
+{
+    if (a.num_pairs <= 0) return;
+    const int blocks = (a.num_pairs + 3) / 4;
+    hipLaunchKernelGGL(ba_cam_gradient_kernel, dim3(blocks), dim3(256), 0, s, d, a, gmax_out);
+}
+
+// ---------------------------------------------------------------------------
+// candidate cameras: x+ = Plus(x, scale * step), step = -y
+// ---------------------------------------------------------------------------
+__global__ void
+ba_cam_update_kernel(BaDev d, const double *y_c, double *cams_out, double *partials_cam)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.C) return;
+    const double *cam = d.cams + 7 * c;
+    double out[7];
+    for (int i = 0; i < 7; ++i) out[i] = cam[i];
+    const int n = d.cam_ldim[c], off = d.cam_off[c];
+    double dl[6];
+    for (int t = 0; t < 6; ++t) dl[t] = t < n ? -y_c[off + t] * d.scale_c[off + t] : 0.0;
+    int t = 0;
+    if (d.model == kModelQuat && n > 0 && d.cam_colmap[6 * c] == 0) { quat_plus(cam, dl, out); t = 3; }
+    for (; t < n; ++t) {
+        const int f = d.cam_colmap[6 * c + t];
+        const int slot = d.model == kModelQuat ? f + 1 : f;
+        out[slot] = cam[slot] + dl[t];
+    }
+    // norms over the ambient coordinates of the non-constant blocks
+    double sn = 0.0, xn = 0.0;
+    bool act[7] = { false, false, false, false, false, false, false };
+    for (int tt = 0; tt < n; ++tt) {
+        const int f = d.cam_colmap[6 * c + tt];
+        if (d.model == kModelQuat) {
+            if (f < 3) { act[0] = act[1] = act[2] = act[3] = true; } else act[f + 1] = true;
+        } else act[f] = true;
+    }
+    for (int i = 0; i < 7; ++i) {
+        cams_out[7 * c + i] = out[i];
+        if (act[i]) { sn += (cam[i] - out[i]) * (cam[i] - out[i]); xn += cam[i] * cam[i]; }
+    }
+    partials_cam[2 * c] = sn;
+    partials_cam[2 * c + 1] = xn;
+}
+
+void launch_cam_update(const BaDev &d, const double *y_c, double *cams_out, double *partials_cam, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_cam_update_kernel, dim3((d.C + 127) / 128), dim3(128), 0, s, d, y_c, cams_out, partials_cam);
+}
+
+// ---------------------------------------------------------------------------
+// back substitution + model cost change + candidate points
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void
+ba_back_pass_kernel(BaDev d, BackPassArgs a)
+{
+    __shared__ double sh[4];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double mcc = 0.0, sn = 0.0, xn = 0.0;
+    if (j < d.M) {
+        const int k0 = d.pt_start[j], k1 = d.pt_start[j + 1];
+        double step_p[3] = { 0, 0, 0 };
+        if (d.pdim) {
+            double t3[3] = { a.ge[3 * j], a.ge[3 * j + 1], a.ge[3 * j + 2] };
+            for (int k = k0; k < k1; ++k) {
+                ObsLin o;
+                linearize_obs(d, k, d.cams, d.points, true, o);
+                double u0 = 0.0, u1 = 0.0;
+                for (int x = 0; x < 6; ++x)
+                    if (x < o.n) { u0 += o.Jc[0][x] * a.y_c[o.off + x]; u1 += o.Jc[1][x] * a.y_c[o.off + x]; }
+                for (int t = 0; t < 3; ++t) t3[t] -= o.Jp[0][t] * u0 + o.Jp[1][t] * u1;
+            }
+            const double *Vi = a.vinv + 9 * j;
+            for (int x = 0; x < 3; ++x) step_p[x] = -(Vi[3 * x] * t3[0] + Vi[3 * x + 1] * t3[1] + Vi[3 * x + 2] * t3[2]);
+        }
+        // model_cost_change = -(J step)^T (r + J step / 2)  (scaled J, scaled step)
+        for (int k = k0; k < k1; ++k) {
+            ObsLin o;
+            linearize_obs(d, k, d.cams, d.points, true, o);
+            double m0 = 0.0, m1 = 0.0;
+            for (int x = 0; x < 6; ++x)
+                if (x < o.n) { m0 -= o.Jc[0][x] * a.y_c[o.off + x]; m1 -= o.Jc[1][x] * a.y_c[o.off + x]; }
+            for (int t = 0; t < 3; ++t) { m0 += o.Jp[0][t] * step_p[t]; m1 += o.Jp[1][t] * step_p[t]; }
+            mcc -= m0 * (o.r[0] + m0 / 2.0) + m1 * (o.r[1] + m1 / 2.0);
+        }
+        const double *P = d.points + 4 * j;
+        double out[4] = { P[0], P[1], P[2], P[3] };
+        if (d.pdim) {
+            double dl[3];
+            for (int x = 0; x < 3; ++x) dl[x] = step_p[x] * d.scale_p[3 * j + x];
+            homog_plus(P, dl, out);
+            for (int x = 0; x < 4; ++x) { sn += (P[x] - out[x]) * (P[x] - out[x]); xn += P[x] * P[x]; }
+        }
+        for (int x = 0; x < 4; ++x) a.points_out[4 * j + x] = out[x];
+    }
+    block_partial<false>(mcc, a.partials, 0, sh);
+    block_partial<false>(sn, a.partials, 1, sh);
+    block_partial<false>(xn, a.partials, 2, sh);
+}
+
+void launch_back_pass(const BaDev &d, const BackPassArgs &a, int blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_back_pass_kernel, dim3(blocks), dim3(256), 0, s, d, a);
+}
+
+// ---------------------------------------------------------------------------
+// cost at (cams, points) given explicitly
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void
+ba_cost_pass_kernel(BaDev d, const double *cams, const double *points, double *partials)
+{
+    __shared__ double sh[4];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double cost = 0.0;
+    if (j < d.M) {
+        for (int k = d.pt_start[j]; k < d.pt_start[j + 1]; ++k) {
+            ObsLin o;
+            linearize_obs(d, k, cams, points, false, o);
+            cost += 0.5 * o.rho0;
+        }
+    }
+    block_partial<false>(cost, partials, 0, sh);
+}
+
+void launch_cost_pass(const BaDev &d, const double *cams, const double *points, double *partials,
+    int blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_cost_pass_kernel, dim3(blocks), dim3(256), 0, s, d, cams, points, partials);
+}
+
+// ---------------------------------------------------------------------------
+// final fixed-order reduction of the per-block partials into scalars
+//   out[slot] = reduce(partials[slot][0..n))
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void
+ba_reduce_kernel(const double *partials, int n, int num_slots, unsigned max_mask, double *out,
+    const double *extra, int extra_n, int extra_stride, int extra_slots)
+{
+    __shared__ double sh[256];
+    for (int slot = 0; slot < num_slots + extra_slots; ++slot) {
+        const bool is_extra = slot >= num_slots;
+        const bool is_max = !is_extra && ((max_mask >> slot) & 1u);
+        double v = 0.0;
+        if (!is_extra) {
+            for (int i = threadIdx.x; i < n; i += 256) {
+                const double x = partials[(size_t)slot * n + i];
+                v = is_max ? fmax(v, x) : v + x;
+            }
+        } else {
+            const int es = slot - num_slots;
+            for (int i = threadIdx.x; i < extra_n; i += 256) v += extra[(size_t)i * extra_stride + es];
+        }
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int st = 128; st >= 1; st >>= 1) {
+            if ((int)threadIdx.x < st)
+                sh[threadIdx.x] = is_max ? fmax(sh[threadIdx.x], sh[threadIdx.x + st]) : sh[threadIdx.x] + sh[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[slot] = sh[0];
+        __syncthreads();
+    }
+}
+
+void launch_reduce(const double *partials, int n, int num_slots, unsigned max_mask, double *out,
+    const double *extra, int extra_n, int extra_stride, int extra_slots, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, s, partials, n, num_slots, max_mask, out,
+        extra, extra_n, extra_stride, extra_slots);
+}
+
+__global__ void
+ba_max_reduce_kernel(const double *v, int n, double *out)
+{
+    __shared__ double sh[256];
+    double m = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmax(m, v[i]);
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sh[0];
+}
+
+void launch_max_reduce(const double *v, int n, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_max_reduce_kernel, dim3(1), dim3(256), 0, s, v, n, out);
+}
+
+// ---------------------------------------------------------------------------
+// B7: batched evaluateReprojectionError (OrthoQuaternionRecoAlgorithm.cpp:175-194)
+// ---------------------------------------------------------------------------
+__global__ void
+ba_reproj_kernel(BaDev d, double *err, double *residuals)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= d.O) return;
+    const int c = d.obs_cam[k], j = d.obs_pt[k];
+    ObsFull e;
+    if (d.model == kModelQuat)
+        eval_quat(d.cams + 7 * c, d.points + 4 * j, (double)d.img_w[c], (double)d.img_h[c],
+            d.obs_xy[2 * k], d.obs_xy[2 * k + 1], false, e);
+    else
+        eval_euler(d.cams + 7 * c, d.points + 4 * j, (double)d.img_w[c], (double)d.img_h[c],
+            d.obs_xy[2 * k], d.obs_xy[2 * k + 1], false, e);
+    if (residuals) { residuals[2 * k] = e.r[0]; residuals[2 * k + 1] = e.r[1]; }
+    if (err) err[k] = sqrt(e.r[0] * e.r[0] + e.r[1] * e.r[1]);
+}
+
+void launch_reproj(const BaDev &d, double *err, double *residuals, hipStream_t s)
+{
+    if (d.O <= 0) return;
+    hipLaunchKernelGGL(ba_reproj_kernel, dim3((d.O + 255) / 256), dim3(256), 0, s, d, err, residuals);
+}
+
+// ---------------------------------------------------------------------------
+// B8: triangulateOrthographicTracks + intersectRays
+// (src/triangulation/triangulation.cpp:11-93; camera accessors
+// OrthoQuaternionCamera.cpp:45-59, OrthographicCamera.cpp:63-95,187-193)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void quat_rot(const double *q, const double v[3], double out[3])
+{
+    const double u[3] = { q[0], q[1], q[2] };
+    double t[3];
+    cross3(u, v, t);
+    t[0] *= 2.0; t[1] *= 2.0; t[2] *= 2.0;
+    double ut[3];
+    cross3(u, t, ut);
+    out[0] = v[0] + q[3] * t[0] + ut[0];
+    out[1] = v[1] + q[3] * t[1] + ut[1];
+    out[2] = v[2] + q[3] * t[2] + ut[2];
+}
+
+__device__ void camera_ray(const BaDev &d, int c, double x, double y, double origin[3], double dir[3])
+{
+    const double *cam = d.cams + 7 * c;
+    const double W = (double)d.img_w[c], H = (double)d.img_h[c];
+    if (d.model == kModelQuat) {
+        const double xn = -2.0 * ((x / W) - 0.5) + cam[4];
+        const double yn = -2.0 * ((y / H) - 0.5) + cam[5];
+        const double loc[3] = { cam[6] * xn, cam[6] * yn, -10.0 };
+        const double z[3] = { 0.0, 0.0, 1.0 };
+        quat_rot(cam, loc, origin);
+        quat_rot(cam, z, dir);
+    } else {
+        const double om = cam[1] + 0.5 * 3.14159265358979323846, ph = cam[0], ro = cam[2];
+        const double Ry[3][3] = { { cos(ro), -sin(ro), 0 }, { sin(ro), cos(ro), 0 }, { 0, 0, 1 } };
+        const double Rx[3][3] = { { 1, 0, 0 }, { 0, cos(om), -sin(om) }, { 0, sin(om), cos(om) } };
+        const double Rz[3][3] = { { cos(ph), -sin(ph), 0 }, { sin(ph), cos(ph), 0 }, { 0, 0, 1 } };
+        double A[3][3], S[3][3];
+        mat3_mul(Rz, Rx, A);
+        mat3_mul(A, Ry, S);
+        const double xn = -2.0 * ((x / W) - 0.5) + cam[3];
+        const double yn = -2.0 * ((y / H) - 0.5) + cam[4];
+        // toCameraSpace(v) = T^T S v = (s0, s2, -s1)
+        auto tcs = [&](double v0, double v1, double v2, double o[3]) {
+            const double s0 = S[0][0] * v0 + S[0][1] * v1 + S[0][2] * v2;
+            const double s1 = S[1][0] * v0 + S[1][1] * v1 + S[1][2] * v2;
+            const double s2 = S[2][0] * v0 + S[2][1] * v1 + S[2][2] * v2;
+            o[0] = s0; o[1] = s2; o[2] = -s1;
+        };
+        double ax[3], ay[3], org[3];
+        tcs(1, 0, 0, ax);
+        tcs(0, 1, 0, ay);
+        tcs(0, 0, -10.0, org);
+        tcs(0, 0, 1, dir);
+        for (int i = 0; i < 3; ++i) origin[i] = org[i] + xn * ax[i] * cam[5] + yn * ay[i] * cam[5];
+    }
+}
+
+__device__ void eig3_jacobi(double A[3][3], double V[3][3], double w[3])
+{
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off < 1e-300) break;
+        for (int pp = 0; pp < 2; ++pp)
+            for (int q = pp + 1; q < 3; ++q) {
+                if (fabs(A[pp][q]) < 1e-300) continue;
+                const double th = (A[q][q] - A[pp][pp]) / (2.0 * A[pp][q]);
+                const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = A[k][pp], akq = A[k][q];
+                    A[k][pp] = cs * akp - sn * akq; A[k][q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = A[pp][k], aqk = A[q][k];
+                    A[pp][k] = cs * apk - sn * aqk; A[q][k] = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[k][pp], vkq = V[k][q];
+                    V[k][pp] = cs * vkp - sn * vkq; V[k][q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < 3; ++i) w[i] = A[i][i];
+}
+
+__global__ void
+ba_triangulate_kernel(BaDev d, double *points_out, uint8_t *valid)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= d.M) return;
+    const int k0 = d.pt_start[j], k1 = d.pt_start[j + 1];
+    if (k1 - k0 < 2) { if (valid) valid[j] = 0; return; }
+    double R[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } }, q[3] = { 0, 0, 0 };
+    for (int k = k0; k < k1; ++k) {
+        double o3[3], dir[3];
+        camera_ray(d, d.obs_cam[k], d.obs_xy[2 * k], d.obs_xy[2 * k + 1], o3, dir);
+        const double n = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+        dir[0] /= n; dir[1] /= n; dir[2] /= n;
+        for (int a = 0; a < 3; ++a) {
+            double row[3];
+            for (int b = 0; b < 3; ++b) { row[b] = (a == b ? 1.0 : 0.0) - dir[a] * dir[b]; R[a][b] += row[b]; }
+            q[a] += row[0] * o3[0] + row[1] * o3[1] + row[2] * o3[2];
+        }
+    }
+    double A[3][3], V[3][3], w[3];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) A[a][b] = R[a][b];
+    eig3_jacobi(A, V, w);
+    const double wmax = fmax(fabs(w[0]), fmax(fabs(w[1]), fabs(w[2])));
+    const double thr = fmax(wmax * 3.0 * 2.220446049250313e-16, 2.2250738585072014e-308);
+    double x[3] = { 0, 0, 0 };
+    for (int i = 0; i < 3; ++i) {
+        if (!(fabs(w[i]) > thr)) continue;
+        const double c = (V[0][i] * q[0] + V[1][i] * q[1] + V[2][i] * q[2]) / w[i];
+        x[0] += c * V[0][i]; x[1] += c * V[1][i]; x[2] += c * V[2][i];
+    }
+    points_out[4 * j] = x[0]; points_out[4 * j + 1] = x[1]; points_out[4 * j + 2] = x[2]; points_out[4 * j + 3] = 1.0;
+    if (valid) valid[j] = 1;
+}
+
+void launch_triangulate(const BaDev &d, double *points_out, uint8_t *valid, hipStream_t s)
+{
+    if (d.M <= 0) return;
+    hipLaunchKernelGGL(ba_triangulate_kernel, dim3((d.M + 127) / 128), dim3(128), 0, s, d, points_out, valid);
+}
+
+}  // namespace osfm
