@@ -108,14 +108,15 @@ class FlatProblem:
 
     def __init__(self, model, cam_params, cam_const, img_w, img_h, points, obs_xy, obs_camera, obs_point):
         self.model = int(model)
-        self.cam_params = np.ascontiguousarray(cam_params, dtype=np.float64).reshape(-1, 7)
-        self.cam_const = np.ascontiguousarray(cam_const, dtype=np.uint8).reshape(-1, 7)
-        self.img_w = np.ascontiguousarray(img_w, dtype=np.int32)
-        self.img_h = np.ascontiguousarray(img_h, dtype=np.int32)
-        self.points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 4)
-        self.obs_xy = np.ascontiguousarray(obs_xy, dtype=np.float64).reshape(-1, 2)
-        self.obs_camera = np.ascontiguousarray(obs_camera, dtype=np.int32)
-        self.obs_point = np.ascontiguousarray(obs_point, dtype=np.int32)
+        # always private copies: the solver updates cam_params / points in place
+        self.cam_params = np.array(cam_params, dtype=np.float64, order="C").reshape(-1, 7)
+        self.cam_const = np.array(cam_const, dtype=np.uint8, order="C").reshape(-1, 7)
+        self.img_w = np.array(img_w, dtype=np.int32, order="C")
+        self.img_h = np.array(img_h, dtype=np.int32, order="C")
+        self.points = np.array(points, dtype=np.float64, order="C").reshape(-1, 4)
+        self.obs_xy = np.array(obs_xy, dtype=np.float64, order="C").reshape(-1, 2)
+        self.obs_camera = np.array(obs_camera, dtype=np.int32, order="C")
+        self.obs_point = np.array(obs_point, dtype=np.int32, order="C")
 
     @classmethod
     def from_scene(cls, sc):
