@@ -1,0 +1,80 @@
+/*
+ * adapter_check.cc -- TEST INFRASTRUCTURE.  Compiled only where the
+ * reference sources exist (this container) into oracle/_ref/adapter_check;
+ * the binary travels to the GPU box.  It runs the product's MVE adapter
+ * (orthosfm_amd/host/mve_hip_matching.h, an sfm::MatchingBase subclass) and
+ * the REFERENCE's own sfm::ExhaustiveMatching side by side through the same
+ * virtual interface on the same random viewports and requires identical
+ * Matching::Result lists and low-res counts.
+ */
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <memory>
+#include <random>
+#include <vector>
+
+#include "sfm/exhaustive_matching.h"
+#include "mve_hip_matching.h"
+
+static void fill_views(sfm::bundler::ViewportList* vl, unsigned seed)
+{
+    std::mt19937 rng(seed);
+    std::normal_distribution<float> nd(0.0f, 1.0f);
+    const int L = 900;
+    std::vector<std::vector<float>> bs(L, std::vector<float>(128)), bu(L, std::vector<float>(64));
+    for (auto& d : bs) { float n = 0; for (auto& x : d) { x = std::fabs(nd(rng)); n += x * x; } n = std::sqrt(n); for (auto& x : d) x /= n; }
+    for (auto& d : bu) { float n = 0; for (auto& x : d) { x = nd(rng); n += x * x; } n = std::sqrt(n); for (auto& x : d) x /= n; }
+    const int counts[5][2] = { { 700, 300 }, { 650, 0 }, { 0, 280 }, { 810, 333 }, { 3, 2 } };
+    vl->resize(5);
+    for (int v = 0; v < 5; ++v) {
+        sfm::FeatureSet& fs = (*vl)[v].features;
+        fs.sift_descriptors.resize(counts[v][0]);
+        for (auto& d : fs.sift_descriptors) {
+            const int id = rng() % L; float n = 0;
+            for (int k = 0; k < 128; ++k) { float x = std::fabs(bs[id][k] + 0.01f * nd(rng)); d.data[k] = x; n += x * x; }
+            n = std::sqrt(n); for (int k = 0; k < 128; ++k) d.data[k] /= n;
+        }
+        fs.surf_descriptors.resize(counts[v][1]);
+        for (auto& d : fs.surf_descriptors) {
+            const int id = rng() % L; float n = 0;
+            for (int k = 0; k < 64; ++k) { float x = bu[id][k] + 0.03f * nd(rng); d.data[k] = x; n += x * x; }
+            n = std::sqrt(n); for (int k = 0; k < 64; ++k) d.data[k] /= n;
+        }
+        fs.positions.resize(counts[v][0] + counts[v][1]);
+    }
+}
+
+int main()
+{
+    sfm::bundler::ViewportList va, vb;
+    fill_views(&va, 7);
+    fill_views(&vb, 7);
+    std::unique_ptr<sfm::MatchingBase> ref(new sfm::ExhaustiveMatching());
+    std::unique_ptr<sfm::MatchingBase> hip(new osfm_adapter::HipMatching(0));
+    ref->init(&va);
+    hip->init(&vb);
+    int checked = 0, valid = 0;
+    for (int a = 0; a < 5; ++a)
+        for (int b = 0; b < 5; ++b) {
+            if (a == b) continue;
+            sfm::Matching::Result r1, r2;
+            ref->pairwise_match(a, b, &r1);
+            hip->pairwise_match(a, b, &r2);
+            if (r1.matches_1_2 != r2.matches_1_2 || r1.matches_2_1 != r2.matches_2_1) {
+                std::fprintf(stderr, "MISMATCH pairwise_match(%d,%d)\n", a, b);
+                return 1;
+            }
+            for (int nf : { 100, 500 }) {
+                const int c1 = ref->pairwise_match_lowres(a, b, nf), c2 = hip->pairwise_match_lowres(a, b, nf);
+                if (c1 != c2) { std::fprintf(stderr, "MISMATCH lowres(%d,%d,%d): %d vs %d\n", a, b, nf, c1, c2); return 1; }
+            }
+            for (int m : r1.matches_1_2) valid += m >= 0;
+            checked++;
+        }
+    bool threw = false;
+    try { hip->init(nullptr); } catch (std::invalid_argument const&) { threw = true; }
+    if (!threw) { std::fprintf(stderr, "init(nullptr) did not throw\n"); return 1; }
+    std::printf("adapter_check ok: %d pairs identical to sfm::ExhaustiveMatching, %d valid matches\n", checked, valid);
+    return 0;
+}

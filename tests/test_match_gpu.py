@@ -236,3 +236,16 @@ def test_error_behaviour(hm):
         m.set_view(0, np.full((3, 128), 300, np.uint16))
     assert e.value.status == capi.E_RANGE
     m.close()
+
+
+def test_cpp_adapter_vs_reference_side_by_side():
+    """oracle/_ref/adapter_check (built in the build container from the
+    reference's own sources + the product's sfm::MatchingBase adapter) drives
+    both matchers through the same C++ virtual interface."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "_ref", "adapter_check")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/adapter_check was not built (reference sources absent)")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "adapter_check ok: 20 pairs identical" in out.stdout
