@@ -150,6 +150,7 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
     std::vector<int64_t> mark_off[2];
     int64_t out_ints = 0, rowpart_recs = 0, colpart_recs = 0, keep_bytes = 0, total_queries = 0;
     int total_blocks[2] = {0, 0}, max_n[2] = {0, 0};
+    bool needs_mask[2] = {false, false};   // some problem is limited below its view size
     int64_t macs = 0, alg_bytes = 0;
 
     for (int p = 0; p < num_pairs; ++p) {
@@ -185,6 +186,7 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
             pr.corrA = (type == 0 ? a.sift_corr : a.surf_corr).as<int32_t>();
             pr.corrB = (type == 0 ? b.sift_corr : b.surf_corr).as<int32_t>();
             const bool empty = pr.n1 == 0 || pr.n2 == 0;
+            if (pr.n1 != (type == 0 ? a.ns : a.nu) || pr.n2 != (type == 0 ? b.ns : b.nu)) needs_mask[type] = true;
             pr.nrb = empty ? 0 : (pr.n1 + kRowsPerBlock - 1) / kRowsPerBlock;
             pr.nseg = empty ? 0 : (pr.n2 + kSegCols - 1) / kSegCols;
             pr.n2stride = round_up(pr.n2, 64);
@@ -255,7 +257,7 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
         int32_t *ecount = m->exact_count.as<int32_t>() + type;
 
         if (total_blocks[type] > 0) { OSFM_HIP_CHECK(hipEventRecord(m->ev[type][0], s)); timed[type] = true; }
-        launch_match_tiles(type == 0 ? 8 : 4, dp, np, total_blocks[type],
+        launch_match_tiles(type == 0 ? 8 : 4, needs_mask[type], dp, np, total_blocks[type],
             m->rowparts.as<RowPart>(), m->colparts.as<ColPart>(), s);
         if (timed[type]) OSFM_HIP_CHECK(hipEventRecord(m->ev[type][1], s));
         launch_match_finish(dp, np, max_n[type], m->rowparts.as<RowPart>(),

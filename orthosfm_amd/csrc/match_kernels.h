@@ -44,7 +44,7 @@ struct LoweTable {
 // wrap-around arithmetic (nearest_neighbor.cc:75-84 and the T-typed state).
 struct ExactItem { int32_t problem; int32_t dir; int32_t query; };
 
-void launch_match_tiles(int ch, const MatchProblem *d_problems, int num_problems,
+void launch_match_tiles(int ch, bool masked, const MatchProblem *d_problems, int num_problems,
     int total_blocks, RowPart *rowparts, ColPart *colparts, hipStream_t s);
 
 void launch_match_finish(const MatchProblem *d_problems, int num_problems,

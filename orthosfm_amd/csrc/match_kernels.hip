@@ -56,26 +56,51 @@ __device__ __forceinline__ int xcd_remap(int bid, int total)
 //   col direction:  (x  << 5) | fr       x = ip - cb_j, fr = 16*rf + reg  (per lane)
 // Both preserve "later index wins on ties" because t / fr grow with the index.
 // ---------------------------------------------------------------------------
-template <int CH, bool MASK_COLS, bool MASK_ROWS>
-__device__ __forceinline__ void
-tile_epilogue(const v16i &acc, int cjt, int fr_base, bool col_valid, unsigned row_valid_bits,
-    v16i &rbest, v16i &rsec, int &cb, int &cs)
+// Three-input integer max / median as single VALU instructions.  Written as
+// asm because hipcc otherwise CSEs max(b, x) between the max3 and med3
+// patterns of the same operands and emits 4-5 two-input ops instead of 2.
+// The operands are always results of compiler-visible VALU ops (the key
+// constructions), never raw MFMA outputs, so no MFMA->VALU wait states are
+// hidden from the hazard recogniser.
+__device__ __forceinline__ int max3i(int a, int b, int c)
 {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int x = acc[r];
-        int rk = (int)(((unsigned)x << 8) + (unsigned)cjt);
-        if (MASK_COLS) rk = col_valid ? rk : kKeyNone;
-        rsec[r] = med3i(rbest[r], rsec[r], rk);
-        rbest[r] = max(rbest[r], rk);
-        int ck = (int)(((unsigned)x << 5) | (unsigned)(fr_base + r));
-        if (MASK_ROWS) ck = ((row_valid_bits >> (fr_base + r)) & 1u) ? ck : kKeyNone;
-        cs = med3i(cb, cs, ck);
-        cb = max(cb, ck);
-    }
+    int r;
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int med3a(int a, int b, int c)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
-template <int CH>
+// Exact running top-2 with three-input ops.  For a state (b >= s) and two new
+// keys x, y:  b' = max3(b, x, y),  s' = max(s, med3(b, x, y))  (the second
+// largest of {b, s, x, y} is s or the median of {b, x, y}).  Four new keys
+// chain two such steps and fold both medians with one max3: 5 ops / 4 keys.
+__device__ __forceinline__ void top2_pair(int &b, int &s, int x, int y)
+{
+    const int m = med3a(b, x, y);
+    b = max3i(b, x, y);
+    s = max(s, m);
+}
+__device__ __forceinline__ void top2_quad(int &b, int &s, int x0, int x1, int x2, int x3)
+{
+    const int m01 = med3a(b, x0, x1);
+    const int b1 = max3i(b, x0, x1);
+    const int m23 = med3a(b1, x2, x3);
+    b = max3i(b1, x2, x3);
+    s = max3i(s, m01, m23);
+}
+
+// MASKED = false: rows >= n1 / columns >= n2 are PADDING descriptors whose
+// stored bytes and corrections make their inner products come out at
+// -2^22 (prepare_*_kernel), so they lose every comparison without a single
+// masking instruction.  MASKED = true (low-res / num_features-limited
+// matching, where the rows behind the limit are real descriptors): explicit
+// per-element masks.
+template <int CH, bool MASKED>
 __global__ __launch_bounds__(256, 2) void
 match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, int total_blocks,
     RowPart *__restrict__ rowparts, ColPart *__restrict__ colparts)
@@ -123,13 +148,15 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
         for (int r = 0; r < 16; ++r)
             ra[rf][r] = pd.corrA[row0 + rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
     }
-    unsigned row_valid_bits = 0;
+    unsigned row_valid_bits = 0xffffffffu;
+    if (MASKED) {
+        row_valid_bits = 0;
 #pragma unroll
-    for (int fr = 0; fr < 32; ++fr) {
-        const int row = row0 + (fr >> 4) * 32 + (fr & 3) + 8 * ((fr >> 2) & 3) + 4 * lh;
-        row_valid_bits |= (row < n1 ? 1u : 0u) << fr;
+        for (int fr = 0; fr < 32; ++fr) {
+            const int row = row0 + (fr >> 4) * 32 + (fr & 3) + 8 * ((fr >> 2) & 3) + 4 * lh;
+            row_valid_bits |= (row < n1 ? 1u : 0u) << fr;
+        }
     }
-    const bool rows_partial = (rb * kRowsPerBlock + kRowsPerBlock > n1);
 
     v16i rbest[2], rsec[2];
 #pragma unroll
@@ -172,35 +199,64 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
         const int buf = t & 1;
         if (t + 1 < ntiles) stage_tile(t + 1, buf ^ 1);
 
-        const bool cols_partial = (col_begin + (t + 1) * kTileCols > n2);
-        int cbj[2];
-        int cb[2] = {kKeyNone, kKeyNone}, cs[2] = {kKeyNone, kKeyNone};
+        // B fragments of the tile: 2 column groups x KS k-steps
+        v4i b[2][KS];
+        int cbj[2], cjt[2];
+        bool col_valid[2];
 #pragma unroll
         for (int cf = 0; cf < 2; ++cf) {
-            // fragments of this 32-column group: KS k-steps
             const int col = cf * 32 + lr;
             const int swz = (col / RPB) % CH;
-            v4i b[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                b[ks] = *reinterpret_cast<const v4i *>(
+                b[cf][ks] = *reinterpret_cast<const v4i *>(
                     bbuf + buf * TILE_BYTES + col * D + (((ks * 2 + lh) ^ swz) * 16));
             cbj[cf] = corrbuf[buf * 64 + col];
-            const int t32 = t * 2 + cf;
-            const int cjt = (int)(((unsigned)cbj[cf] << 8) + (unsigned)t32);
-            const bool col_valid = (col_begin + t * kTileCols + col) < n2;
+            cjt[cf] = (int)(((unsigned)cbj[cf] << 8) + (unsigned)(t * 2 + cf));
+            // opaque to the optimiser: otherwise it re-associates the key into
+            // ((acc + cb) << 8) + t, two ops per element instead of one v_lshl_add_u32
+            asm volatile("" : "+v"(cjt[cf]));
+            col_valid[cf] = (col_begin + t * kTileCols + col) < n2;
+        }
+
+        int cb[2] = {kKeyNone, kKeyNone}, cs[2] = {kKeyNone, kKeyNone};
 #pragma unroll
-            for (int rf = 0; rf < 2; ++rf) {
-                v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rf][0], b[0], ra[rf], 0, 0, 0);
+        for (int rf = 0; rf < 2; ++rf) {
+            v16i acc[2];
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf) {
+                acc[cf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rf][0], b[cf][0], ra[rf], 0, 0, 0);
 #pragma unroll
                 for (int ks = 1; ks < KS; ++ks)
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rf][ks], b[ks], acc, 0, 0, 0);
-                if (!cols_partial && !rows_partial)
-                    tile_epilogue<CH, false, false>(acc, cjt, rf * 16, col_valid, row_valid_bits,
-                        rbest[rf], rsec[rf], cb[cf], cs[cf]);
-                else
-                    tile_epilogue<CH, true, true>(acc, cjt, rf * 16, col_valid, row_valid_bits,
-                        rbest[rf], rsec[rf], cb[cf], cs[cf]);
+                    acc[cf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rf][ks], b[cf][ks], acc[cf], 0, 0, 0);
+            }
+            // row direction: the two column groups feed the same (lane, reg) slot
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int k0 = (int)(((unsigned)acc[0][r] << 8) + (unsigned)cjt[0]);
+                int k1 = (int)(((unsigned)acc[1][r] << 8) + (unsigned)cjt[1]);
+                if (MASKED) {
+                    k0 = col_valid[0] ? k0 : kKeyNone;
+                    k1 = col_valid[1] ? k1 : kKeyNone;
+                }
+                int bb = rbest[rf][r], ss = rsec[rf][r];
+                top2_pair(bb, ss, k0, k1);
+                rbest[rf][r] = bb; rsec[rf][r] = ss;
+            }
+            // column direction: 16 rows of this fragment per column group, in quads
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int c[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int fr = rf * 16 + q * 4 + i;
+                        c[i] = (int)(((unsigned)acc[cf][q * 4 + i] << 5) | (unsigned)fr);
+                        if (MASKED) c[i] = ((row_valid_bits >> fr) & 1u) ? c[i] : kKeyNone;
+                    }
+                    top2_quad(cb[cf], cs[cf], c[0], c[1], c[2], c[3]);
+                }
             }
         }
 
@@ -283,18 +339,21 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
     }
 }
 
-void launch_match_tiles(int ch, const MatchProblem *d_problems, int num_problems,
+void launch_match_tiles(int ch, bool masked, const MatchProblem *d_problems, int num_problems,
     int total_blocks, RowPart *rowparts, ColPart *colparts, hipStream_t s)
 {
     if (total_blocks <= 0) return;
     const int d = ch * 16;
     const size_t lds = 2 * (size_t)kTileCols * d + 2 * 64 * 4 + 2 * 4 * 64 * sizeof(ColPart);
-    if (ch == 8)
-        hipLaunchKernelGGL(match_tile_kernel<8>, dim3(total_blocks), dim3(256), lds, s,
-            d_problems, num_problems, total_blocks, rowparts, colparts);
+    const dim3 grid(total_blocks), block(256);
+    if (ch == 8 && !masked)
+        hipLaunchKernelGGL((match_tile_kernel<8, false>), grid, block, lds, s, d_problems, num_problems, total_blocks, rowparts, colparts);
+    else if (ch == 8)
+        hipLaunchKernelGGL((match_tile_kernel<8, true>), grid, block, lds, s, d_problems, num_problems, total_blocks, rowparts, colparts);
+    else if (!masked)
+        hipLaunchKernelGGL((match_tile_kernel<4, false>), grid, block, lds, s, d_problems, num_problems, total_blocks, rowparts, colparts);
     else
-        hipLaunchKernelGGL(match_tile_kernel<4>, dim3(total_blocks), dim3(256), lds, s,
-            d_problems, num_problems, total_blocks, rowparts, colparts);
+        hipLaunchKernelGGL((match_tile_kernel<4, true>), grid, block, lds, s, d_problems, num_problems, total_blocks, rowparts, colparts);
 }
 
 // ---------------------------------------------------------------------------
@@ -593,7 +652,7 @@ prepare_sift_kernel(const uint16_t *__restrict__ src, int n, int npad, int8_t *_
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int e = lane * 2 + k;
-        int v = row < n ? (int)src[(size_t)row * 128 + e] : 128;   // pad rows: a' = 0
+        int v = row < n ? (int)src[(size_t)row * 128 + e] : 0;     // pad rows: the zero vector
         if (v > 255) { bad = true; v = 255; }
         const int a = v - 128;
         dst[(size_t)row * 128 + e] = (int8_t)a;
@@ -601,7 +660,9 @@ prepare_sift_kernel(const uint16_t *__restrict__ src, int n, int npad, int8_t *_
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
-    if (lane == 0) corr[row] = row < n ? 128 * sum + (1 << 20) : 0;
+    // padding rows: correction of a zero vector minus 2^22, so every inner
+    // product with a padding row comes out at exactly -2^22 (see match_tile_kernel)
+    if (lane == 0) corr[row] = 128 * sum + (1 << 20) - (row < n ? 0 : (1 << 22));
     if (bad) atomicOr(range_err, 1);
 }
 
@@ -619,7 +680,7 @@ prepare_surf_kernel(const int16_t *__restrict__ src, int n, int npad, int8_t *__
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
     if (lane == 0) {
-        corr[row] = 0;
+        corr[row] = row < n ? 0 : -(1 << 22);     // padding rows lose every comparison
         atomicMax(norm2max, sq);
     }
 }
