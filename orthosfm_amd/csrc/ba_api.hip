@@ -283,14 +283,14 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
 
     const int blocksM = std::max(1, (M + 255) / 256);
     const int N = cholesky_padded_dim(std::max(nc, 1));
-    DevArray diag_c, diag_p, vinv, ge, S, S_init, Ldiag, y_c, partA, partB, partC, part_cam, gmax_cam, scalars, info;
+    DevArray obsrec, diag_c, diag_p, vinv, ge, S, Ldiag, y_c, partA, partB, partC, part_cam, gmax_cam, scalars, info;
+    OSFM_RETURN_IF(obsrec.alloc((size_t)std::max(p->num_observations, 1) * kObsRec * 8));
     OSFM_RETURN_IF(diag_c.alloc((size_t)nc * 8));
     OSFM_RETURN_IF(diag_p.alloc((size_t)3 * M * 8));
     OSFM_RETURN_IF(vinv.alloc((size_t)9 * M * 8));
     OSFM_RETURN_IF(ge.alloc((size_t)3 * M * 8));
     const size_t s_elems = (size_t)(N + 32) * N;
     OSFM_RETURN_IF(S.alloc(s_elems * 8));
-    OSFM_RETURN_IF(S_init.alloc(s_elems * 8));
     OSFM_RETURN_IF(Ldiag.alloc((size_t)N * 32 * 8));
     OSFM_RETURN_IF(y_c.alloc((size_t)N * 8));
     OSFM_RETURN_IF(partA.alloc((size_t)3 * blocksM * 8));
@@ -300,12 +300,6 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     OSFM_RETURN_IF(gmax_cam.alloc((size_t)std::max(C, 1) * 8));
     OSFM_RETURN_IF(scalars.alloc(16 * 8));
     OSFM_RETURN_IF(info.alloc(16));
-    {   // S template: zeros with identity on the padding diagonal
-        std::vector<double> h(s_elems, 0.0);
-        for (int i = nc; i < N; ++i) h[(size_t)i * N + i] = 1.0;
-        OSFM_HIP_CHECK(hipMemcpyAsync(S_init.ptr, h.data(), s_elems * 8, hipMemcpyHostToDevice, s));
-        OSFM_HIP_CHECK(hipStreamSynchronize(s));
-    }
     OSFM_HIP_CHECK(hipMemsetAsync(gmax_cam.ptr, 0, (size_t)std::max(C, 1) * 8, s));
 
     PointPassArgs pa;
@@ -313,13 +307,14 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     pa.min_diag = o.min_lm_diagonal; pa.max_diag = o.max_lm_diagonal;
     pa.diag_p = diag_p.as<double>(); pa.vinv = vinv.as<double>(); pa.ge = ge.as<double>();
     pa.scale_p_out = D.scale_p.as<double>(); pa.partials = partA.as<double>();
+    pa.obsrec = obsrec.as<double>();
     PairPassArgs qa;
     memset(&qa, 0, sizeof(qa));
     qa.min_diag = o.min_lm_diagonal; qa.max_diag = o.max_lm_diagonal;
     qa.num_pairs = num_pairs;
     qa.pair_c1 = pair_c1.as<int32_t>(); qa.pair_c2 = pair_c2.as<int32_t>(); qa.pair_start = pair_start.as<int32_t>();
     qa.entry_a = entry_a.as<int32_t>(); qa.entry_b = entry_b.as<int32_t>();
-    qa.vinv = vinv.as<double>(); qa.ge = ge.as<double>();
+    qa.vinv = vinv.as<double>(); qa.ge = ge.as<double>(); qa.obsrec = obsrec.as<double>();
     qa.diag_c = diag_c.as<double>(); qa.scale_c_out = D.scale_c.as<double>();
     qa.S = S.as<double>(); qa.ldS = N; qa.rhs = S.as<double>() + (size_t)N * N;
 
@@ -348,7 +343,8 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
         OSFM_HIP_CHECK(hipEventRecord(ev[0].a, s));
         launch_point_pass(d, pa, blocksM, s);
         OSFM_HIP_CHECK(hipEventRecord(ev[0].b, s));
-        OSFM_HIP_CHECK(hipMemcpyAsync(S.ptr, S_init.ptr, s_elems * 8, hipMemcpyDeviceToDevice, s));
+        OSFM_HIP_CHECK(hipMemsetAsync(S.ptr, 0, s_elems * 8, s));
+        launch_pad_diag(S.as<double>(), N, nc, N, s);
         OSFM_HIP_CHECK(hipEventRecord(ev[1].a, s));
         launch_pair_pass(d, qa, s);
         OSFM_HIP_CHECK(hipEventRecord(ev[1].b, s));
@@ -406,7 +402,7 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
             OSFM_HIP_CHECK(hipEventRecord(ev[3].a, s));
             launch_cam_update(d, y_c.as<double>(), D.cams[nxt].as<double>(), part_cam.as<double>(), s);
             BackPassArgs ba;
-            ba.y_c = y_c.as<double>(); ba.vinv = vinv.as<double>(); ba.ge = ge.as<double>();
+            ba.y_c = y_c.as<double>(); ba.vinv = vinv.as<double>(); ba.ge = ge.as<double>(); ba.obsrec = obsrec.as<double>();
             ba.points_out = D.points[nxt].as<double>(); ba.partials = partB.as<double>();
             launch_back_pass(d, ba, blocksM, s);
             OSFM_HIP_CHECK(hipEventRecord(ev[3].b, s));

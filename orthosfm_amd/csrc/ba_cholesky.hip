@@ -12,8 +12,8 @@
 // kernel then runs the backward substitution x = L^-T y.
 //
 // Right-looking blocked algorithm, block 32:
-//   chol_panel(k):  every row block i >= k factors A_kk in LDS (redundantly,
-//                   32^3/3 flops) and solves its A_ik <- A_ik L_kk^-T
+//   chol_panel(k):  every workgroup factors A_kk redundantly (32^3/3 flops) and
+//                   solves A_ik <- A_ik L_kk^-T for 64 rows of the panel
 //   chol_update(k): A_ij -= L_ik L_jk^T for k < j <= i (incl. the rhs row)
 #include "ba_kernels.h"
 
@@ -21,55 +21,71 @@ namespace osfm {
 
 constexpr int NB = 32;
 
-__global__ __launch_bounds__(256) void
+__device__ __forceinline__ double readlane_d(double x, int l)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+
+// One wave per workgroup.  Every workgroup factors the 32x32 diagonal block
+// with its rows held in registers (lane r = row r; the pivot column is
+// broadcast with v_readlane), workgroup 0 publishes the factor, the others solve
+// X L_kk^T = A_ik for 64 rows of the panel (lane = row, X in registers, L
+// broadcast from LDS).
+__global__ __launch_bounds__(64, 1) void
 chol_panel_kernel(double *A, int ld, int nblk, int k, double *Ldiag, int *info)
 {
-    __shared__ double L[NB][NB + 1];
-    __shared__ double X[NB][NB + 1];
-    const int i = k + blockIdx.x;          // row block (nblk = the rhs block row)
-    const int tid = threadIdx.x;
-    const int r = tid >> 3, c0 = (tid & 7) * 4;   // 32 rows x 8 threads x 4 columns
-    double *Akk = A + (size_t)(k * NB) * ld + k * NB;
-    for (int c = 0; c < 4; ++c) L[r][c0 + c] = Akk[(size_t)r * ld + c0 + c];
-    __syncthreads();
-    // factor the diagonal block in LDS (lower triangle)
+    __shared__ double Ls[NB][NB + 1];
+    const int lane = threadIdx.x, r = lane & 31;
+    const double *Akk = A + (size_t)(k * NB + r) * ld + k * NB;
+    double L[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) L[c] = Akk[c];
+    int bad = 0;
+#pragma unroll
     for (int j = 0; j < NB; ++j) {
-        if (tid == 0) {
-            const double d = L[j][j];
-            if (!(d > 0.0)) { L[j][j] = 1.0; if (i == k) atomicMax(info, k * NB + j + 1); }
-            else L[j][j] = sqrt(d);
-        }
-        __syncthreads();
-        if (tid > j && tid < NB) L[tid][j] /= L[j][j];
-        __syncthreads();
-        // trailing update of the lower triangle: rows > j, cols in (j, row]
-        for (int e = tid; e < NB * NB; e += 256) {
-            const int rr = e / NB, cc = e % NB;
-            if (rr > j && cc > j && cc <= rr) L[rr][cc] -= L[rr][j] * L[cc][j];
-        }
-        __syncthreads();
+        double d = readlane_d(L[j], j);
+        if (!(d > 0.0)) { d = 1.0; bad = j + 1; }
+        const double piv = sqrt(d);
+        const double lj = (r == j && bad == j + 1) ? 1.0 : L[j] / piv;   // lane j: d / sqrt(d) = sqrt(d)
+        L[j] = lj;
+#pragma unroll
+        for (int c = j + 1; c < NB; ++c) L[c] -= lj * readlane_d(lj, c);   // meaningful for r >= c
     }
-    if (i == k) {
-        // the factored diagonal block goes to a side buffer: A_kk itself is
-        // still being read by the other workgroups of this launch
-        double *Lk = Ldiag + (size_t)k * NB * NB;
-        for (int c = 0; c < 4; ++c)
-            Lk[r * NB + c0 + c] = (c0 + c <= r) ? L[r][c0 + c] : 0.0;
+    if (blockIdx.x == 0) {
+        if (bad && lane == 0) atomicMax(info, k * NB + bad);
+        if (lane < NB) {
+            double *Lk = Ldiag + (size_t)k * NB * NB + r * NB;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) Lk[c] = c <= r ? L[c] : 0.0;
+        }
         return;
     }
-    // panel solve: X L_kk^T = A_ik  (one thread per row of the block)
-    double *Aik = A + (size_t)(i * NB) * ld + k * NB;
-    for (int c = 0; c < 4; ++c) X[r][c0 + c] = Aik[(size_t)r * ld + c0 + c];
-    __syncthreads();
-    if (tid < NB) {
-        for (int c = 0; c < NB; ++c) {
-            double v = X[tid][c];
-            for (int m = 0; m < c; ++m) v -= X[tid][m] * L[c][m];
-            X[tid][c] = v / L[c][c];
-        }
+    if (lane < NB) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) Ls[r][c] = c <= r ? L[c] : 0.0;
     }
     __syncthreads();
-    for (int c = 0; c < 4; ++c) Aik[(size_t)r * ld + c0 + c] = X[r][c0 + c];
+    const int row = (k + 1) * NB + (blockIdx.x - 1) * 64 + lane;
+    if (row >= (nblk + 1) * NB) return;
+    double *Ar = A + (size_t)row * ld + k * NB;
+    double X[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) X[c] = Ar[c];
+    // right-looking forward substitution: once x_c is final, retire it from
+    // the later columns (keeps only X live and bounds the loads in flight)
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        asm volatile("" ::: "memory");    // keep the LDS reads of step c behind step c-1
+        const double xc = X[c] / Ls[c][c];
+        X[c] = xc;
+#pragma unroll
+        for (int m = c + 1; m < NB; ++m) X[m] -= xc * Ls[m][c];
+    }
+#pragma unroll
+    for (int c = 0; c < NB; ++c) Ar[c] = X[c];
 }
 
 __global__ __launch_bounds__(256) void
@@ -105,26 +121,32 @@ chol_backsolve_kernel(const double *A, int ld, int nblk, int n, const double *Ld
 {
     extern __shared__ double y[];            // [nblk * NB]
     __shared__ double xk[NB];
+    __shared__ double Lk[NB][NB + 1];
     const int N = nblk * NB;
     const int tid = threadIdx.x;
     for (int c = tid; c < N; c += blockDim.x) y[c] = A[(size_t)N * ld + c];
     __syncthreads();
     for (int k = nblk - 1; k >= 0; --k) {
-        const double *Lkk = Ldiag + (size_t)k * NB * NB;
-        // L_kk^T x_k = y_k, backward substitution by one thread (32 unknowns)
-        if (tid == 0) {
+        Lk[tid >> 5][tid & 31] = Ldiag[(size_t)k * NB * NB + tid];     // 1024 threads = 32 x 32
+        __syncthreads();
+        // L_kk^T x_k = y_k: wave 0, lane m keeps y_m; unknowns resolved last to first
+        if (tid < 64) {
+            const int m = tid & 31;
+            double ym = y[k * NB + m];
             for (int c = NB - 1; c >= 0; --c) {
-                double v = y[k * NB + c];
-                for (int m = c + 1; m < NB; ++m) v -= Lkk[m * NB + c] * xk[m];
-                xk[c] = v / Lkk[c * NB + c];
+                const double xc = __shfl(ym, c) / Lk[c][c];
+                if (m < c) ym -= Lk[c][m] * xc;
+                if (m == c) ym = xc;
             }
+            if (tid < NB) xk[tid] = ym;
         }
         __syncthreads();
         // y_j -= L[k-block rows][j]^T x_k for every column j left of the block
-        const double *Lk = A + (size_t)(k * NB) * ld;
+        const double *Lrow = A + (size_t)(k * NB) * ld;
         for (int c = tid; c < k * NB; c += blockDim.x) {
             double v = y[c];
-            for (int m = 0; m < NB; ++m) v -= Lk[(size_t)m * ld + c] * xk[m];
+#pragma unroll 8
+            for (int m = 0; m < NB; ++m) v -= Lrow[(size_t)m * ld + c] * xk[m];
             y[c] = v;
         }
         if (tid < NB && k * NB + tid < n) x[k * NB + tid] = xk[tid];
@@ -141,8 +163,8 @@ void launch_cholesky_solve(double *A, int n, double *Ldiag, double *x, int *info
     const int N = cholesky_padded_dim(n);
     const int nblk = N / NB;
     for (int k = 0; k < nblk; ++k) {
-        const int rows = nblk - k + 1;          // row blocks k..nblk (incl. rhs row)
-        hipLaunchKernelGGL(chol_panel_kernel, dim3(rows), dim3(256), 0, s, A, N, nblk, k, Ldiag, info);
+        const int below = (nblk - k) * NB;      // rows under the diagonal block (incl. the rhs block row)
+        hipLaunchKernelGGL(chol_panel_kernel, dim3(1 + (below + 63) / 64), dim3(64), 0, s, A, N, nblk, k, Ldiag, info);
         const int t = nblk - k - 1;
         if (t > 0)
             hipLaunchKernelGGL(chol_update_kernel, dim3(t, t + 1), dim3(256), 0, s, A, N, nblk, k);

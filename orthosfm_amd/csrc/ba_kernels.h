@@ -6,6 +6,13 @@ namespace osfm {
 
 enum { kPassNormal = 0, kPassScaleInit = 1 };
 
+// Per-observation record written by the point pass and consumed by the pair,
+// gradient and back-substitution passes of the same linearisation:
+//   Jc[2][6] (Huber-corrected, Jacobi-scaled camera block, unused columns 0),
+//   Jp[2][3], Q[2][3] = Jp (V_j + D^2)^-1, r[2]
+constexpr int kObsRec = 26;
+constexpr int kRecJc = 0, kRecJp = 12, kRecQ = 18, kRecR = 24;
+
 struct PointPassArgs {
     int mode;                 // kPassScaleInit: only derive the Jacobi scaling
     int update_diag;          // recompute the LM diagonal (reuse_diagonal == false)
@@ -16,6 +23,7 @@ struct PointPassArgs {
     double *ge;               // [3M] Jp^T r
     double *scale_p_out;      // [3M] (scale-init mode)
     double *partials;         // [3][blocks]: cost, gradient max, not-PD flag
+    double *obsrec;           // [O][kObsRec]: per-observation blocks of this linearisation
 };
 
 struct PairPassArgs {
@@ -25,6 +33,7 @@ struct PairPassArgs {
     const int32_t *pair_c1, *pair_c2, *pair_start;   // [num_pairs], [num_pairs + 1]
     const int32_t *entry_a, *entry_b;                // observation indices
     const double *vinv, *ge;
+    const double *obsrec;     // [O][kObsRec]
     double *diag_c;           // [nc]
     double *scale_c_out;      // [nc] (scale-init mode)
     double *S;                // [.][ldS] row-major, lower triangle blocks written
@@ -35,6 +44,7 @@ struct PairPassArgs {
 struct BackPassArgs {
     const double *y_c;        // [nc] solution of the reduced system
     const double *vinv, *ge;
+    const double *obsrec;     // [O][kObsRec]
     double *points_out;       // [M][4] candidate points
     double *partials;         // [3][blocks]: model cost change, |dx|^2, |x|^2
 };
@@ -49,6 +59,7 @@ void launch_cost_pass(const BaDev &d, const double *cams, const double *points, 
 void launch_reduce(const double *partials, int n, int num_slots, unsigned max_mask, double *out,
     const double *extra, int extra_n, int extra_stride, int extra_slots, hipStream_t s);
 void launch_max_reduce(const double *v, int n, double *out, hipStream_t s);
+void launch_pad_diag(double *S, int ld, int n, int N, hipStream_t s);
 void launch_reproj(const BaDev &d, double *err, double *residuals, hipStream_t s);
 void launch_triangulate(const BaDev &d, double *points_out, uint8_t *valid, hipStream_t s);
 

@@ -64,8 +64,12 @@ ba_point_pass_kernel(BaDev d, PointPassArgs a)
         double V[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } }, g[3] = { 0, 0, 0 };
         for (int k = k0; k < k1; ++k) {
             ObsLin o;
-            linearize_obs(d, k, d.cams, d.points, d.pdim != 0, o);
+            linearize_obs(d, k, d.cams, d.points, true, o);
             cost += 0.5 * o.rho0;
+            double *rec = a.obsrec + (size_t)k * kObsRec;
+            for (int x = 0; x < 6; ++x) { rec[kRecJc + x] = o.Jc[0][x]; rec[kRecJc + 6 + x] = o.Jc[1][x]; }
+            for (int x = 0; x < 3; ++x) { rec[kRecJp + x] = o.Jp[0][x]; rec[kRecJp + 3 + x] = o.Jp[1][x]; }
+            rec[kRecR] = o.r[0]; rec[kRecR + 1] = o.r[1];
             if (d.pdim) {
                 for (int x = 0; x < 3; ++x) {
                     g[x] += o.Jp[0][x] * o.r[0] + o.Jp[1][x] * o.r[1];
@@ -94,6 +98,15 @@ ba_point_pass_kernel(BaDev d, PointPassArgs a)
                 for (int x = 0; x < 3; ++x) {
                     a.ge[3 * j + x] = g[x];
                     for (int y = 0; y < 3; ++y) a.vinv[9 * j + 3 * x + y] = bad ? 0.0 : Vi[x][y];
+                }
+                // Q = Jp V^-1 for every observation of the track
+                for (int k = k0; k < k1; ++k) {
+                    double *rec = a.obsrec + (size_t)k * kObsRec;
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const double j0 = rec[kRecJp + 3 * rr], j1 = rec[kRecJp + 3 * rr + 1], j2 = rec[kRecJp + 3 * rr + 2];
+                        for (int t = 0; t < 3; ++t)
+                            rec[kRecQ + 3 * rr + t] = bad ? 0.0 : j0 * Vi[0][t] + j1 * Vi[1][t] + j2 * Vi[2][t];
+                    }
                 }
                 if (a.want_gradient) {
                     // |Plus(x, -g) - x|_inf with the UNSCALED gradient g / scale
@@ -142,43 +155,43 @@ ba_pair_pass_kernel(BaDev d, PairPassArgs a)
     }
     for (int e = e0 + lane; e < e1; e += 64) {
         const int ka = a.entry_a[e], kb = a.entry_b[e];
-        ObsLin oa;
-        linearize_obs(d, ka, d.cams, d.points, true, oa);
+        const double *ra = a.obsrec + (size_t)ka * kObsRec;
+        double Ja[2][6];
+#pragma unroll
+        for (int x = 0; x < 6; ++x) { Ja[0][x] = ra[kRecJc + x]; Ja[1][x] = ra[kRecJc + 6 + x]; }
         if (ka == kb) {
+            double rr0 = ra[kRecR], rr1 = ra[kRecR + 1];
+            if (d.pdim && a.mode != kPassScaleInit) {
+                // rhs = Jc^T (r - Q g):  Z g = Jc^T (Q g)
+                const double *g = a.ge + 3 * d.obs_pt[ka];
+                rr0 -= ra[kRecQ] * g[0] + ra[kRecQ + 1] * g[1] + ra[kRecQ + 2] * g[2];
+                rr1 -= ra[kRecQ + 3] * g[0] + ra[kRecQ + 4] * g[1] + ra[kRecQ + 5] * g[2];
+            }
 #pragma unroll
             for (int x = 0; x < 6; ++x) {
-                rhs[x] += oa.Jc[0][x] * oa.r[0] + oa.Jc[1][x] * oa.r[1];
-                U[x] += oa.Jc[0][x] * oa.Jc[0][x] + oa.Jc[1][x] * oa.Jc[1][x];
+                rhs[x] += Ja[0][x] * rr0 + Ja[1][x] * rr1;
+                U[x] += Ja[0][x] * Ja[0][x] + Ja[1][x] * Ja[1][x];
 #pragma unroll
-                for (int y = 0; y < 6; ++y) acc[x][y] += oa.Jc[0][x] * oa.Jc[0][y] + oa.Jc[1][x] * oa.Jc[1][y];
+                for (int y = 0; y < 6; ++y) acc[x][y] += Ja[0][x] * Ja[0][y] + Ja[1][x] * Ja[1][y];
             }
         }
         if (d.pdim && a.mode != kPassScaleInit) {
-            const int j = d.obs_pt[ka];
-            const double *Vi = a.vinv + 9 * j;
-            double Z[6][3];
+            // Z_a W_b^T = Jc_a^T (Q_a Jp_b^T) Jc_b
+            const double *rb = a.obsrec + (size_t)kb * kObsRec;
+            double M[2][2];
 #pragma unroll
-            for (int x = 0; x < 6; ++x) {
-                double W[3];
+            for (int r1 = 0; r1 < 2; ++r1)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) W[t] = oa.Jc[0][x] * oa.Jp[0][t] + oa.Jc[1][x] * oa.Jp[1][t];
-#pragma unroll
-                for (int t = 0; t < 3; ++t) Z[x][t] = W[0] * Vi[t] + W[1] * Vi[3 + t] + W[2] * Vi[6 + t];
-            }
-            if (ka == kb) {
-                const double *g = a.ge + 3 * j;
-#pragma unroll
-                for (int x = 0; x < 6; ++x) rhs[x] -= Z[x][0] * g[0] + Z[x][1] * g[1] + Z[x][2] * g[2];
-            }
-            ObsLin ob;
-            if (ka == kb) ob = oa; else linearize_obs(d, kb, d.cams, d.points, true, ob);
+                for (int r2 = 0; r2 < 2; ++r2)
+                    M[r1][r2] = ra[kRecQ + 3 * r1] * rb[kRecJp + 3 * r2] + ra[kRecQ + 3 * r1 + 1] * rb[kRecJp + 3 * r2 + 1] +
+                                ra[kRecQ + 3 * r1 + 2] * rb[kRecJp + 3 * r2 + 2];
 #pragma unroll
             for (int y = 0; y < 6; ++y) {
-                double W2[3];
+                const double jb0 = rb[kRecJc + y], jb1 = rb[kRecJc + 6 + y];
+                const double t0 = M[0][0] * jb0 + M[0][1] * jb1;
+                const double t1 = M[1][0] * jb0 + M[1][1] * jb1;
 #pragma unroll
-                for (int t = 0; t < 3; ++t) W2[t] = ob.Jc[0][y] * ob.Jp[0][t] + ob.Jc[1][y] * ob.Jp[1][t];
-#pragma unroll
-                for (int x = 0; x < 6; ++x) acc[x][y] -= Z[x][0] * W2[0] + Z[x][1] * W2[1] + Z[x][2] * W2[2];
+                for (int x = 0; x < 6; ++x) acc[x][y] -= Ja[0][x] * t0 + Ja[1][x] * t1;
             }
         }
     }
@@ -231,10 +244,9 @@ ba_cam_gradient_kernel(BaDev d, PairPassArgs a, double *gmax_out)
     for (int e = e0 + lane; e < e1; e += 64) {
         const int ka = a.entry_a[e];
         if (ka != a.entry_b[e]) continue;
-        ObsLin oa;
-        linearize_obs(d, ka, d.cams, d.points, true, oa);
+        const double *ra = a.obsrec + (size_t)ka * kObsRec;
 #pragma unroll
-        for (int x = 0; x < 6; ++x) g[x] += oa.Jc[0][x] * oa.r[0] + oa.Jc[1][x] * oa.r[1];
+        for (int x = 0; x < 6; ++x) g[x] += ra[kRecJc + x] * ra[kRecR] + ra[kRecJc + 6 + x] * ra[kRecR + 1];
     }
 #pragma unroll
     for (int x = 0; x < 6; ++x) g[x] = wave_sum(g[x]);
@@ -321,25 +333,25 @@ ba_back_pass_kernel(BaDev d, BackPassArgs a)
         if (d.pdim) {
             double t3[3] = { a.ge[3 * j], a.ge[3 * j + 1], a.ge[3 * j + 2] };
             for (int k = k0; k < k1; ++k) {
-                ObsLin o;
-                linearize_obs(d, k, d.cams, d.points, true, o);
+                const double *rec = a.obsrec + (size_t)k * kObsRec;
+                const int c = d.obs_cam[k], n = d.cam_ldim[c], off = d.cam_off[c];
                 double u0 = 0.0, u1 = 0.0;
                 for (int x = 0; x < 6; ++x)
-                    if (x < o.n) { u0 += o.Jc[0][x] * a.y_c[o.off + x]; u1 += o.Jc[1][x] * a.y_c[o.off + x]; }
-                for (int t = 0; t < 3; ++t) t3[t] -= o.Jp[0][t] * u0 + o.Jp[1][t] * u1;
+                    if (x < n) { u0 += rec[kRecJc + x] * a.y_c[off + x]; u1 += rec[kRecJc + 6 + x] * a.y_c[off + x]; }
+                for (int t = 0; t < 3; ++t) t3[t] -= rec[kRecJp + t] * u0 + rec[kRecJp + 3 + t] * u1;
             }
             const double *Vi = a.vinv + 9 * j;
             for (int x = 0; x < 3; ++x) step_p[x] = -(Vi[3 * x] * t3[0] + Vi[3 * x + 1] * t3[1] + Vi[3 * x + 2] * t3[2]);
         }
         // model_cost_change = -(J step)^T (r + J step / 2)  (scaled J, scaled step)
         for (int k = k0; k < k1; ++k) {
-            ObsLin o;
-            linearize_obs(d, k, d.cams, d.points, true, o);
+            const double *rec = a.obsrec + (size_t)k * kObsRec;
+            const int c = d.obs_cam[k], n = d.cam_ldim[c], off = d.cam_off[c];
             double m0 = 0.0, m1 = 0.0;
             for (int x = 0; x < 6; ++x)
-                if (x < o.n) { m0 -= o.Jc[0][x] * a.y_c[o.off + x]; m1 -= o.Jc[1][x] * a.y_c[o.off + x]; }
-            for (int t = 0; t < 3; ++t) { m0 += o.Jp[0][t] * step_p[t]; m1 += o.Jp[1][t] * step_p[t]; }
-            mcc -= m0 * (o.r[0] + m0 / 2.0) + m1 * (o.r[1] + m1 / 2.0);
+                if (x < n) { m0 -= rec[kRecJc + x] * a.y_c[off + x]; m1 -= rec[kRecJc + 6 + x] * a.y_c[off + x]; }
+            for (int t = 0; t < 3; ++t) { m0 += rec[kRecJp + t] * step_p[t]; m1 += rec[kRecJp + 3 + t] * step_p[t]; }
+            mcc -= m0 * (rec[kRecR] + m0 / 2.0) + m1 * (rec[kRecR + 1] + m1 / 2.0);
         }
         const double *P = d.points + 4 * j;
         double out[4] = { P[0], P[1], P[2], P[3] };
@@ -440,6 +452,19 @@ ba_max_reduce_kernel(const double *v, int n, double *out)
         __syncthreads();
     }
     if (threadIdx.x == 0) *out = sh[0];
+}
+
+// identity on the padding diagonal of the (zeroed) reduced system
+__global__ void
+ba_pad_diag_kernel(double *S, int ld, int n, int N)
+{
+    const int i = n + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) S[(size_t)i * ld + i] = 1.0;
+}
+
+void launch_pad_diag(double *S, int ld, int n, int N, hipStream_t s)
+{
+    if (N > n) hipLaunchKernelGGL(ba_pad_diag_kernel, dim3(1), dim3(64), 0, s, S, ld, n, N);
 }
 
 void launch_max_reduce(const double *v, int n, double *out, hipStream_t s)
