@@ -74,6 +74,22 @@ def cpu_baseline(iset, pairs, n_sample):
                       f"two-way + cross-check) of the same image set, {dt:.1f} s"}
 
 
+def ba_cpu_baseline(iterations=2):
+    """The BA oracle (double-precision restatement of the reference's Ceres
+    solve, parity unpinned) on the same config-4 scene, bounded to a few LM
+    iterations."""
+    import oracle_lib
+    from orthosfm_amd import synth
+    sc = synth.make_ba_scene(synth.MODEL_QUATERNION, 200, 100000, config_id=4)
+    t0 = time.perf_counter()
+    s = oracle_lib.oracle_ba_solve(sc, max_num_iterations=iterations)
+    dt = time.perf_counter() - t0
+    return {"value": s.num_iterations / dt, "unit": "LM iterations/s",
+            "cores": int(oracle_lib.oracle().oracle_num_threads()), "kind": "port",
+            "sample": f"{s.num_iterations} LM iterations of the same 200-camera / 100k-track problem, {dt:.1f} s "
+                      "(residual/Jacobian evaluation OpenMP-parallel, Schur + dense Cholesky serial)"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -163,6 +179,9 @@ def main():
             ba = ba_mod.bench_global_ba()
         except Exception as e:       # BA reporting must never hide the matching line
             ba = {"error": str(e)}
+
+    if ba is not None and "error" not in ba and not args.no_cpu_baseline and rank == 0:
+        ba["cpu_baseline"] = ba_cpu_baseline()
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3

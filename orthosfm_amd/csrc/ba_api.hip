@@ -103,59 +103,6 @@ void build_layout(const osfm_ba_problem *p, Layout *L)
     for (int j = 0; j < M; ++j) L->pt_start[j + 1] += L->pt_start[j];
 }
 
-struct PairLists {
-    std::vector<int32_t> c1, c2, start, ea, eb;
-};
-
-// Observation pairs (a, b) of one track grouped by camera pair (cam(a) >=
-// cam(b)); the diagonal pair (c, c) holds (a, a) for every observation of c.
-void build_pair_lists(const osfm_ba_problem *p, const Layout &L, bool with_points, PairLists *out)
-{
-    const int C = p->num_cameras, M = p->num_points;
-    std::vector<int32_t> count((size_t)C * C, 0);
-    auto active = [&](int c) { return L.cam_ldim[c] > 0; };
-    for (int j = 0; j < M; ++j) {
-        const int k0 = L.pt_start[j], k1 = L.pt_start[j + 1];
-        for (int a = k0; a < k1; ++a) {
-            const int ca = p->obs_camera[a];
-            if (!active(ca)) continue;
-            for (int b = with_points ? k0 : a; b < (with_points ? k1 : a + 1); ++b) {
-                const int cb = p->obs_camera[b];
-                if (!active(cb) || ca < cb) continue;
-                count[(size_t)ca * C + cb]++;
-            }
-        }
-    }
-    std::vector<int32_t> slot((size_t)C * C, -1);
-    out->c1.clear(); out->c2.clear(); out->start.clear();
-    int total = 0;
-    for (int a = 0; a < C; ++a)
-        for (int b = 0; b <= a; ++b) {
-            const int n = count[(size_t)a * C + b];
-            if (!n) continue;
-            slot[(size_t)a * C + b] = (int)out->c1.size();
-            out->c1.push_back(a); out->c2.push_back(b); out->start.push_back(total);
-            total += n;
-        }
-    out->start.push_back(total);
-    out->ea.assign(total, 0); out->eb.assign(total, 0);
-    std::vector<int32_t> fill(out->c1.size(), 0);
-    for (int j = 0; j < M; ++j) {
-        const int k0 = L.pt_start[j], k1 = L.pt_start[j + 1];
-        for (int a = k0; a < k1; ++a) {
-            const int ca = p->obs_camera[a];
-            if (!active(ca)) continue;
-            for (int b = with_points ? k0 : a; b < (with_points ? k1 : a + 1); ++b) {
-                const int cb = p->obs_camera[b];
-                if (!active(cb) || ca < cb) continue;
-                const int sidx = slot[(size_t)ca * C + cb];
-                const int pos = out->start[sidx] + fill[sidx]++;
-                out->ea[pos] = a; out->eb[pos] = b;
-            }
-        }
-    }
-}
-
 struct DeviceProblem {
     DevArray cams[2], points[2], obs_xy, obs_cam, obs_pt, pt_start, img_w, img_h;
     DevArray cam_ldim, cam_off, colmap, scale_c, scale_p;
@@ -258,10 +205,12 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     build_layout(p, &L);
     const int pdim = o.optimize_points ? 3 : 0;
     const int nc = L.nc;
-    PairLists PL;
-    build_pair_lists(p, L, pdim != 0, &PL);
-    const int num_pairs = (int)PL.c1.size();
-    sum->num_pair_entries = (int)PL.ea.size();
+    auto lap = [&](const char *what) {
+        if (o.verbose >= 2)
+            fprintf(stderr, "[osfm ba] %-18s %8.3f ms\n", what,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
+    lap("layout");
 
     StreamGuard sg;
     OSFM_HIP_CHECK(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
@@ -272,14 +221,21 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     DeviceProblem D;
     OSFM_RETURN_IF(upload_problem(p, L, o.huber_delta, pdim, s, &D));
     BaDev &d = D.dev;
+    lap("upload problem");
 
-    DevArray pair_c1, pair_c2, pair_start, entry_a, entry_b;
-    OSFM_RETURN_IF(upload(pair_c1, PL.c1.data(), PL.c1.size(), s));
-    OSFM_RETURN_IF(upload(pair_c2, PL.c2.data(), PL.c2.size(), s));
-    OSFM_RETURN_IF(upload(pair_start, PL.start.data(), PL.start.size(), s));
-    OSFM_RETURN_IF(upload(entry_a, PL.ea.data(), PL.ea.size(), s));
-    OSFM_RETURN_IF(upload(entry_b, PL.eb.data(), PL.eb.size(), s));
-    OSFM_HIP_CHECK(hipStreamSynchronize(s));
+    // camera-pair lists of the Schur complement, built on the device
+    PairListsDev PL;
+    {
+        int64_t bound = 0;
+        for (int j = 0; j < M; ++j) {
+            const int64_t l = L.pt_start[j + 1] - L.pt_start[j];
+            bound += pdim ? l * l : l;
+        }
+        OSFM_RETURN_IF(pair_lists_build(d, pdim != 0, std::max<int64_t>(bound, 1), &PL, s));
+    }
+    const int num_pairs = PL.num_pairs;
+    sum->num_pair_entries = PL.num_entries;
+    lap("pair lists (device)");
 
     const int blocksM = std::max(1, (M + 255) / 256);
     const int N = cholesky_padded_dim(std::max(nc, 1));
@@ -312,8 +268,8 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     memset(&qa, 0, sizeof(qa));
     qa.min_diag = o.min_lm_diagonal; qa.max_diag = o.max_lm_diagonal;
     qa.num_pairs = num_pairs;
-    qa.pair_c1 = pair_c1.as<int32_t>(); qa.pair_c2 = pair_c2.as<int32_t>(); qa.pair_start = pair_start.as<int32_t>();
-    qa.entry_a = entry_a.as<int32_t>(); qa.entry_b = entry_b.as<int32_t>();
+    qa.pair_key = PL.unique.as<uint32_t>(); qa.pair_start = PL.starts.as<int32_t>();
+    qa.entries = PL.entries.as<uint64_t>();
     qa.vinv = vinv.as<double>(); qa.ge = ge.as<double>(); qa.obsrec = obsrec.as<double>();
     qa.diag_c = diag_c.as<double>(); qa.scale_c_out = D.scale_c.as<double>();
     qa.S = S.as<double>(); qa.ldS = N; qa.rhs = S.as<double>() + (size_t)N * N;
@@ -369,7 +325,9 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
         launch_pair_pass(d, qa, s);
         OSFM_HIP_CHECK(hipGetLastError());
     }
+    lap("alloc + lists up");
     OSFM_RETURN_IF(linearize(true));
+    lap("first linearize");
     double x_cost = h_scal[0];
     double grad_max = std::max(h_scal[1], h_scal[3]);
     sum->initial_cost = x_cost;
@@ -466,6 +424,7 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
             fprintf(stderr, "[osfm ba] it %d cost %.9e radius %.3e\n", iteration, x_cost, radius);
     }
 
+    lap("LM loop");
     // ---- write back the current iterate --------------------------------------
     std::vector<double> pts0((size_t)4 * M);
     if (M) memcpy(pts0.data(), p->points, (size_t)4 * M * 8);

@@ -1,6 +1,7 @@
 // Launchers and argument blocks of the bundle-adjustment kernels.
 #pragma once
 #include "ba_device.h"
+#include "osfm_common.h"
 
 namespace osfm {
 
@@ -30,8 +31,9 @@ struct PairPassArgs {
     int mode, update_diag, want_gradient;
     double radius, min_diag, max_diag;
     int num_pairs;
-    const int32_t *pair_c1, *pair_c2, *pair_start;   // [num_pairs], [num_pairs + 1]
-    const int32_t *entry_a, *entry_b;                // observation indices
+    const uint32_t *pair_key;        // [num_pairs] c1 * C + c2, c1 >= c2
+    const int32_t *pair_start;       // [num_pairs + 1]
+    const uint64_t *entries;         // (obs a << 32) | obs b, grouped by pair, track order inside
     const double *vinv, *ge;
     const double *obsrec;     // [O][kObsRec]
     double *diag_c;           // [nc]
@@ -62,6 +64,19 @@ void launch_max_reduce(const double *v, int n, double *out, hipStream_t s);
 void launch_pad_diag(double *S, int ld, int n, int N, hipStream_t s);
 void launch_reproj(const BaDev &d, double *err, double *residuals, hipStream_t s);
 void launch_triangulate(const BaDev &d, double *points_out, uint8_t *valid, hipStream_t s);
+
+// camera-pair lists built on the device (ba_pairs.hip)
+struct PairListsDev {
+    DeviceBuffer counts, offsets, keys_in, keys, vals_in, entries, unique, runs, starts, scalars, temp;
+    int num_pairs = 0;
+    int num_entries = 0;
+    ~PairListsDev()
+    {
+        DeviceBuffer *b[] = {&counts, &offsets, &keys_in, &keys, &vals_in, &entries, &unique, &runs, &starts, &scalars, &temp};
+        for (auto *x : b) x->release();
+    }
+};
+int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, PairListsDev *out, hipStream_t s);
 
 // dense Cholesky solve of the reduced camera system (ba_cholesky.hip)
 int cholesky_padded_dim(int n);

@@ -137,7 +137,7 @@ ba_pair_pass_kernel(BaDev d, PairPassArgs a)
     const int lane = threadIdx.x & 63;
     const int pi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (pi >= a.num_pairs) return;
-    const int c1 = a.pair_c1[pi], c2 = a.pair_c2[pi];
+    const int c1 = (int)(a.pair_key[pi] / (uint32_t)d.C), c2 = (int)(a.pair_key[pi] % (uint32_t)d.C);
     const int e0 = a.pair_start[pi], e1 = a.pair_start[pi + 1];
     const int n1 = d.cam_ldim[c1], n2 = d.cam_ldim[c2];
     const int o1 = d.cam_off[c1], o2 = d.cam_off[c2];
@@ -154,7 +154,8 @@ ba_pair_pass_kernel(BaDev d, PairPassArgs a)
         for (int y = 0; y < 6; ++y) acc[x][y] = 0.0;
     }
     for (int e = e0 + lane; e < e1; e += 64) {
-        const int ka = a.entry_a[e], kb = a.entry_b[e];
+        const uint64_t ent = a.entries[e];
+        const int ka = (int)(ent >> 32), kb = (int)(ent & 0xffffffffu);
         const double *ra = a.obsrec + (size_t)ka * kObsRec;
         double Ja[2][6];
 #pragma unroll
@@ -236,14 +237,15 @@ ba_cam_gradient_kernel(BaDev d, PairPassArgs a, double *gmax_out)
     const int lane = threadIdx.x & 63;
     const int pi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (pi >= a.num_pairs) return;
-    const int c1 = a.pair_c1[pi], c2 = a.pair_c2[pi];
+    const int c1 = (int)(a.pair_key[pi] / (uint32_t)d.C), c2 = (int)(a.pair_key[pi] % (uint32_t)d.C);
     if (c1 != c2) return;
     const int e0 = a.pair_start[pi], e1 = a.pair_start[pi + 1];
     const int n1 = d.cam_ldim[c1], o1 = d.cam_off[c1];
     double g[6] = { 0, 0, 0, 0, 0, 0 };
     for (int e = e0 + lane; e < e1; e += 64) {
-        const int ka = a.entry_a[e];
-        if (ka != a.entry_b[e]) continue;
+        const uint64_t ent = a.entries[e];
+        const int ka = (int)(ent >> 32);
+        if (ka != (int)(ent & 0xffffffffu)) continue;
         const double *ra = a.obsrec + (size_t)ka * kObsRec;
 #pragma unroll
         for (int x = 0; x < 6; ++x) g[x] += ra[kRecJc + x] * ra[kRecR] + ra[kRecJc + 6 + x] * ra[kRecR + 1];

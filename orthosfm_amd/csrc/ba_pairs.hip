@@ -1,0 +1,120 @@
+// Camera-pair lists of the Schur complement, built on the device.
+//
+// For every track, every ordered pair of its observations (a, b) with
+// cam(a) >= cam(b) (both cameras having free parameters) contributes a block to
+// S[cam(a)][cam(b)].  The pair pass wants these grouped by camera pair, in a
+// reproducible order: keys cam(a) * C + cam(b) are generated track by track at
+// offsets given by a prefix sum, then sorted with a STABLE radix sort, so the
+// order inside one camera pair is the track order on every run.
+// (Host-side construction of the same lists cost ~14 ms for 3.6 M entries;
+// here it is a few launches.)
+#include <hipcub/hipcub.hpp>
+
+#include "ba_kernels.h"
+#include "osfm_common.h"
+
+namespace osfm {
+
+__global__ void
+pair_count_kernel(BaDev d, int with_points, int32_t *counts)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= d.M) return;
+    const int k0 = d.pt_start[j], k1 = d.pt_start[j + 1];
+    int n = 0;
+    for (int a = k0; a < k1; ++a) {
+        const int ca = d.obs_cam[a];
+        if (d.cam_ldim[ca] == 0) continue;
+        if (!with_points) { n++; continue; }
+        for (int b = k0; b < k1; ++b) {
+            const int cb = d.obs_cam[b];
+            if (d.cam_ldim[cb] == 0 || ca < cb) continue;
+            n++;
+        }
+    }
+    counts[j] = n;
+}
+
+__global__ void
+pair_fill_kernel(BaDev d, int with_points, const int32_t *offsets, uint32_t *keys, uint64_t *vals)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= d.M) return;
+    const int k0 = d.pt_start[j], k1 = d.pt_start[j + 1];
+    int pos = offsets[j];
+    for (int a = k0; a < k1; ++a) {
+        const int ca = d.obs_cam[a];
+        if (d.cam_ldim[ca] == 0) continue;
+        for (int b = with_points ? k0 : a; b < (with_points ? k1 : a + 1); ++b) {
+            const int cb = d.obs_cam[b];
+            if (d.cam_ldim[cb] == 0 || ca < cb) continue;
+            keys[pos] = (uint32_t)ca * (uint32_t)d.C + (uint32_t)cb;
+            vals[pos] = ((uint64_t)(uint32_t)a << 32) | (uint32_t)b;
+            pos++;
+        }
+    }
+}
+
+int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, PairListsDev *out, hipStream_t s)
+{
+    const int M = d.M;
+    out->num_pairs = 0; out->num_entries = 0;
+    if (M == 0) return OSFM_OK;
+    OSFM_RETURN_IF(out->counts.reserve((size_t)(M + 1) * 4));
+    OSFM_RETURN_IF(out->offsets.reserve((size_t)(M + 1) * 4));
+    OSFM_RETURN_IF(out->keys_in.reserve((size_t)max_entries * 4));
+    OSFM_RETURN_IF(out->keys.reserve((size_t)max_entries * 4));
+    OSFM_RETURN_IF(out->vals_in.reserve((size_t)max_entries * 8));
+    OSFM_RETURN_IF(out->entries.reserve((size_t)max_entries * 8));
+    OSFM_RETURN_IF(out->unique.reserve((size_t)max_entries * 4 + 16));
+    OSFM_RETURN_IF(out->runs.reserve((size_t)max_entries * 4 + 16));
+    OSFM_RETURN_IF(out->starts.reserve((size_t)max_entries * 4 + 16));
+    OSFM_RETURN_IF(out->scalars.reserve(64));
+
+    const int blocks = (M + 255) / 256;
+    hipLaunchKernelGGL(pair_count_kernel, dim3(blocks), dim3(256), 0, s, d, with_points ? 1 : 0,
+        out->counts.as<int32_t>());
+    size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    int32_t *counts = out->counts.as<int32_t>(), *offsets = out->offsets.as<int32_t>();
+    uint32_t *kin = out->keys_in.as<uint32_t>(), *kout = out->keys.as<uint32_t>();
+    uint64_t *vin = out->vals_in.as<uint64_t>(), *vout = out->entries.as<uint64_t>();
+    int bits = 1;
+    while ((1ull << bits) < (unsigned long long)d.C * (unsigned long long)d.C) ++bits;
+    OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, t1, counts, offsets, M, s));
+    OSFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, t2, kin, kout, vin, vout, (int)max_entries, 0, bits, s));
+    OSFM_HIP_CHECK(hipcub::DeviceRunLengthEncode::Encode(nullptr, t3, kout, out->unique.as<uint32_t>(),
+        out->runs.as<int32_t>(), out->scalars.as<int32_t>(), (int)max_entries, s));
+    OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, t4, out->runs.as<int32_t>(), out->starts.as<int32_t>(),
+        (int)max_entries, s));
+    OSFM_RETURN_IF(out->temp.reserve(std::max(std::max(t1, t2), std::max(t3, t4)) + 256));
+
+    size_t tb = out->temp.bytes;
+    OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(out->temp.ptr, tb, counts, offsets, M, s));
+    // total = offsets[M-1] + counts[M-1]
+    int32_t h_last[2] = { 0, 0 };
+    OSFM_HIP_CHECK(hipMemcpyAsync(&h_last[0], offsets + (M - 1), 4, hipMemcpyDeviceToHost, s));
+    OSFM_HIP_CHECK(hipMemcpyAsync(&h_last[1], counts + (M - 1), 4, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(pair_fill_kernel, dim3(blocks), dim3(256), 0, s, d, with_points ? 1 : 0, offsets, kin, vin);
+    OSFM_HIP_CHECK(hipStreamSynchronize(s));
+    const int E = h_last[0] + h_last[1];
+    if (E > max_entries) { set_error("pair lists: %d entries exceed the bound %lld", E, (long long)max_entries); return OSFM_E_ARG; }
+    out->num_entries = E;
+    if (E == 0) return OSFM_OK;
+    tb = out->temp.bytes;
+    OSFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(out->temp.ptr, tb, kin, kout, vin, vout, E, 0, bits, s));
+    tb = out->temp.bytes;
+    OSFM_HIP_CHECK(hipcub::DeviceRunLengthEncode::Encode(out->temp.ptr, tb, kout, out->unique.as<uint32_t>(),
+        out->runs.as<int32_t>(), out->scalars.as<int32_t>(), E, s));
+    int32_t h_runs = 0;
+    OSFM_HIP_CHECK(hipMemcpyAsync(&h_runs, out->scalars.ptr, 4, hipMemcpyDeviceToHost, s));
+    OSFM_HIP_CHECK(hipStreamSynchronize(s));
+    out->num_pairs = h_runs;
+    tb = out->temp.bytes;
+    // starts[num_pairs] must hold the total: scan over num_pairs + 1 with a trailing zero run
+    OSFM_HIP_CHECK(hipMemsetAsync(out->runs.as<int32_t>() + h_runs, 0, 4, s));
+    OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(out->temp.ptr, tb, out->runs.as<int32_t>(),
+        out->starts.as<int32_t>(), h_runs + 1, s));
+    return OSFM_OK;
+}
+
+}  // namespace osfm
