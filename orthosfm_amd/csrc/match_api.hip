@@ -597,9 +597,18 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
     }
 
     // per-pair workspace estimate -> batch size
+    // pairs per launch group: bounded by the partial-result workspace
+    // (column partials dominate: nrb * n2 * 8 B per pair) -- 24 GB of the 288 GB
     auto batch_size_for = [&](bool lowres) {
         if (o.pairs_per_batch > 0) return o.pairs_per_batch;
-        return lowres ? 8192 : 256;
+        if (lowres) return 16384;
+        size_t worst = 1;
+        for (const auto &v : m->views) {
+            const size_t n = (size_t)std::max(v.ns, v.nu) + 256;
+            worst = std::max(worst, (n / kRowsPerBlock + 1) * n * sizeof(ColPart) + n * 64);
+        }
+        const size_t budget = (size_t)24 << 30;
+        return (int)std::max<size_t>(1, std::min<size_t>(budget / worst, 4096));
     };
 
     // ---- low-res gate -------------------------------------------------------

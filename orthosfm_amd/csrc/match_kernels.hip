@@ -20,6 +20,8 @@
 // per-descriptor corrections ra = 128*sum(a') + 2^20 (the two 2^20 make up
 // 128*128*128).  ra enters through the MFMA C operand, cb through the key
 // construction, so the correction costs no extra instruction per element.
+#include <algorithm>
+
 #include "match_kernels.h"
 
 namespace osfm {
@@ -94,12 +96,32 @@ __device__ __forceinline__ void top2_quad(int &b, int &s, int x0, int x1, int x2
     s = max3i(s, m01, m23);
 }
 
+// Epilogue (per 32x32 accumulator fragment, everything stays in registers).
+// The VALU, not the matrix pipe, bounds this kernel (a wave64 integer op
+// occupies its SIMD for 4 cycles, an int8 32x32x32 MFMA for 32), so the
+// running top-2 is organised to touch each score as little as possible:
+//   * scores are first reduced to GROUP bests with v_max3 (0.5 op / score):
+//     row direction  - a (lane, register) slot sees 2 columns per tile; a group
+//                      is kGroupTiles tiles = 16 columns of that slot;
+//     column direction - a lane sees 32 rows of a column per tile; a group is
+//                      the 8 rows of half an accumulator fragment;
+//   * only group bests enter the exact (best, second) update (v_med3 + v_max).
+// Hence best / index are exact, while "second" is the second largest GROUP
+// best: the true second largest can only be larger if it sits in the same
+// group as the best.  The finish kernel closes that gap exactly: a query that
+// passes the ratio test against this lower bound gets its best group (16
+// columns / 8 rows) re-scored and re-tested; one that fails it is rejected for
+// good (the test is monotone in the second-best value).
+//
 // MASKED = false: rows >= n1 / columns >= n2 are PADDING descriptors whose
 // stored bytes and corrections make their inner products come out at
 // -2^22 (prepare_*_kernel), so they lose every comparison without a single
 // masking instruction.  MASKED = true (low-res / num_features-limited
 // matching, where the rows behind the limit are real descriptors): explicit
 // per-element masks.
+constexpr int kGroupTiles = 8;          // tiles per row-direction group (16 columns per slot)
+constexpr int kValNone = -(1 << 28);    // "no candidate" for un-keyed column scores
+
 template <int CH, bool MASKED>
 __global__ __launch_bounds__(256, 2) void
 match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, int total_blocks,
@@ -113,9 +135,11 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
     constexpr int CPT = CHUNKS / 256;             // chunks per thread (2 or 1)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *bbuf = smem;                                              // [2][TILE_BYTES]
-    int *corrbuf = reinterpret_cast<int *>(smem + 2 * TILE_BYTES);  // [2][64]
-    ColPart *colbuf = reinterpret_cast<ColPart *>(smem + 2 * TILE_BYTES + 2 * 64 * 4);  // [2][4][64]
+    constexpr int BBUF_BYTES = 2 * TILE_BYTES > 16384 ? 2 * TILE_BYTES : 16384;
+    char *bbuf = smem;                                              // [2][TILE_BYTES] (>= 16 KB)
+    int *corrbuf = reinterpret_cast<int *>(smem + BBUF_BYTES);      // [2][64]
+    ColPart *colbuf = reinterpret_cast<ColPart *>(smem + BBUF_BYTES + 2 * 64 * 4);  // [2][4][64]
+    int *rsecbuf = reinterpret_cast<int *>(smem + BBUF_BYTES + 2 * 64 * 4 + 2 * 4 * 64 * 8);  // [32][256]
 
     const int lin = xcd_remap(blockIdx.x, total_blocks);
     // locate the problem: largest p with block_start <= lin
@@ -158,11 +182,16 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
         }
     }
 
-    v16i rbest[2], rsec[2];
+    // row direction state: best key and the running best of the current group
+    // in registers, the second-best group key in LDS (touched once per group)
+    v16i rbest[2], rcur[2];
 #pragma unroll
     for (int rf = 0; rf < 2; ++rf)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { rbest[rf][r] = kKeyNone; rsec[rf][r] = kKeyNone; }
+        for (int r = 0; r < 16; ++r) {
+            rbest[rf][r] = kKeyNone; rcur[rf][r] = kKeyNone;
+            rsecbuf[(rf * 16 + r) * 256 + tid] = kKeyNone;
+        }
 
     const int col_begin = seg * kSegCols;
     const int col_lim = min(n2, col_begin + kSegCols);
@@ -239,38 +268,54 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
                     k0 = col_valid[0] ? k0 : kKeyNone;
                     k1 = col_valid[1] ? k1 : kKeyNone;
                 }
-                int bb = rbest[rf][r], ss = rsec[rf][r];
-                top2_pair(bb, ss, k0, k1);
-                rbest[rf][r] = bb; rsec[rf][r] = ss;
+                rcur[rf][r] = max3i(rcur[rf][r], k0, k1);
             }
-            // column direction: 16 rows of this fragment per column group, in quads
+            // column direction: un-keyed scores, groups of 8 rows (half a fragment)
 #pragma unroll
             for (int cf = 0; cf < 2; ++cf) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int c[4];
+                for (int h = 0; h < 2; ++h) {
+                    int x[8];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int fr = rf * 16 + q * 4 + i;
-                        c[i] = (int)(((unsigned)acc[cf][q * 4 + i] << 5) | (unsigned)fr);
-                        if (MASKED) c[i] = ((row_valid_bits >> fr) & 1u) ? c[i] : kKeyNone;
+                    for (int i = 0; i < 8; ++i) {
+                        x[i] = acc[cf][h * 8 + i];
+                        if (MASKED) x[i] = ((row_valid_bits >> (rf * 16 + h * 8 + i)) & 1u) ? x[i] : kValNone;
                     }
-                    top2_quad(cb[cf], cs[cf], c[0], c[1], c[2], c[3]);
+                    int g = max(x[0], x[1]);
+                    g = max3i(g, x[2], x[3]);
+                    g = max3i(g, x[4], x[5]);
+                    g = max3i(g, x[6], x[7]);
+                    const int gk = (int)(((unsigned)g << 2) | (unsigned)(rf * 2 + h));
+                    cs[cf] = med3a(cb[cf], cs[cf], gk);
+                    cb[cf] = max(cb[cf], gk);
                 }
             }
         }
 
-        // column direction: lane-local keys -> (ip << 8 | row in block), merge
-        // the two half-waves (same column, other rows), hand to LDS.
+        // close a row-direction group: fold the group bests into (best, second)
+        if ((t % kGroupTiles) == kGroupTiles - 1 || t == ntiles - 1) {
+#pragma unroll
+            for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int *sp = rsecbuf + (rf * 16 + r) * 256 + tid;
+                    *sp = med3a(rbest[rf][r], *sp, rcur[rf][r]);
+                    rbest[rf][r] = max(rbest[rf][r], rcur[rf][r]);
+                    rcur[rf][r] = kKeyNone;
+                }
+        }
+
+        // column direction: lane-local keys -> (ip << 8 | group code), merge the
+        // two half-waves (same column, other rows), hand to LDS.
+        // group code = wave * 8 + half-wave * 4 + (fragment * 2 + register half)
         int kb[2], ksd[2];
 #pragma unroll
         for (int cf = 0; cf < 2; ++cf) {
-            const int fr = cb[cf] & 31;
-            const int rowl = wave * 64 + (fr >> 4) * 32 + (fr & 3) + 8 * ((fr >> 2) & 3) + 4 * lh;
-            int k1 = (int)((unsigned)((cb[cf] >> 5) + cbj[cf]) << 8) | rowl;
-            int k2 = (int)((unsigned)((cs[cf] >> 5) + cbj[cf]) << 8);
-            k1 = cb[cf] == kKeyNone ? kKeyNone : k1;
-            k2 = cs[cf] == kKeyNone ? kKeyNone : k2;
+            const int code = wave * 8 + lh * 4 + (cb[cf] & 3);
+            int k1 = (int)((unsigned)((cb[cf] >> 2) + cbj[cf]) << 8) | code;
+            int k2 = (int)((unsigned)((cs[cf] >> 2) + cbj[cf]) << 8);
+            k1 = cb[cf] < -(1 << 29) ? kKeyNone : k1;      // no valid row in this lane
+            k2 = cs[cf] < -(1 << 29) ? kKeyNone : k2;
             const int o1 = __shfl_xor(k1, 32);
             const int o2 = __shfl_xor(k2, 32);
             kb[cf] = max(k1, o1);
@@ -291,7 +336,6 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const ColPart cp = colbuf[(buf * 4 + w) * 64 + lane];
-                // rows of wave w are above those of wave w-1: >= keeps the later row on ties
                 k2 = max(min(k1, cp.key_best), max(k2, cp.key_second));
                 k1 = max(k1, cp.key_best);
             }
@@ -305,36 +349,36 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
         }
     }
 
-    // --- row direction: reduce the 32 lanes of each half-wave --------------
+    // --- row direction: merge the 32 lanes that hold the same row -------------
+    // Through LDS (the tile buffers are free now): each of 32 threads per wave
+    // walks the 32 source lanes of one row.  (ip, column) composites keep
+    // "later column wins" across lanes.
     RowPart *rp = rowparts + pd.rowpart_off + (int64_t)seg * ((int64_t)pd.nrb * kRowsPerBlock);
+    int *bb = reinterpret_cast<int *>(bbuf);                        // [16][256]
 #pragma unroll
     for (int rf = 0; rf < 2; ++rf) {
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kbest = rbest[rf][r], ksec = rsec[rf][r];
-            // 64-bit composite: (ip, global column)
-            long long b1 = kbest == kKeyNone
-                ? (long long)LLONG_MIN
-                : ((long long)(kbest >> 8) << 32) | (unsigned)(col_begin + (kbest & 255) * 32 + lr);
-            int s1 = ksec == kKeyNone ? INT_MIN : (ksec >> 8);
-#pragma unroll
-            for (int m = 1; m < 32; m <<= 1) {
-                const long long ob = __shfl_xor(b1, m);
-                const int os = __shfl_xor(s1, m);
-                const long long lo2 = b1 < ob ? b1 : ob;
-                const int lo_ip = lo2 == (long long)LLONG_MIN ? INT_MIN : (int)(lo2 >> 32);
-                s1 = max(max(s1, os), lo_ip);
-                b1 = b1 > ob ? b1 : ob;
+        for (int r = 0; r < 16; ++r) bb[r * 256 + tid] = rbest[rf][r];
+        __syncthreads();
+        if (lane < 32) {
+            const int r = lane & 15, h = lane >> 4;
+            int bip = INT_MIN, bcol = 0, sec = INT_MIN;
+            for (int i = 0; i < 32; ++i) {
+                const int l = (i + r) & 31;                          // skewed: bank-conflict free
+                const int src = wave * 64 + h * 32 + l;
+                const int kbest = bb[r * 256 + src];
+                const int ksec = rsecbuf[(rf * 16 + r) * 256 + src];
+                if (ksec != kKeyNone) sec = max(sec, ksec >> 8);
+                if (kbest == kKeyNone) continue;
+                const int ip = kbest >> 8, col = col_begin + (kbest & 255) * 32 + l;
+                if (ip > bip || (ip == bip && col > bcol)) { sec = max(sec, bip); bip = ip; bcol = col; }
+                else sec = max(sec, ip);
             }
-            if (lr == r) {
-                const int row = row0 + rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                RowPart out;
-                out.ip_best = b1 == (long long)LLONG_MIN ? INT_MIN : (int)(b1 >> 32);
-                out.idx_best = b1 == (long long)LLONG_MIN ? 0 : (int)(b1 & 0xffffffffLL);
-                out.ip_second = s1;
-                out.pad = 0;
-                rp[row] = out;
-            }
+            const int row = row0 + rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            RowPart out;
+            out.ip_best = bip; out.idx_best = bcol; out.ip_second = sec; out.pad = 0;
+            rp[row] = out;
         }
     }
 }
@@ -344,7 +388,7 @@ void launch_match_tiles(int ch, bool masked, const MatchProblem *d_problems, int
 {
     if (total_blocks <= 0) return;
     const int d = ch * 16;
-    const size_t lds = 2 * (size_t)kTileCols * d + 2 * 64 * 4 + 2 * 4 * 64 * sizeof(ColPart);
+    const size_t lds = std::max<size_t>(2 * (size_t)kTileCols * d, 16384) + 2 * 64 * 4 + 2 * 4 * 64 * sizeof(ColPart) + 32 * 256 * 4;
     const dim3 grid(total_blocks), block(256);
     if (ch == 8 && !masked)
         hipLaunchKernelGGL((match_tile_kernel<8, false>), grid, block, lds, s, d_problems, num_problems, total_blocks, rowparts, colparts);
@@ -384,6 +428,77 @@ accept_match(int ip1, int ip2, int idx1, const LoweTable &tab)
     return idx;
 }
 
+// exact inner product of two stored descriptors (SIFT bytes hold value - 128),
+// four byte products per v_dot4_i32_i8
+template <int DIM, bool SIGNED>
+__device__ __forceinline__ int exact_ip(const int8_t *q, const int8_t *c)
+{
+    const int4 *q4 = reinterpret_cast<const int4 *>(q);
+    const int4 *c4 = reinterpret_cast<const int4 *>(c);
+    int acc = 0, sq = 0, sc = 0;
+#pragma unroll
+    for (int i = 0; i < DIM / 16; ++i) {
+        const int4 a = q4[i], b = c4[i];
+        acc = __builtin_amdgcn_sdot4(a.x, b.x, acc, false);
+        acc = __builtin_amdgcn_sdot4(a.y, b.y, acc, false);
+        acc = __builtin_amdgcn_sdot4(a.z, b.z, acc, false);
+        acc = __builtin_amdgcn_sdot4(a.w, b.w, acc, false);
+        if (!SIGNED) {
+            sq = __builtin_amdgcn_sdot4(a.x, 0x01010101, sq, false);
+            sq = __builtin_amdgcn_sdot4(a.y, 0x01010101, sq, false);
+            sq = __builtin_amdgcn_sdot4(a.z, 0x01010101, sq, false);
+            sq = __builtin_amdgcn_sdot4(a.w, 0x01010101, sq, false);
+            sc = __builtin_amdgcn_sdot4(b.x, 0x01010101, sc, false);
+            sc = __builtin_amdgcn_sdot4(b.y, 0x01010101, sc, false);
+            sc = __builtin_amdgcn_sdot4(b.z, 0x01010101, sc, false);
+            sc = __builtin_amdgcn_sdot4(b.w, 0x01010101, sc, false);
+        }
+    }
+    // sum (x+128)(y+128) = sum xy + 128 (sum x + sum y) + 128*128*DIM
+    return SIGNED ? acc : acc + 128 * (sq + sc) + 128 * 128 * DIM;
+}
+
+// Re-scores the group that produced the best match and returns the exact
+// (best index, second-best value) of the query.
+//   dir 0: query = row q, group = 16 columns of one (lane, tile-group) stream
+//   dir 1: query = column q, group = 8 rows of one (wave, half-wave, fragment half)
+template <int DIM, bool SIGNED>
+__device__ void
+rescan_group(const MatchProblem &pd, int dir, int q, int ip1, int idx1, int code, int m_other,
+    int *idx_out, int *second_out)
+{
+    int best = INT_MIN, best_idx = 0, second = INT_MIN;
+    if (dir == 0) {
+        const int8_t *qrow = pd.A + (size_t)q * DIM;
+        const int seg = idx1 / kSegCols, off = idx1 - seg * kSegCols;
+        const int lr = off & 31, tile = (off >> 5) >> 1, g = tile / kGroupTiles;
+        for (int u = 0; u < kGroupTiles; ++u)
+            for (int cf = 0; cf < 2; ++cf) {
+                const int col = seg * kSegCols + (g * kGroupTiles + u) * kTileCols + cf * 32 + lr;
+                if (col >= pd.n2) continue;
+                const int v = exact_ip<DIM, SIGNED>(qrow, pd.B + (size_t)col * DIM);
+                if (v >= best) { second = best; best = v; best_idx = col; }   // later index wins ties
+                else if (v > second) second = v;
+            }
+    } else {
+        const int8_t *qrow = pd.B + (size_t)q * DIM;
+        const int rb = idx1;   // row block of the winning group
+        const int wave = code >> 3, lh = (code >> 2) & 1, gid = code & 3;
+        for (int i = 0; i < 8; ++i) {
+            const int r = (gid & 1) * 8 + i;
+            const int row = rb * kRowsPerBlock + wave * 64 + (gid >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row >= pd.n1) continue;
+            const int v = exact_ip<DIM, SIGNED>(qrow, pd.A + (size_t)row * DIM);
+            if (v >= best) { second = best; best = v; best_idx = row; }
+            else if (v > second) second = v;
+        }
+    }
+    (void)ip1;
+    *idx_out = best_idx;
+    *second_out = max(second, m_other);
+}
+
+template <int DIM, bool SIGNED>
 __global__ void
 match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__restrict__ rowparts,
     const ColPart *__restrict__ colparts, LoweTable tab, int force_exact,
@@ -398,7 +513,9 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
     int32_t *out = dir == 0 ? pd.m12 : pd.m21;
     if (nc == 0) { out[q] = -1; return; }
 
-    int ip1 = INT_MIN, ip2 = INT_MIN, idx1 = 0;
+    // ip1 / idx1: exact best; ip2: second largest GROUP best (lower bound of the
+    // true second); code: group of the best (dir 1), idx1 = its row block there
+    int ip1 = INT_MIN, ip2 = INT_MIN, idx1 = 0, code = 0;
     if (dir == 0) {
         const int64_t stride = (int64_t)pd.nrb * kRowsPerBlock;
         for (int sgi = 0; sgi < pd.nseg; ++sgi) {
@@ -413,11 +530,29 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
             const int pb = p.key_best == kKeyNone ? INT_MIN : (p.key_best >> 8);
             const int ps = p.key_second == kKeyNone ? INT_MIN : (p.key_second >> 8);
             ip2 = max(max(ip2, ps), min(ip1, pb));
-            if (pb >= ip1 && pb != INT_MIN) { ip1 = pb; idx1 = rb * kRowsPerBlock + (p.key_best & 255); }
+            if (pb >= ip1 && pb != INT_MIN) { ip1 = pb; idx1 = rb; code = p.key_best & 255; }
         }
     }
     const int limit = tab.is_signed ? 32767 : 65535;
-    if (force_exact || pd.force_exact || ip1 > limit) {
+    bool exact = force_exact || pd.force_exact || ip1 > limit;
+    int res = -1;
+    if (!exact) {
+        // optimistic test against the lower bound of the second best
+        res = accept_match(ip1, ip2, 0, tab);
+        if (res >= 0) {
+            if (ip1 < 0) {
+                res = 0;                      // reference state (0, 0, idx 0): nothing to refine
+            } else if (ip2 == ip1) {
+                exact = true;                 // accepted despite a tie for best (NaN accept /
+                                              // ratio >= 1): defer to the sequential-scan kernel
+            } else {
+                int idx, second;
+                rescan_group<DIM, SIGNED>(pd, dir, q, ip1, idx1, code, ip2, &idx, &second);
+                res = accept_match(ip1, second, idx, tab);
+            }
+        }
+    }
+    if (exact) {
         const int slot = atomicAdd(exact_count, 1);
         if (slot < exact_cap) {
             ExactItem it;
@@ -425,7 +560,7 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
             exact_items[slot] = it;
         }
     }
-    out[q] = accept_match(ip1, ip2, idx1, tab);
+    out[q] = res;
 }
 
 void launch_match_finish(const MatchProblem *d_problems, int num_problems, int max_n,
@@ -433,9 +568,13 @@ void launch_match_finish(const MatchProblem *d_problems, int num_problems, int m
     ExactItem *exact_items, int32_t *exact_count, int exact_cap, hipStream_t s)
 {
     if (num_problems <= 0 || max_n <= 0) return;
-    dim3 grid((max_n + 255) / 256, num_problems, 2);
-    hipLaunchKernelGGL(match_finish_kernel, grid, dim3(256), 0, s, d_problems, rowparts, colparts,
-        tab, force_exact, exact_items, exact_count, exact_cap);
+    dim3 grid((max_n + 127) / 128, num_problems, 2);
+    if (tab.is_signed)
+        hipLaunchKernelGGL((match_finish_kernel<64, true>), grid, dim3(128), 0, s, d_problems, rowparts,
+            colparts, tab, force_exact, exact_items, exact_count, exact_cap);
+    else
+        hipLaunchKernelGGL((match_finish_kernel<128, false>), grid, dim3(128), 0, s, d_problems, rowparts,
+            colparts, tab, force_exact, exact_items, exact_count, exact_cap);
 }
 
 // ---------------------------------------------------------------------------

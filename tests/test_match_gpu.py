@@ -105,7 +105,7 @@ def test_sift_vs_oracle_multi_block(hm, n1, n2, seed):
     c12, c21 = om.remove_inconsistent(e12, e21)
     r = m.pairwise_match(0, 1)
     assert np.array_equal(r.matches_1_2, c12) and np.array_equal(r.matches_2_1, c21)
-    assert m.stats().exact_scan_queries == 0
+    assert m.stats().exact_scan_queries <= (n1 + n2) // 100      # only ties for best go to the sequential-scan kernel
     m.close()
 
 
