@@ -34,6 +34,10 @@ struct ViewData {
     int ns = 0, nu = 0;
     int ns_pad = 0, nu_pad = 0;
     DeviceBuffer sift, sift_corr, surf, surf_corr;
+    // raw form of the SIFT rows (rows with a value > 127 blanked) and the
+    // gathered "special" rows that need the value-128 form on the row side
+    DeviceBuffer sift_raw, sift_raw_corr, special, special_corr, special_map, special_slot;
+    int n_special = 0;
     int surf_norm2_max = 0;
 };
 
@@ -185,9 +189,22 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
             pr.B = (type == 0 ? b.sift : b.surf).as<int8_t>();
             pr.corrA = (type == 0 ? a.sift_corr : a.surf_corr).as<int32_t>();
             pr.corrB = (type == 0 ? b.sift_corr : b.surf_corr).as<int32_t>();
+            // raw row operand: SURF bytes are the values already
+            pr.A_raw = (type == 0 ? a.sift_raw : a.surf).as<int8_t>();
+            pr.corrA_raw = (type == 0 ? a.sift_raw_corr : a.surf_corr).as<int32_t>();
+            // a num_features-limited batch runs the masked kernel, which keeps every
+            // row on the keyed (value-128) path
+            const bool limited = lowres_limit > 0;
+            const int n_special = (type == 0 && !limited) ? a.n_special : 0;
+            pr.n_special = n_special;
+            pr.A_special = a.special.as<int8_t>();
+            pr.corrA_special = a.special_corr.as<int32_t>();
+            pr.special_map = a.special_map.as<int32_t>();
+            pr.special_slot = n_special > 0 ? a.special_slot.as<int32_t>() : nullptr;
             const bool empty = pr.n1 == 0 || pr.n2 == 0;
-            if (pr.n1 != (type == 0 ? a.ns : a.nu) || pr.n2 != (type == 0 ? b.ns : b.nu)) needs_mask[type] = true;
-            pr.nrb = empty ? 0 : (pr.n1 + kRowsPerBlock - 1) / kRowsPerBlock;
+            if (limited) needs_mask[type] = true;
+            pr.nrb_main = empty ? 0 : (pr.n1 + kRowsPerBlock - 1) / kRowsPerBlock;
+            pr.nrb = pr.nrb_main + (empty ? 0 : (n_special + kRowsPerBlock - 1) / kRowsPerBlock);
             pr.nseg = empty ? 0 : (pr.n2 + kSegCols - 1) / kSegCols;
             pr.n2stride = round_up(pr.n2, 64);
             pr.block_start = total_blocks[type];
@@ -321,6 +338,8 @@ int upload_view(osfm_matcher *m, int view, const uint16_t *sift, int n_sift, con
     v.nu_pad = round_up(std::max(n_surf, 1), kRowsPerBlock);
     OSFM_RETURN_IF(v.sift.reserve((size_t)v.ns_pad * 128));
     OSFM_RETURN_IF(v.sift_corr.reserve((size_t)v.ns_pad * 4));
+    OSFM_RETURN_IF(v.sift_raw.reserve((size_t)v.ns_pad * 128));
+    OSFM_RETURN_IF(v.sift_raw_corr.reserve((size_t)v.ns_pad * 4));
     OSFM_RETURN_IF(v.surf.reserve((size_t)v.nu_pad * 64));
     OSFM_RETURN_IF(v.surf_corr.reserve((size_t)v.nu_pad * 4));
     const size_t b_sift = (size_t)n_sift * 128 * 2, b_surf = (size_t)n_surf * 64 * 2;
@@ -332,7 +351,33 @@ int upload_view(osfm_matcher *m, int view, const uint16_t *sift, int n_sift, con
     if (b_surf) OSFM_HIP_CHECK(hipMemcpyAsync(stage + b_sift, surf, b_surf, hipMemcpyHostToDevice, s));
     int32_t *flags = m->flags.as<int32_t>();
     launch_prepare_sift(reinterpret_cast<const uint16_t *>(stage), n_sift, v.ns_pad,
-        v.sift.as<int8_t>(), v.sift_corr.as<int32_t>(), flags + 0, s);
+        v.sift.as<int8_t>(), v.sift_corr.as<int32_t>(), v.sift_raw.as<int8_t>(),
+        v.sift_raw_corr.as<int32_t>(), flags + 0, s);
+    // special rows (any value > 127): listed on the host in ascending order so
+    // that the gathered set is the same on every run
+    std::vector<int32_t> special, slot;
+    for (int i = 0; i < n_sift; ++i) {
+        const uint16_t *d = sift + (size_t)i * 128;
+        bool big = false;
+        for (int k = 0; k < 128; ++k) big |= d[k] > 127;
+        if (big) special.push_back(i);
+    }
+    v.n_special = (int)special.size();
+    if (v.n_special > 0) {
+        slot.assign(n_sift, -1);
+        for (int k = 0; k < v.n_special; ++k) slot[special[k]] = k;
+        const int sp_pad = round_up(v.n_special, kRowsPerBlock);
+        OSFM_RETURN_IF(v.special.reserve((size_t)sp_pad * 128));
+        OSFM_RETURN_IF(v.special_corr.reserve((size_t)sp_pad * 4));
+        OSFM_RETURN_IF(v.special_map.reserve((size_t)v.n_special * 4));
+        OSFM_RETURN_IF(v.special_slot.reserve((size_t)n_sift * 4));
+        OSFM_HIP_CHECK(hipMemcpyAsync(v.special_map.ptr, special.data(), (size_t)v.n_special * 4, hipMemcpyHostToDevice, s));
+        OSFM_HIP_CHECK(hipMemcpyAsync(v.special_slot.ptr, slot.data(), (size_t)n_sift * 4, hipMemcpyHostToDevice, s));
+        // zero-vector padding in the value-128 form: bytes -128, correction -2^20 - 2^22
+        launch_gather_rows(v.sift.as<int8_t>(), v.sift_corr.as<int32_t>(), v.special_map.as<int32_t>(),
+            v.n_special, sp_pad, 128, -(1 << 20) - (1 << 22), (int8_t)-128, v.special.as<int8_t>(),
+            v.special_corr.as<int32_t>(), s);
+    }
     launch_prepare_surf(reinterpret_cast<const int16_t *>(stage + b_sift), n_surf, v.nu_pad,
         v.surf.as<int8_t>(), v.surf_corr.as<int32_t>(), flags + 1, flags + 0, s);
     OSFM_HIP_CHECK(hipGetLastError());

@@ -27,6 +27,20 @@ struct MatchProblem {
     int32_t out_off12;      // combine_results offset added to valid m12 entries
     int32_t out_off21;
     int32_t force_exact;    // every query goes through the wrap-exact scan
+    // Row blocks [0, nrb_main) run the RAW path: A_raw holds the descriptor
+    // values themselves (rows with a value > 127 replaced by padding rows) and
+    // corrA_raw = 128 * sum(a), so that  ip = sum(a * b') + corrA_raw  needs no
+    // per-column correction.  The rows that do not fit ("special rows", SIFT
+    // only) are gathered into A_special (value - 128 form, with corrA_special)
+    // and handled by the row blocks [nrb_main, nrb) with the keyed epilogue.
+    int32_t nrb_main;
+    const int8_t *A_raw;
+    const int32_t *corrA_raw;
+    const int8_t *A_special;
+    const int32_t *corrA_special;
+    const int32_t *special_map;    // [n_special] original row of a special slot
+    const int32_t *special_slot;   // [n1] slot of a row or -1 (null when n_special == 0)
+    int32_t n_special;
     int32_t pad_;
 };
 
@@ -66,7 +80,9 @@ void launch_compact_pairs(int num_pairs, const int32_t *m12_all, const int64_t *
     hipStream_t s);
 
 void launch_prepare_sift(const uint16_t *src, int n, int npad, int8_t *dst,
-    int32_t *corr, int32_t *range_err, hipStream_t s);
+    int32_t *corr, int8_t *dst_raw, int32_t *corr_raw, int32_t *range_err, hipStream_t s);
+void launch_gather_rows(const int8_t *src, const int32_t *corr, const int32_t *map, int n, int npad,
+    int dim, int32_t pad_corr, int8_t pad_byte, int8_t *dst, int32_t *dst_corr, hipStream_t s);
 void launch_prepare_surf(const int16_t *src, int n, int npad, int8_t *dst,
     int32_t *corr, int32_t *norm2max, int32_t *range_err, hipStream_t s);
 

@@ -122,10 +122,15 @@ __device__ __forceinline__ void top2_quad(int &b, int &s, int x0, int x1, int x2
 constexpr int kGroupTiles = 8;          // tiles per row-direction group (16 columns per slot)
 constexpr int kValNone = -(1 << 28);    // "no candidate" for un-keyed column scores
 
-template <int CH, bool MASKED>
-__global__ __launch_bounds__(256, 2) void
-match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, int total_blocks,
-    RowPart *__restrict__ rowparts, ColPart *__restrict__ colparts)
+// RAW = true: row operand in raw form (see MatchProblem): the accumulator IS
+// the inner product, no key is built per score in either direction (group keys
+// only), and the best column is recovered by the group rescan of the finish
+// kernel.  RAW = false: value-128 row operand with per-score keys
+// (ip << 8 | tile) carrying the column correction.
+template <int CH, bool MASKED, bool RAW>
+__device__ __forceinline__ void
+tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowparts,
+    ColPart *__restrict__ colparts, char *smem)
 {
     constexpr int D = CH * 16;
     constexpr int KS = CH / 2;            // MFMA k-steps (K = 32 bytes each)
@@ -133,44 +138,39 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
     constexpr int TILE_BYTES = kTileCols * D;
     constexpr int CHUNKS = kTileCols * CH;        // 16-B chunks per tile
     constexpr int CPT = CHUNKS / 256;             // chunks per thread (2 or 1)
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BBUF_BYTES = 2 * TILE_BYTES > 16384 ? 2 * TILE_BYTES : 16384;
+    constexpr int kCurNone = RAW ? -(1 << 26) : kKeyNone;   // (-2^26 << 4) == kKeyNone
+
     char *bbuf = smem;                                              // [2][TILE_BYTES] (>= 16 KB)
     int *corrbuf = reinterpret_cast<int *>(smem + BBUF_BYTES);      // [2][64]
     ColPart *colbuf = reinterpret_cast<ColPart *>(smem + BBUF_BYTES + 2 * 64 * 4);  // [2][4][64]
     int *rsecbuf = reinterpret_cast<int *>(smem + BBUF_BYTES + 2 * 64 * 4 + 2 * 4 * 64 * 8);  // [32][256]
 
-    const int lin = xcd_remap(blockIdx.x, total_blocks);
-    // locate the problem: largest p with block_start <= lin
-    int lo = 0, hi = num_problems - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (problems[mid].block_start <= lin) lo = mid; else hi = mid - 1;
-    }
-    const MatchProblem &pd = problems[lo];
-    const int local = lin - pd.block_start;
-    const int nseg = pd.nseg;
-    const int rb = local / nseg;
-    const int seg = local - rb * nseg;
     const int n1 = pd.n1, n2 = pd.n2;
-
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
-    const int row0 = rb * kRowsPerBlock + wave * 64;
+    const int row0 = rb * kRowsPerBlock + wave * 64;      // row slot (partials, validity)
 
     // --- resident A fragments and row corrections -------------------------
+    const int8_t *Abase = pd.A;
+    const int32_t *corrA = pd.corrA;
+    int arow0 = row0;
+    if (RAW) { Abase = pd.A_raw; corrA = pd.corrA_raw; }
+    else if (!MASKED && rb >= pd.nrb_main) {
+        Abase = pd.A_special; corrA = pd.corrA_special;
+        arow0 = (rb - pd.nrb_main) * kRowsPerBlock + wave * 64;
+    }
     v4i a[2][KS];
     v16i ra[2];
 #pragma unroll
     for (int rf = 0; rf < 2; ++rf) {
-        const int8_t *arow = pd.A + (size_t)(row0 + rf * 32 + lr) * D;
+        const int8_t *arow = Abase + (size_t)(arow0 + rf * 32 + lr) * D;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
             a[rf][ks] = *reinterpret_cast<const v4i *>(arow + (ks * 2 + lh) * 16);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            ra[rf][r] = pd.corrA[row0 + rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+            ra[rf][r] = corrA[arow0 + rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
     }
     unsigned row_valid_bits = 0xffffffffu;
     if (MASKED) {
@@ -189,7 +189,7 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
     for (int rf = 0; rf < 2; ++rf)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            rbest[rf][r] = kKeyNone; rcur[rf][r] = kKeyNone;
+            rbest[rf][r] = kKeyNone; rcur[rf][r] = kCurNone;
             rsecbuf[(rf * 16 + r) * 256 + tid] = kKeyNone;
         }
 
@@ -215,7 +215,7 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
                 (glb_void *)(src + (size_t)col * D + ch * 16),
                 (lds_void *)(uintptr_t)(bbuf + buf * TILE_BYTES + q0 * 16), 16, 0, 0);
         }
-        if (wave == 0)
+        if (!RAW && wave == 0)
             __builtin_amdgcn_global_load_lds(
                 (glb_void *)(pd.corrB + col_begin + t * kTileCols + lane),
                 (lds_void *)(uintptr_t)(corrbuf + buf * 64), 4, 0, 0);
@@ -230,7 +230,7 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
 
         // B fragments of the tile: 2 column groups x KS k-steps
         v4i b[2][KS];
-        int cbj[2], cjt[2];
+        int cbj[2] = {0, 0}, cjt[2] = {0, 0};
         bool col_valid[2];
 #pragma unroll
         for (int cf = 0; cf < 2; ++cf) {
@@ -240,11 +240,13 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
             for (int ks = 0; ks < KS; ++ks)
                 b[cf][ks] = *reinterpret_cast<const v4i *>(
                     bbuf + buf * TILE_BYTES + col * D + (((ks * 2 + lh) ^ swz) * 16));
-            cbj[cf] = corrbuf[buf * 64 + col];
-            cjt[cf] = (int)(((unsigned)cbj[cf] << 8) + (unsigned)(t * 2 + cf));
-            // opaque to the optimiser: otherwise it re-associates the key into
-            // ((acc + cb) << 8) + t, two ops per element instead of one v_lshl_add_u32
-            asm volatile("" : "+v"(cjt[cf]));
+            if (!RAW) {
+                cbj[cf] = corrbuf[buf * 64 + col];
+                cjt[cf] = (int)(((unsigned)cbj[cf] << 8) + (unsigned)(t * 2 + cf));
+                // opaque to the optimiser: otherwise it re-associates the key into
+                // ((acc + cb) << 8) + t, two ops per element instead of one v_lshl_add_u32
+                asm volatile("" : "+v"(cjt[cf]));
+            }
             col_valid[cf] = (col_begin + t * kTileCols + col) < n2;
         }
 
@@ -262,13 +264,22 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
             // row direction: the two column groups feed the same (lane, reg) slot
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int k0 = (int)(((unsigned)acc[0][r] << 8) + (unsigned)cjt[0]);
-                int k1 = (int)(((unsigned)acc[1][r] << 8) + (unsigned)cjt[1]);
-                if (MASKED) {
-                    k0 = col_valid[0] ? k0 : kKeyNone;
-                    k1 = col_valid[1] ? k1 : kKeyNone;
+                int k0, k1;
+                if (RAW) {
+                    // plain C++ (not the asm max3): these are the first readers of
+                    // the MFMA results and must stay visible to the hazard recogniser
+                    k0 = acc[0][r];
+                    k1 = acc[1][r];
+                    rcur[rf][r] = max(max(rcur[rf][r], k0), k1);
+                } else {
+                    k0 = (int)(((unsigned)acc[0][r] << 8) + (unsigned)cjt[0]);
+                    k1 = (int)(((unsigned)acc[1][r] << 8) + (unsigned)cjt[1]);
+                    if (MASKED) {
+                        k0 = col_valid[0] ? k0 : kKeyNone;
+                        k1 = col_valid[1] ? k1 : kKeyNone;
+                    }
+                    rcur[rf][r] = max3i(rcur[rf][r], k0, k1);
                 }
-                rcur[rf][r] = max3i(rcur[rf][r], k0, k1);
             }
             // column direction: un-keyed scores, groups of 8 rows (half a fragment)
 #pragma unroll
@@ -294,14 +305,16 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
 
         // close a row-direction group: fold the group bests into (best, second)
         if ((t % kGroupTiles) == kGroupTiles - 1 || t == ntiles - 1) {
+            const int gidx = t / kGroupTiles;
 #pragma unroll
             for (int rf = 0; rf < 2; ++rf)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     int *sp = rsecbuf + (rf * 16 + r) * 256 + tid;
-                    *sp = med3a(rbest[rf][r], *sp, rcur[rf][r]);
-                    rbest[rf][r] = max(rbest[rf][r], rcur[rf][r]);
-                    rcur[rf][r] = kKeyNone;
+                    const int gk = RAW ? (int)(((unsigned)rcur[rf][r] << 4) | (unsigned)gidx) : rcur[rf][r];
+                    *sp = med3a(rbest[rf][r], *sp, gk);
+                    rbest[rf][r] = max(rbest[rf][r], gk);
+                    rcur[rf][r] = kCurNone;
                 }
         }
 
@@ -352,7 +365,8 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
     // --- row direction: merge the 32 lanes that hold the same row -------------
     // Through LDS (the tile buffers are free now): each of 32 threads per wave
     // walks the 32 source lanes of one row.  (ip, column) composites keep
-    // "later column wins" across lanes.
+    // "later column wins" across lanes.  RAW keys carry the tile group only:
+    // the column reported is the first one of the winning (lane, group) stream.
     RowPart *rp = rowparts + pd.rowpart_off + (int64_t)seg * ((int64_t)pd.nrb * kRowsPerBlock);
     int *bb = reinterpret_cast<int *>(bbuf);                        // [16][256]
 #pragma unroll
@@ -369,9 +383,11 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
                 const int src = wave * 64 + h * 32 + l;
                 const int kbest = bb[r * 256 + src];
                 const int ksec = rsecbuf[(rf * 16 + r) * 256 + src];
-                if (ksec != kKeyNone) sec = max(sec, ksec >> 8);
+                if (ksec != kKeyNone) sec = max(sec, RAW ? (ksec >> 4) : (ksec >> 8));
                 if (kbest == kKeyNone) continue;
-                const int ip = kbest >> 8, col = col_begin + (kbest & 255) * 32 + l;
+                const int ip = RAW ? (kbest >> 4) : (kbest >> 8);
+                const int col = RAW ? col_begin + (kbest & 15) * kGroupTiles * kTileCols + l
+                                    : col_begin + (kbest & 255) * 32 + l;
                 if (ip > bip || (ip == bip && col > bcol)) { sec = max(sec, bip); bip = ip; bcol = col; }
                 else sec = max(sec, ip);
             }
@@ -381,6 +397,29 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
             rp[row] = out;
         }
     }
+}
+
+template <int CH, bool MASKED>
+__global__ __launch_bounds__(256, 2) void
+match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, int total_blocks,
+    RowPart *__restrict__ rowparts, ColPart *__restrict__ colparts)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lin = xcd_remap(blockIdx.x, total_blocks);
+    // locate the problem: largest p with block_start <= lin
+    int lo = 0, hi = num_problems - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (problems[mid].block_start <= lin) lo = mid; else hi = mid - 1;
+    }
+    const MatchProblem &pd = problems[lo];
+    const int local = lin - pd.block_start;
+    const int rb = local / pd.nseg;
+    const int seg = local - rb * pd.nseg;
+    if (!MASKED && rb < pd.nrb_main)
+        tile_body<CH, MASKED, true>(pd, rb, seg, rowparts, colparts, smem);
+    else
+        tile_body<CH, MASKED, false>(pd, rb, seg, rowparts, colparts, smem);
 }
 
 void launch_match_tiles(int ch, bool masked, const MatchProblem *d_problems, int num_problems,
@@ -465,7 +504,7 @@ __device__ __forceinline__ int exact_ip(const int8_t *q, const int8_t *c)
 template <int DIM, bool SIGNED>
 __device__ void
 rescan_group(const MatchProblem &pd, int dir, int q, int ip1, int idx1, int code, int m_other,
-    int *idx_out, int *second_out)
+    int *idx_out, int *best_out, int *second_out)
 {
     int best = INT_MIN, best_idx = 0, second = INT_MIN;
     if (dir == 0) {
@@ -486,15 +525,22 @@ rescan_group(const MatchProblem &pd, int dir, int q, int ip1, int idx1, int code
         const int wave = code >> 3, lh = (code >> 2) & 1, gid = code & 3;
         for (int i = 0; i < 8; ++i) {
             const int r = (gid & 1) * 8 + i;
-            const int row = rb * kRowsPerBlock + wave * 64 + (gid >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row >= pd.n1) continue;
+            int row = rb * kRowsPerBlock + wave * 64 + (gid >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (rb >= pd.nrb_main) {
+                // a block of gathered special rows: back to the original row
+                const int sidx = row - pd.nrb_main * kRowsPerBlock;
+                if (sidx >= pd.n_special) continue;
+                row = pd.special_map[sidx];
+            } else if (row >= pd.n1) continue;
             const int v = exact_ip<DIM, SIGNED>(qrow, pd.A + (size_t)row * DIM);
-            if (v >= best) { second = best; best = v; best_idx = row; }
+            // later ORIGINAL row wins ties (the gathered order need not be monotone)
+            if (v > best || (v == best && row > best_idx)) { second = best; best = v; best_idx = row; }
             else if (v > second) second = v;
         }
     }
     (void)ip1;
     *idx_out = best_idx;
+    *best_out = best;
     *second_out = max(second, m_other);
 }
 
@@ -518,8 +564,14 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
     int ip1 = INT_MIN, ip2 = INT_MIN, idx1 = 0, code = 0;
     if (dir == 0) {
         const int64_t stride = (int64_t)pd.nrb * kRowsPerBlock;
+        // special rows keep their partials behind the main row blocks
+        int slot = q;
+        if (pd.special_slot) {
+            const int sidx = pd.special_slot[q];
+            if (sidx >= 0) slot = pd.nrb_main * kRowsPerBlock + sidx;
+        }
         for (int sgi = 0; sgi < pd.nseg; ++sgi) {
-            const RowPart p = rowparts[pd.rowpart_off + sgi * stride + q];
+            const RowPart p = rowparts[pd.rowpart_off + sgi * stride + slot];
             // later segment wins ties (its columns have larger indices)
             ip2 = max(max(ip2, p.ip_second), min(ip1, p.ip_best));
             if (p.ip_best >= ip1 && p.ip_best != INT_MIN) { ip1 = p.ip_best; idx1 = p.idx_best; }
@@ -546,9 +598,12 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
                 exact = true;                 // accepted despite a tie for best (NaN accept /
                                               // ratio >= 1): defer to the sequential-scan kernel
             } else {
-                int idx, second;
-                rescan_group<DIM, SIGNED>(pd, dir, q, ip1, idx1, code, ip2, &idx, &second);
-                res = accept_match(ip1, second, idx, tab);
+                // the rescan also yields the exact best of the group: it differs from
+                // ip1 only when ip1 = 0 came from a padding column (raw path), i.e.
+                // when no real candidate reaches 0 -- then it is the value to test
+                int idx, found, second;
+                rescan_group<DIM, SIGNED>(pd, dir, q, ip1, idx1, code, ip2, &idx, &found, &second);
+                res = accept_match(found, second, idx, tab);
             }
         }
     }
@@ -781,28 +836,61 @@ void launch_compact_pairs(int num_pairs, const int32_t *m12_all, const int64_t *
 // ---------------------------------------------------------------------------
 __global__ void
 prepare_sift_kernel(const uint16_t *__restrict__ src, int n, int npad, int8_t *__restrict__ dst,
-    int32_t *__restrict__ corr, int32_t *__restrict__ range_err)
+    int32_t *__restrict__ corr, int8_t *__restrict__ dst_raw, int32_t *__restrict__ corr_raw,
+    int32_t *__restrict__ range_err)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= npad) return;
-    int sum = 0;
+    int sum = 0, vmax = 0, vals[2];
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int e = lane * 2 + k;
         int v = row < n ? (int)src[(size_t)row * 128 + e] : 0;     // pad rows: the zero vector
         if (v > 255) { bad = true; v = 255; }
-        const int a = v - 128;
-        dst[(size_t)row * 128 + e] = (int8_t)a;
-        sum += a;
+        vals[k] = v;
+        dst[(size_t)row * 128 + e] = (int8_t)(v - 128);
+        sum += v;
+        vmax = max(vmax, v);
     }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
-    // padding rows: correction of a zero vector minus 2^22, so every inner
-    // product with a padding row comes out at exactly -2^22 (see match_tile_kernel)
-    if (lane == 0) corr[row] = 128 * sum + (1 << 20) - (row < n ? 0 : (1 << 22));
+    for (int m = 32; m >= 1; m >>= 1) { sum += __shfl_xor(sum, m); vmax = max(vmax, __shfl_xor(vmax, m)); }
+    // raw form: only rows whose values all fit int8; the others (and the
+    // padding) become zero rows that lose every comparison (ip = -2^22)
+    const bool raw_ok = row < n && vmax <= 127;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) dst_raw[(size_t)row * 128 + lane * 2 + k] = (int8_t)(raw_ok ? vals[k] : 0);
+    if (lane == 0) {
+        // offset form: 128 * sum(a - 128) + 2^20; padding rows 2^22 lower, so every
+        // inner product with a padding row comes out at exactly -2^22
+        corr[row] = 128 * (sum - 128 * 128) + (1 << 20) - (row < n ? 0 : (1 << 22));
+        corr_raw[row] = raw_ok ? 128 * sum : -(1 << 22);
+    }
     if (bad) atomicOr(range_err, 1);
+}
+
+// rows map[0..n) of (src, corr) gathered into a compact padded set
+__global__ void
+gather_rows_kernel(const int8_t *__restrict__ src, const int32_t *__restrict__ corr,
+    const int32_t *__restrict__ map, int n, int npad, int dim, int32_t pad_corr, int8_t pad_byte,
+    int8_t *__restrict__ dst, int32_t *__restrict__ dst_corr)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= npad) return;
+    const int from = row < n ? map[row] : -1;
+    for (int e = lane; e < dim; e += 64)
+        dst[(size_t)row * dim + e] = from >= 0 ? src[(size_t)from * dim + e] : pad_byte;
+    if (lane == 0) dst_corr[row] = from >= 0 ? corr[from] : pad_corr;
+}
+
+void launch_gather_rows(const int8_t *src, const int32_t *corr, const int32_t *map, int n, int npad,
+    int dim, int32_t pad_corr, int8_t pad_byte, int8_t *dst, int32_t *dst_corr, hipStream_t s)
+{
+    if (npad <= 0) return;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((npad + 3) / 4), dim3(256), 0, s, src, corr, map, n, npad,
+        dim, pad_corr, pad_byte, dst, dst_corr);
 }
 
 __global__ void
@@ -825,11 +913,11 @@ prepare_surf_kernel(const int16_t *__restrict__ src, int n, int npad, int8_t *__
 }
 
 void launch_prepare_sift(const uint16_t *src, int n, int npad, int8_t *dst, int32_t *corr,
-    int32_t *range_err, hipStream_t s)
+    int8_t *dst_raw, int32_t *corr_raw, int32_t *range_err, hipStream_t s)
 {
     if (npad <= 0) return;
     hipLaunchKernelGGL(prepare_sift_kernel, dim3((npad + 3) / 4), dim3(256), 0, s, src, n, npad, dst,
-        corr, range_err);
+        corr, dst_raw, corr_raw, range_err);
 }
 
 void launch_prepare_surf(const int16_t *src, int n, int npad, int8_t *dst, int32_t *corr,

@@ -249,3 +249,34 @@ def test_cpp_adapter_vs_reference_side_by_side():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "adapter_check ok: 20 pairs identical" in out.stdout
+
+
+def test_special_rows_large_values(hm):
+    """Descriptors with entries > 127 cannot use the raw int8 row form: they are
+    gathered into extra row blocks on the keyed path.  Mix them into both views
+    (several hundred, spread over many row blocks) and compare with the oracle."""
+    s1, s2 = match_cases.sift_pair(3000, 2600, 1500, 900)
+    r = np.random.default_rng(11)
+    for s in (s1, s2):
+        rows = r.choice(s.shape[0], 300, replace=False)
+        for k in rows:
+            d = np.zeros(128, np.uint16)
+            pos = r.choice(128, 3, replace=False)
+            d[pos] = [int(r.integers(128, 256)), int(r.integers(0, 90)), int(r.integers(0, 60))]
+            s[k] = d
+    # duplicates of special rows: ties between special and ordinary blocks
+    s1[10] = s1[2990]
+    s2[5] = s2[2000]
+    om = oracle_lib.oracle_matcher()
+    e12, e21 = om.twoway(s1, s2, 0.8)
+    m = hm(2)
+    m.set_view(0, s1)
+    m.set_view(1, s2)
+    got = m.twoway_match(0, 1, 0)       # masked (keyed) kernel
+    assert np.array_equal(got.matches_1_2, e12) and np.array_equal(got.matches_2_1, e21)
+    c12, c21 = om.remove_inconsistent(e12, e21)
+    got = m.pairwise_match(0, 1)        # raw + special-row kernel
+    assert np.array_equal(got.matches_1_2, c12) and np.array_equal(got.matches_2_1, c21)
+    got = m.pairwise_match(1, 0)
+    assert np.array_equal(got.matches_1_2, c21) and np.array_equal(got.matches_2_1, c12)
+    m.close()
