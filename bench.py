@@ -42,13 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = auto (about 15 s of CPU work)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsal)")
     return ap.parse_args()
-
-
-def shard_pairs(pairs, rank, world):
-    """Static round-robin deal of the triangular pair list (work per pair is
-    N1*N2, known up front; equal-sized views -> equal work)."""
-    return pairs[rank::world]
 
 
 def cpu_baseline(iset, pairs, n_sample):
@@ -72,6 +67,19 @@ def cpu_baseline(iset, pairs, n_sample):
     return {"value": n_sample / dt, "unit": "pairs/s", "cores": int(threads), "kind": "port",
             "sample": f"{n_sample} full-size pairs ({iset.sift[0].shape[0]} x {iset.sift[0].shape[0]} SIFT, "
                       f"two-way + cross-check) of the same image set, {dt:.1f} s"}
+
+
+def pmc_traffic_per_launch(pairs_per_launch):
+    """HBM bytes of one launch of the dominant kernel from the committed PMC
+    passes (profiles/r01_match_traffic_pmc.json: FETCH_SIZE and WRITE_SIZE
+    collected in separate rocprofv3 --pmc runs of this same command, FETCH_SIZE
+    doubled as the gfx950 guide prescribes), scaled to the pairs per launch."""
+    path = os.path.join(ROOT, "profiles", "r01_match_traffic_pmc.json")
+    try:
+        rec = json.load(open(path))
+        return rec["hbm_bytes_per_pair"] * pairs_per_launch
+    except Exception:
+        return None
 
 
 def ba_cpu_baseline(iterations=2):
@@ -98,16 +106,25 @@ def main():
     dist = None
     torch = None
     if world > 1:
+        # torch first: it brings its own ROCm runtime, which libosfm_hip.so then shares
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
     from orthosfm_amd import capi, synth
+    from orthosfm_amd import distributed as D
     from orthosfm_amd.matching import HipExhaustiveMatching
 
-    if capi.device_count() < 1:
+    ndev = capi.device_count()
+    if ndev < 1:
         raise RuntimeError("bench.py: no HIP device (the backend has no CPU fallback)")
+    device_index = local_rank % ndev
+    tdev = "cpu"
+    if world > 1:
+        if args.backend == "nccl":
+            torch.cuda.set_device(device_index)
+            tdev = torch.device("cuda", device_index)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=tdev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     # weak scaling: the image set grows with the rank count so that every
     # GPU keeps ~1225 pairs (50 views -> 1225; 71 -> 2485; 100 -> 4950; 141 -> 9870)
@@ -119,9 +136,9 @@ def main():
     F = args.features
     iset = synth.make_image_set(V, F, config_id=2)
     all_pairs = [capi.pair_from_index(i) for i in range(V * (V - 1) // 2)]
-    my_pairs = shard_pairs(all_pairs, rank, world)
+    my_pairs = D.shard_pairs(all_pairs, rank, world)
 
-    m = HipExhaustiveMatching(V, device=local_rank)
+    m = HipExhaustiveMatching(V, device=device_index)
     t0 = time.perf_counter()
     for v in range(V):
         m.set_view(v, iset.sift[v])
@@ -131,23 +148,19 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
 
     def step():
         out = m.compute(my_pairs, capacity=capacity)
         st = m.stats()
-        n_corr = sum(int(tv.num_matches) for tv in out if tv.status == capi.PAIR_MATCHED)
+        counts = np.array([tv.num_matches if tv.status == capi.PAIR_MATCHED else 0 for tv in out], dtype=np.int64)
+        n_corr = int(counts.sum())
+        # the only collective of the path: the match lists travel to rank 0
+        # (pair order restored there) for RANSAC / track building
         if world > 1:
-            # the only collective of the path: gather the match lists on rank 0
-            counts = torch.tensor([n_corr], dtype=torch.int64, device="cuda")
-            allc = [torch.zeros_like(counts) for _ in range(world)]
-            dist.all_gather(allc, counts)
-            mx = int(max(int(c.item()) for c in allc))
-            flat = np.concatenate([tv.matches.reshape(-1) for tv in out] + [np.zeros(0, np.int32)])
-            buf = torch.zeros(2 * mx, dtype=torch.int32, device="cuda")
-            buf[:flat.size] = torch.from_numpy(flat).cuda()
-            gathered = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
-            dist.gather(buf, gathered, dst=0)
+            flat = np.concatenate([tv.matches for tv in out] + [np.zeros((0, 2), np.int32)], axis=0)
+            D.gather_match_lists(counts, flat, len(all_pairs), rank, world, device=tdev)
         return out, st, n_corr
 
     for _ in range(args.warmup):
@@ -162,15 +175,8 @@ def main():
         macs += st.mac_count
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        tot = torch.tensor([float(len(my_pairs))], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tot)
-        total_pairs = int(tot.item())
-    else:
-        total_pairs = len(my_pairs)
+    dt = D.max_over_ranks(dt, world, device=tdev)
+    total_pairs = len(all_pairs)
 
     ba = None
     if not args.no_ba and rank == 0:
@@ -201,7 +207,8 @@ def main():
                        "views": V, "features_per_view": F, "pairs": total_pairs,
                        "sharding": f"pairs round-robin over {world} rank(s)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_MFMA_PEAK_TOPS,
-                         "unit": "TFLOP/s", "frac": achieved / I8_MFMA_PEAK_TOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / I8_MFMA_PEAK_TOPS,
+                         "traffic": pmc_traffic_per_launch(len(my_pairs) * args.steps / max(kern_launches, 1)),
                          "kernel": "match_tile_kernel<8>", "launches_per_step": kern_launches / args.steps,
                          "avg_launch_ms": avg_launch_s * 1e3,
                          "hbm_algorithmic_GBs": (st.algorithmic_bytes / max(st.tile_kernel_launches, 1))
