@@ -387,3 +387,47 @@ def ba_cost(scene, huber=1.0):
     b = huber * huber
     rho = np.where(s > b, 2.0 * huber * np.sqrt(s) - b, s)
     return 0.5 * rho.sum()
+
+
+# ---------------------------------------------------------------------------
+# geometric verification oracle (oracle/ransac_oracle.c) and reference shim
+# ---------------------------------------------------------------------------
+REF_RANSAC_SO = os.path.join(ORACLE_DIR, "_ref", "libref_ransac.so")
+_ref_ransac = None
+
+
+def ref_ransac():
+    global _ref_ransac
+    if _ref_ransac is None and os.path.exists(REF_RANSAC_SO):
+        _ref_ransac = C.CDLL(REF_RANSAC_SO)
+    return _ref_ransac
+
+
+def oracle_sampson(F, p1, p2):
+    f = oracle().oracle_sampson_distance
+    f.argtypes = [_f64p, _f64p, _f64p]
+    f.restype = C.c_double
+    return f(np.ascontiguousarray(F, np.float64).reshape(-1), np.ascontiguousarray(p1, np.float64),
+             np.ascontiguousarray(p2, np.float64))
+
+
+def oracle_fundamental_8_point(p1, p2):
+    f = oracle().oracle_fundamental_8_point
+    f.argtypes = [_f64p, _f64p, _f64p]
+    f.restype = C.c_int
+    F = np.zeros(9)
+    ok = f(np.ascontiguousarray(p1, np.float64).reshape(-1), np.ascontiguousarray(p2, np.float64).reshape(-1), F)
+    return ok, F.reshape(3, 3)
+
+
+def oracle_ransac(pos1, pos2, corr, max_iterations=1000, threshold=0.0015, seed=0, pair_id=0):
+    f = oracle().oracle_ransac_fundamental
+    f.argtypes = [_f32p, _f32p, _i32p, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_uint64, _i32p, _f64p]
+    f.restype = C.c_int
+    corr = np.ascontiguousarray(corr, np.int32).reshape(-1, 2)
+    inl = np.zeros(max(corr.shape[0], 1), np.int32)
+    F = np.zeros(9)
+    n = f(np.ascontiguousarray(pos1, np.float32).reshape(-1), np.ascontiguousarray(pos2, np.float32).reshape(-1),
+          corr.reshape(-1) if corr.size else np.zeros(2, np.int32), corr.shape[0], max_iterations, threshold,
+          seed, pair_id, inl, F)
+    return n, inl[:max(n, 0)].copy(), F.reshape(3, 3)
