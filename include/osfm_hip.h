@@ -58,6 +58,13 @@ typedef struct osfm_match_options {
     int32_t min_lowres_matches;     /* 5      bundler_matching.h:70 */
     int32_t min_feature_matches;    /* 50     matching_mve.cpp:403 */
     int32_t pairs_per_batch;        /* pairs resident in one launch group (0 = auto) */
+    /* geometric verification (RansacFundamental, bundler_matching.cc:194-219) */
+    int32_t geometric_verification; /* 0: osfm_match_all stops before RANSAC (default) */
+    int32_t ransac_max_iterations;  /* 1000   ransac_fundamental.h:42 */
+    double ransac_threshold;        /* 0.0015 matching_mve.cpp:395 */
+    int32_t min_matching_inliers;   /* 30     matching_mve.cpp:402 */
+    int32_t reserved0;
+    uint64_t ransac_seed;           /* stream seed of the counter-based sampler */
 } osfm_match_options;
 
 OSFM_API int osfm_match_options_default(osfm_match_options *opts);
@@ -95,6 +102,11 @@ OSFM_API int osfm_match_set_view_float(osfm_matcher *m, int view,
 OSFM_API int osfm_match_view_size(const osfm_matcher *m, int view,
     int *n_sift, int *n_surf);
 
+/* FeatureSet::positions of a view (src/mve/sfm/feature_set.h:66): n = n_sift +
+ * n_surf normalised (x, y) float pairs in the combined feature index space.
+ * Needed only for geometric verification. */
+OSFM_API int osfm_match_set_positions(osfm_matcher *m, int view, const float *xy, int n);
+
 /*
  * MatchingBase::pairwise_match (matching_base.h:43-44;
  * ExhaustiveMatching::pairwise_match, exhaustive_matching.cc:114-144):
@@ -131,14 +143,15 @@ enum {
     OSFM_PAIR_MATCHED = 0,          /* survived both gates */
     OSFM_PAIR_REJECTED_LOWRES = 1,  /* bundler_matching.cc:146-158 */
     OSFM_PAIR_REJECTED_COUNT = 2,   /* bundler_matching.cc:163-172 */
-    OSFM_PAIR_SKIPPED_EMPTY = 3     /* a view without features, :96-99 */
+    OSFM_PAIR_SKIPPED_EMPTY = 3,    /* a view without features, :96-99 */
+    OSFM_PAIR_REJECTED_INLIERS = 4  /* bundler_matching.cc:203-210 (verification on) */
 };
 
 typedef struct osfm_pair_result {
     int32_t status;          /* OSFM_PAIR_* */
     int32_t lowres_matches;  /* -1 when the low-res gate did not apply */
     int32_t num_matches;     /* count_consistent_matches of the full match */
-    int32_t reserved;
+    int32_t num_inliers;     /* RANSAC inliers (-1 when verification is off / not reached) */
     int64_t offset;          /* first correspondence in `corr` (pairs of ints) */
 } osfm_pair_result;
 
@@ -151,6 +164,10 @@ typedef struct osfm_pair_result {
  * reference's thread-completion order).  corr receives 2 ints per
  * correspondence; if more than `capacity` correspondences are produced the
  * call fails with OSFM_E_CAPACITY and *total holds the required count.
+ * With opts.geometric_verification the call continues through RANSAC-F
+ * (bundler_matching.cc:194-219): the list of a pair then holds its num_inliers
+ * inlier correspondences (TwoViewMatching::matches) and pairs with fewer than
+ * max(8, min_matching_inliers) inliers are OSFM_PAIR_REJECTED_INLIERS.
  */
 OSFM_API int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs,
     int num_pairs, osfm_pair_result *results, int32_t *corr,
@@ -170,6 +187,24 @@ typedef struct osfm_match_stats {
     int64_t algorithmic_bytes;   /* descriptors read once + results written */
 } osfm_match_stats;
 OSFM_API int osfm_match_get_stats(const osfm_matcher *m, osfm_match_stats *out);
+
+/* RansacFundamental::Options (src/mve/sfm/ransac_fundamental.h:33-54). */
+typedef struct osfm_ransac_options {
+    int32_t max_iterations;   /* 1000 */
+    int32_t reserved;
+    double threshold;         /* 0.0015 */
+    uint64_t seed;
+} osfm_ransac_options;
+OSFM_API int osfm_ransac_options_default(osfm_ransac_options *o);
+
+/* RansacFundamental::estimate for one pair (ransac_fundamental.cc:26-60):
+ * pos1/pos2 normalised feature positions, corr k (feature_1, feature_2) pairs.
+ * inliers receives ascending ids into corr (capacity k); *num_inliers = -1 for
+ * k < 8 (the reference throws).  F (9 doubles, row major) may be NULL.  The
+ * sample stream is (seed, pair_id): results do not depend on batching. */
+OSFM_API int osfm_ransac_fundamental(int device, const float *pos1, int n1, const float *pos2, int n2,
+    const int32_t *corr, int k, const osfm_ransac_options *opts, uint64_t pair_id,
+    int32_t *inliers, int32_t *num_inliers, double *F);
 
 /* ====================================================================== */
 /* (B) Bundle adjustment                                                   */

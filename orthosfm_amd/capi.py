@@ -29,7 +29,7 @@ class OsfmError(RuntimeError):
 
 
 OK, E_ARG, E_DEVICE, E_RANGE, E_CAPACITY, E_STATE, E_NUMERIC = 0, -1, -2, -3, -4, -5, -6
-PAIR_MATCHED, PAIR_REJECTED_LOWRES, PAIR_REJECTED_COUNT, PAIR_SKIPPED_EMPTY = 0, 1, 2, 3
+PAIR_MATCHED, PAIR_REJECTED_LOWRES, PAIR_REJECTED_COUNT, PAIR_SKIPPED_EMPTY, PAIR_REJECTED_INLIERS = 0, 1, 2, 3, 4
 
 
 class MatchOptions(C.Structure):
@@ -37,7 +37,15 @@ class MatchOptions(C.Structure):
                 ("surf_lowe_ratio", C.c_float), ("surf_distance_threshold", C.c_float),
                 ("use_lowres_matching", C.c_int32), ("num_lowres_features", C.c_int32),
                 ("min_lowres_matches", C.c_int32), ("min_feature_matches", C.c_int32),
-                ("pairs_per_batch", C.c_int32)]
+                ("pairs_per_batch", C.c_int32),
+                ("geometric_verification", C.c_int32), ("ransac_max_iterations", C.c_int32),
+                ("ransac_threshold", C.c_double), ("min_matching_inliers", C.c_int32),
+                ("reserved0", C.c_int32), ("ransac_seed", C.c_uint64)]
+
+
+class RansacOptions(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("reserved", C.c_int32),
+                ("threshold", C.c_double), ("seed", C.c_uint64)]
 
 
 class Pair(C.Structure):
@@ -46,7 +54,7 @@ class Pair(C.Structure):
 
 class PairResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("lowres_matches", C.c_int32),
-                ("num_matches", C.c_int32), ("reserved", C.c_int32), ("offset", C.c_int64)]
+                ("num_matches", C.c_int32), ("num_inliers", C.c_int32), ("offset", C.c_int64)]
 
 
 class MatchStats(C.Structure):
@@ -91,7 +99,8 @@ EXPORTS = [
     "osfm_last_error", "osfm_version", "osfm_device_count",
     "osfm_match_options_default", "osfm_match_create", "osfm_match_destroy",
     "osfm_quantize_sift", "osfm_quantize_surf",
-    "osfm_match_set_view", "osfm_match_set_view_float", "osfm_match_view_size",
+    "osfm_match_set_view", "osfm_match_set_view_float", "osfm_match_view_size", "osfm_match_set_positions",
+    "osfm_ransac_options_default", "osfm_ransac_fundamental",
     "osfm_match_pair", "osfm_match_pair_lowres", "osfm_match_twoway", "osfm_match_all",
     "osfm_pair_from_index", "osfm_match_get_stats",
     "osfm_ba_options_default", "osfm_ba_solve", "osfm_ba_reprojection_errors",

@@ -10,6 +10,7 @@
 
 #include "match_kernels.h"
 #include "osfm_common.h"
+#include "ransac_kernels.h"
 
 namespace osfm {
 
@@ -39,6 +40,8 @@ struct ViewData {
     DeviceBuffer sift_raw, sift_raw_corr, special, special_corr, special_map, special_slot;
     int n_special = 0;
     int surf_norm2_max = 0;
+    DeviceBuffer positions;      // [ns + nu][2] floats (geometric verification only)
+    int n_positions = -1;
 };
 
 // Host twin of matching.h:126-127,138-143 for every (d1, d2): the smallest
@@ -97,6 +100,7 @@ struct osfm_matcher {
     DeviceBuffer d_problems[2], rowparts, colparts, out, keep, mark_off[2], counts[2];
     DeviceBuffer exact_items, exact_count, stage_in, flags;
     DeviceBuffer d_m12_off, d_len12, d_corr_off, d_keep_pair, d_corr;
+    DeviceBuffer d_jobs, d_inl, d_inl_count, d_corr2, d_gather_off;
     hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
 
     osfm_match_stats stats;
@@ -422,6 +426,12 @@ int osfm_match_options_default(osfm_match_options *o)
     o->min_lowres_matches = 5;
     o->min_feature_matches = 50;
     o->pairs_per_batch = 0;
+    o->geometric_verification = 0;
+    o->ransac_max_iterations = 1000;
+    o->ransac_threshold = 0.0015;
+    o->min_matching_inliers = 30;
+    o->reserved0 = 0;
+    o->ransac_seed = 0;
     return OSFM_OK;
 }
 
@@ -469,11 +479,16 @@ int osfm_match_destroy(osfm_matcher *m)
     if (!m) return OSFM_OK;
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);
-    for (auto &v : m->views) { v.sift.release(); v.sift_corr.release(); v.surf.release(); v.surf_corr.release(); }
+    for (auto &v : m->views) {
+        DeviceBuffer *vb[] = {&v.sift, &v.sift_corr, &v.surf, &v.surf_corr, &v.sift_raw, &v.sift_raw_corr,
+            &v.special, &v.special_corr, &v.special_map, &v.special_slot, &v.positions};
+        for (auto *b : vb) b->release();
+    }
     DeviceBuffer *bufs[] = {&m->lowe_sift, &m->lowe_surf, &m->d_problems[0], &m->d_problems[1],
         &m->rowparts, &m->colparts, &m->out, &m->keep, &m->mark_off[0], &m->mark_off[1],
         &m->counts[0], &m->counts[1], &m->exact_items, &m->exact_count, &m->stage_in, &m->flags,
-        &m->d_m12_off, &m->d_len12, &m->d_corr_off, &m->d_keep_pair, &m->d_corr};
+        &m->d_m12_off, &m->d_len12, &m->d_corr_off, &m->d_keep_pair, &m->d_corr,
+        &m->d_jobs, &m->d_inl, &m->d_inl_count, &m->d_corr2, &m->d_gather_off};
     for (auto *b : bufs) b->release();
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2; ++j)
@@ -538,6 +553,76 @@ int osfm_match_view_size(const osfm_matcher *m, int view, int *n_sift, int *n_su
     OSFM_RETURN_IF(check_view(m, view, "view_size"));
     if (n_sift) *n_sift = m->views[view].ns;
     if (n_surf) *n_surf = m->views[view].nu;
+    return OSFM_OK;
+}
+
+int osfm_match_set_positions(osfm_matcher *m, int view, const float *xy, int n)
+{
+    if (!m || n < 0 || (n > 0 && !xy)) { set_error("set_positions: bad argument"); return OSFM_E_ARG; }
+    std::lock_guard<std::mutex> lock(m->mu);
+    OSFM_HIP_CHECK(hipSetDevice(m->device));
+    OSFM_RETURN_IF(check_view(m, view, "set_positions"));
+    ViewData &v = m->views[view];
+    if (n != v.ns + v.nu) {
+        set_error("set_positions: view %d has %d features, got %d positions", view, v.ns + v.nu, n);
+        return OSFM_E_ARG;
+    }
+    OSFM_RETURN_IF(v.positions.reserve((size_t)std::max(n, 1) * 8));
+    if (n) OSFM_HIP_CHECK(hipMemcpy(v.positions.ptr, xy, (size_t)n * 8, hipMemcpyHostToDevice));
+    v.n_positions = n;
+    return OSFM_OK;
+}
+
+int osfm_ransac_options_default(osfm_ransac_options *o)
+{
+    if (!o) { set_error("ransac_options_default: null"); return OSFM_E_ARG; }
+    o->max_iterations = 1000; o->reserved = 0; o->threshold = 0.0015; o->seed = 0;
+    return OSFM_OK;
+}
+
+int osfm_ransac_fundamental(int device, const float *pos1, int n1, const float *pos2, int n2,
+    const int32_t *corr, int k, const osfm_ransac_options *opts, uint64_t pair_id,
+    int32_t *inliers, int32_t *num_inliers, double *F)
+{
+    if (n1 < 0 || n2 < 0 || k < 0 || !num_inliers || (k > 0 && (!pos1 || !pos2 || !corr || !inliers))) {
+        set_error("ransac_fundamental: bad argument"); return OSFM_E_ARG;
+    }
+    for (int i = 0; i < k; ++i)
+        if (corr[2 * i] < 0 || corr[2 * i] >= n1 || corr[2 * i + 1] < 0 || corr[2 * i + 1] >= n2) {
+            set_error("ransac_fundamental: correspondence %d out of range", i); return OSFM_E_ARG;
+        }
+    osfm_ransac_options o;
+    if (opts) o = *opts; else osfm_ransac_options_default(&o);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("ransac_fundamental: no HIP device available (this backend has no CPU fallback)");
+        return OSFM_E_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { set_error("ransac_fundamental: bad device"); return OSFM_E_ARG; }
+    OSFM_HIP_CHECK(hipSetDevice(device));
+    if (k < 8) { *num_inliers = -1; return OSFM_OK; }
+    DeviceBuffer d1, d2, dc, di, dn, df, dj;
+    struct Rel { DeviceBuffer *b[7]; ~Rel() { for (auto *x : b) x->release(); } } rel{{&d1, &d2, &dc, &di, &dn, &df, &dj}};
+    OSFM_RETURN_IF(d1.reserve((size_t)n1 * 8)); OSFM_RETURN_IF(d2.reserve((size_t)n2 * 8));
+    OSFM_RETURN_IF(dc.reserve((size_t)k * 8)); OSFM_RETURN_IF(di.reserve((size_t)k * 4));
+    OSFM_RETURN_IF(dn.reserve(16)); OSFM_RETURN_IF(df.reserve(72)); OSFM_RETURN_IF(dj.reserve(sizeof(RansacJob)));
+    OSFM_HIP_CHECK(hipMemcpy(d1.ptr, pos1, (size_t)n1 * 8, hipMemcpyHostToDevice));
+    OSFM_HIP_CHECK(hipMemcpy(d2.ptr, pos2, (size_t)n2 * 8, hipMemcpyHostToDevice));
+    OSFM_HIP_CHECK(hipMemcpy(dc.ptr, corr, (size_t)k * 8, hipMemcpyHostToDevice));
+    RansacJob job;
+    memset(&job, 0, sizeof(job));
+    job.pos1 = d1.as<float>(); job.pos2 = d2.as<float>(); job.corr = dc.as<int32_t>(); job.k = k;
+    job.pair_id = pair_id; job.inliers_out = di.as<int32_t>(); job.count_out = dn.as<int32_t>();
+    job.F_out = df.as<double>();
+    OSFM_HIP_CHECK(hipMemcpy(dj.ptr, &job, sizeof(job), hipMemcpyHostToDevice));
+    launch_ransac(dj.as<RansacJob>(), 1, o.max_iterations, o.threshold, o.seed, nullptr);
+    OSFM_HIP_CHECK(hipGetLastError());
+    OSFM_HIP_CHECK(hipDeviceSynchronize());
+    int32_t cnt = 0;
+    OSFM_HIP_CHECK(hipMemcpy(&cnt, dn.ptr, 4, hipMemcpyDeviceToHost));
+    *num_inliers = cnt;
+    if (cnt > 0) OSFM_HIP_CHECK(hipMemcpy(inliers, di.ptr, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    if (F) OSFM_HIP_CHECK(hipMemcpy(F, df.ptr, 72, hipMemcpyDeviceToHost));
     return OSFM_OK;
 }
 
@@ -634,7 +719,7 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
         OSFM_RETURN_IF(check_view(m, pairs[p].view_2, "match_all"));
         const ViewData &a = m->views[pairs[p].view_1], &b = m->views[pairs[p].view_2];
         osfm_pair_result &r = results[p];
-        r.status = OSFM_PAIR_MATCHED; r.lowres_matches = -1; r.num_matches = 0; r.reserved = 0; r.offset = 0;
+        r.status = OSFM_PAIR_MATCHED; r.lowres_matches = -1; r.num_matches = 0; r.num_inliers = -1; r.offset = 0;
         const size_t np1 = (size_t)a.ns + a.nu, np2 = (size_t)b.ns + b.nu;
         if (np1 == 0 || np2 == 0) { r.status = OSFM_PAIR_SKIPPED_EMPTY; continue; }
         if (o.use_lowres_matching && np1 * np2 > 1000000) lowres_idx.push_back(p);
@@ -682,7 +767,7 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
 
     // ---- full matching + ordered correspondence lists -----------------------
     const int min_matches = std::max(8, o.min_feature_matches);
-    int64_t written = 0;
+    int64_t written = 0, written_out = 0;     // pre-RANSAC / post-RANSAC correspondence counts
     bool overflow = false;
     {
         const int bs = batch_size_for(false);
@@ -712,7 +797,7 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
                 h_corr_off[k] = chunk_corr;
                 chunk_corr += res.counts[k];
             }
-            if (written + chunk_corr > capacity) overflow = true;
+            if (!o.geometric_verification && written + chunk_corr > capacity) overflow = true;
             if (!overflow && chunk_corr > 0) {
                 hipStream_t s = m->stream;
                 OSFM_RETURN_IF(m->d_m12_off.reserve(n * 8));
@@ -728,13 +813,86 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
                     m->d_len12.as<int32_t>(), m->d_corr_off.as<int64_t>(), m->d_keep_pair.as<uint8_t>(),
                     m->d_corr.as<int32_t>(), s);
                 OSFM_HIP_CHECK(hipGetLastError());
-                OSFM_HIP_CHECK(hipMemcpyAsync(corr + 2 * written, m->d_corr.ptr, (size_t)chunk_corr * 8,
-                    hipMemcpyDeviceToHost, s));
+                if (!o.geometric_verification) {
+                    OSFM_HIP_CHECK(hipMemcpyAsync(corr + 2 * written, m->d_corr.ptr, (size_t)chunk_corr * 8,
+                        hipMemcpyDeviceToHost, s));
+                    OSFM_HIP_CHECK(hipStreamSynchronize(s));
+                }
+            }
+            if (o.geometric_verification && chunk_corr > 0) {
+                // ---- RANSAC-F on the device-resident lists (bundler_matching.cc:194-219) ----
+                hipStream_t s = m->stream;
+                std::vector<RansacJob> jobs;
+                std::vector<int> job_pair;
+                OSFM_RETURN_IF(m->d_inl.reserve((size_t)chunk_corr * 4));
+                OSFM_RETURN_IF(m->d_inl_count.reserve((size_t)n * 4));
+                for (int k = 0; k < n; ++k) {
+                    if (!h_keep[k]) continue;
+                    const int p = full_idx[start + k];
+                    const ViewData &a = m->views[pairs[p].view_1], &b = m->views[pairs[p].view_2];
+                    if (a.n_positions < 0 || b.n_positions < 0) {
+                        set_error("match_all: geometric verification needs osfm_match_set_positions for views %d and %d",
+                            pairs[p].view_1, pairs[p].view_2);
+                        return OSFM_E_STATE;
+                    }
+                    RansacJob j;
+                    memset(&j, 0, sizeof(j));
+                    j.pos1 = a.positions.as<float>(); j.pos2 = b.positions.as<float>();
+                    j.corr = m->d_corr.as<int32_t>() + 2 * h_corr_off[k];
+                    j.k = res.counts[k];
+                    // stream id = linear index of the pair in the reference's enumeration
+                    const int64_t hi = std::max(pairs[p].view_1, pairs[p].view_2), lo = std::min(pairs[p].view_1, pairs[p].view_2);
+                    j.pair_id = (uint64_t)(hi * (hi - 1) / 2 + lo);
+                    j.inliers_out = m->d_inl.as<int32_t>() + h_corr_off[k];
+                    j.count_out = m->d_inl_count.as<int32_t>() + (int)jobs.size();
+                    j.F_out = nullptr;
+                    jobs.push_back(j); job_pair.push_back(k);
+                }
+                OSFM_RETURN_IF(m->d_jobs.reserve(jobs.size() * sizeof(RansacJob)));
+                OSFM_HIP_CHECK(hipMemcpyAsync(m->d_jobs.ptr, jobs.data(), jobs.size() * sizeof(RansacJob), hipMemcpyHostToDevice, s));
+                launch_ransac(m->d_jobs.as<RansacJob>(), (int)jobs.size(), o.ransac_max_iterations, o.ransac_threshold,
+                    o.ransac_seed, s);
+                OSFM_HIP_CHECK(hipGetLastError());
+                std::vector<int32_t> h_cnt(jobs.size());
+                OSFM_HIP_CHECK(hipMemcpyAsync(h_cnt.data(), m->d_inl_count.ptr, jobs.size() * 4, hipMemcpyDeviceToHost, s));
                 OSFM_HIP_CHECK(hipStreamSynchronize(s));
+                // keep pairs with enough inliers; gather their inlier correspondences
+                const int min_inl = std::max(8, o.min_matching_inliers);
+                std::vector<int64_t> g_src, g_dst;     // per job: source offset (corr / inlier ids), destination
+                std::vector<int32_t> g_cnt;
+                int64_t chunk_out = 0;
+                for (size_t jx = 0; jx < jobs.size(); ++jx) {
+                    const int k = job_pair[jx];
+                    osfm_pair_result &r = results[full_idx[start + k]];
+                    r.num_inliers = h_cnt[jx];
+                    if (h_cnt[jx] < min_inl) { r.status = OSFM_PAIR_REJECTED_INLIERS; r.offset = 0; continue; }
+                    r.offset = written_out + chunk_out;
+                    g_src.push_back(h_corr_off[k]); g_dst.push_back(chunk_out); g_cnt.push_back(h_cnt[jx]);
+                    chunk_out += h_cnt[jx];
+                }
+                if (written_out + chunk_out > capacity) overflow = true;
+                if (!overflow && chunk_out > 0) {
+                    const int ng = (int)g_cnt.size();
+                    OSFM_RETURN_IF(m->d_gather_off.reserve((size_t)ng * 20));
+                    OSFM_RETURN_IF(m->d_corr2.reserve((size_t)chunk_out * 8));
+                    char *gb = m->d_gather_off.as<char>();
+                    OSFM_HIP_CHECK(hipMemcpyAsync(gb, g_src.data(), (size_t)ng * 8, hipMemcpyHostToDevice, s));
+                    OSFM_HIP_CHECK(hipMemcpyAsync(gb + (size_t)ng * 8, g_dst.data(), (size_t)ng * 8, hipMemcpyHostToDevice, s));
+                    OSFM_HIP_CHECK(hipMemcpyAsync(gb + (size_t)ng * 16, g_cnt.data(), (size_t)ng * 4, hipMemcpyHostToDevice, s));
+                    launch_gather_inliers(ng, m->d_corr.as<int32_t>(), m->d_inl.as<int32_t>(),
+                        reinterpret_cast<const int64_t *>(gb), reinterpret_cast<const int64_t *>(gb + (size_t)ng * 8),
+                        reinterpret_cast<const int32_t *>(gb + (size_t)ng * 16), m->d_corr2.as<int32_t>(), s);
+                    OSFM_HIP_CHECK(hipGetLastError());
+                    OSFM_HIP_CHECK(hipMemcpyAsync(corr + 2 * written_out, m->d_corr2.ptr, (size_t)chunk_out * 8,
+                        hipMemcpyDeviceToHost, s));
+                    OSFM_HIP_CHECK(hipStreamSynchronize(s));
+                }
+                written_out += chunk_out;
             }
             written += chunk_corr;
         }
     }
+    if (o.geometric_verification) written = written_out;
     if (total) *total = written;
     if (overflow) {
         set_error("match_all: %lld correspondences need more than the given capacity %lld",

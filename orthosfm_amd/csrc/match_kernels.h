@@ -79,6 +79,9 @@ void launch_compact_pairs(int num_pairs, const int32_t *m12_all, const int64_t *
     const int32_t *len12, const int64_t *corr_off, const uint8_t *keep, int32_t *corr,
     hipStream_t s);
 
+void launch_gather_inliers(int num, const int32_t *corr, const int32_t *inl, const int64_t *src_off,
+    const int64_t *dst_off, const int32_t *counts, int32_t *out, hipStream_t s);
+
 void launch_prepare_sift(const uint16_t *src, int n, int npad, int8_t *dst,
     int32_t *corr, int8_t *dst_raw, int32_t *corr_raw, int32_t *range_err, hipStream_t s);
 void launch_gather_rows(const int8_t *src, const int32_t *corr, const int32_t *map, int n, int npad,

@@ -831,6 +831,29 @@ void launch_compact_pairs(int num_pairs, const int32_t *m12_all, const int64_t *
         corr_off, keep, corr);
 }
 
+// inlier correspondences of the verified pairs: dst[j] = corr[src + inl[src + j]]
+__global__ void
+gather_inliers_kernel(const int32_t *__restrict__ corr, const int32_t *__restrict__ inl,
+    const int64_t *__restrict__ src_off, const int64_t *__restrict__ dst_off,
+    const int32_t *__restrict__ counts, int32_t *__restrict__ out)
+{
+    const int g = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= counts[g]) return;
+    const int64_t so = src_off[g], d = dst_off[g];
+    const int id = inl[so + j];
+    out[2 * (d + j)] = corr[2 * (so + id)];
+    out[2 * (d + j) + 1] = corr[2 * (so + id) + 1];
+}
+
+void launch_gather_inliers(int num, const int32_t *corr, const int32_t *inl, const int64_t *src_off,
+    const int64_t *dst_off, const int32_t *counts, int32_t *out, hipStream_t s)
+{
+    if (num <= 0) return;
+    // counts are bounded by the features of a view
+    hipLaunchKernelGGL(gather_inliers_kernel, dim3(512, num), dim3(256), 0, s, corr, inl, src_off, dst_off, counts, out);
+}
+
 // ---------------------------------------------------------------------------
 // View preparation: 16-bit lanes -> int8 storage + per-descriptor correction.
 // ---------------------------------------------------------------------------

@@ -1,0 +1,265 @@
+// Geometric verification on the GPU: RANSAC over 8-point fundamental matrices
+// with Sampson-distance inliers, one workgroup per view pair
+// (sfm::RansacFundamental::estimate, src/mve/sfm/ransac_fundamental.cc:26-105;
+// fundamental_8_point / enforce_fundamental_constraints / sampson_distance,
+// src/mve/sfm/fundamental.cc:78-127,225-246), as called per pair from
+// bundler::Matching::two_view_matching (bundler_matching.cc:194-219).
+//
+// The reference draws samples from std::rand() shared between OpenMP threads,
+// so its inlier sets change from run to run; here sample d of iteration i of
+// pair p is splitmix64(seed, p, i, d): results are reproducible and independent
+// of how pairs are batched or sharded.  All arithmetic is double precision in
+// the operation order of the CPU oracle, so both agree bit for bit.
+#include "ransac_kernels.h"
+
+namespace osfm {
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ uint64_t ransac_rand(uint64_t seed, uint64_t pair, uint64_t it, uint64_t draw)
+{
+    return splitmix64(splitmix64(seed ^ (pair * 0xD1342543DE82EF95ull)) + it * 0x2545F4914F6CDD1Dull + draw);
+}
+
+// fundamental.cc:225-246
+__device__ __forceinline__ double
+sampson(const double *F, double x1, double y1, double x2, double y2)
+{
+    double n = 0.0;
+    n += x2 * (x1 * F[0] + y1 * F[1] + F[2]);
+    n += y2 * (x1 * F[3] + y1 * F[4] + F[5]);
+    n += 1.0 * (x1 * F[6] + y1 * F[7] + F[8]);
+    n *= n;
+    double sum = 0.0, t;
+    t = x1 * F[0] + y1 * F[1] + F[2]; sum += t * t;
+    t = x1 * F[3] + y1 * F[4] + F[5]; sum += t * t;
+    t = x2 * F[0] + y2 * F[3] + F[6]; sum += t * t;
+    t = x2 * F[1] + y2 * F[4] + F[7]; sum += t * t;
+    return n / sum;
+}
+
+__device__ void eig3_fixed(double A[3][3], double V[3][3], double w[3])
+{
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off == 0.0) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (A[p][q] == 0.0) continue;
+                const double th = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < 3; ++i) w[i] = A[i][i];
+}
+
+// 8-point fundamental matrix of one sample: null vector of the 8x9 system by
+// Gauss-Jordan elimination with full pivoting, then the rank-2 projection.
+__device__ bool
+eight_point(const double p1[8][2], const double p2[8][2], double F[9])
+{
+    double A[8][9];
+    for (int i = 0; i < 8; ++i) {
+        const double x1 = p1[i][0], y1 = p1[i][1], x2 = p2[i][0], y2 = p2[i][1];
+        A[i][0] = x2 * x1; A[i][1] = x2 * y1; A[i][2] = x2;
+        A[i][3] = y2 * x1; A[i][4] = y2 * y1; A[i][5] = y2;
+        A[i][6] = x1; A[i][7] = y1; A[i][8] = 1.0;
+    }
+    int colperm[9];
+    for (int c = 0; c < 9; ++c) colperm[c] = c;
+    for (int r = 0; r < 8; ++r) {
+        int pr = r, pc = r;
+        double best = -1.0;
+        for (int i = r; i < 8; ++i)
+            for (int j = r; j < 9; ++j) {
+                const double v = fabs(A[i][j]);
+                if (v > best) { best = v; pr = i; pc = j; }
+            }
+        if (!(best > 0.0)) { for (int i = 0; i < 9; ++i) F[i] = 0.0; return false; }
+        if (pr != r) for (int j = 0; j < 9; ++j) { const double t = A[r][j]; A[r][j] = A[pr][j]; A[pr][j] = t; }
+        if (pc != r) {
+            for (int i = 0; i < 8; ++i) { const double t = A[i][r]; A[i][r] = A[i][pc]; A[i][pc] = t; }
+            const int t = colperm[r]; colperm[r] = colperm[pc]; colperm[pc] = t;
+        }
+        const double inv = 1.0 / A[r][r];
+        for (int j = r; j < 9; ++j) A[r][j] *= inv;
+        for (int i = 0; i < 8; ++i) {
+            if (i == r) continue;
+            const double fct = A[i][r];
+            for (int j = r; j < 9; ++j) A[i][j] -= fct * A[r][j];
+        }
+    }
+    double f[9], n2 = 1.0;
+    for (int r = 0; r < 8; ++r) { f[colperm[r]] = -A[r][8]; n2 += A[r][8] * A[r][8]; }
+    f[colperm[8]] = 1.0;
+    const double invn = 1.0 / sqrt(n2);
+    for (int i = 0; i < 9; ++i) f[i] *= invn;
+    double M[3][3], V[3][3], w[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            M[i][j] = f[0 + i] * f[0 + j] + f[3 + i] * f[3 + j] + f[6 + i] * f[6 + j];
+    eig3_fixed(M, V, w);
+    int m = 0;
+    if (w[1] < w[m]) m = 1;
+    if (w[2] < w[m]) m = 2;
+    const double v3[3] = { V[0][m], V[1][m], V[2][m] };
+    for (int r = 0; r < 3; ++r) {
+        const double fv = f[3 * r] * v3[0] + f[3 * r + 1] * v3[1] + f[3 * r + 2] * v3[2];
+        for (int c = 0; c < 3; ++c) F[3 * r + c] = f[3 * r + c] - fv * v3[c];
+    }
+    return true;
+}
+
+constexpr int kHyp = 4;            // hypotheses per thread and pass
+constexpr int kChunk = 1024;       // matches staged in LDS at a time
+
+__global__ __launch_bounds__(256) void
+ransac_kernel(const RansacJob *__restrict__ jobs, int max_iterations, double thr2, uint64_t seed)
+{
+    __shared__ float mx1[kChunk], my1[kChunk], mx2[kChunk], my2[kChunk];
+    __shared__ int s_count[256], s_iter[256];
+    __shared__ double s_F[9];
+    __shared__ int s_wave[4], s_run;
+
+    const RansacJob job = jobs[blockIdx.x];
+    const int k = job.k, tid = threadIdx.x;
+    if (k < 8) {                      // the reference throws (ransac_fundamental.cc:66-67)
+        if (tid == 0) *job.count_out = -1;
+        return;
+    }
+    int best_count = 0, best_iter = 0x7fffffff;
+    double bestF[9];
+    for (int i = 0; i < 9; ++i) bestF[i] = 0.0;
+
+    for (int base = 0; base < max_iterations; base += 256 * kHyp) {
+        double F[kHyp][9];
+        bool valid[kHyp];
+        int cnt[kHyp];
+#pragma unroll
+        for (int h = 0; h < kHyp; ++h) {
+            const int it = base + h * 256 + tid;
+            valid[h] = false; cnt[h] = 0;
+            for (int i = 0; i < 9; ++i) F[h][i] = 0.0;
+            if (it >= max_iterations) continue;
+            // 8 distinct match ids, ascending (std::set order, :69-76)
+            int idx[8], n = 0;
+            for (uint64_t d = 0; n < 8; ++d) {
+                const int v = (int)(ransac_rand(seed, job.pair_id, (uint64_t)it, d) % (uint64_t)k);
+                bool dup = false;
+                for (int i = 0; i < n; ++i) dup |= idx[i] == v;
+                if (!dup) idx[n++] = v;
+            }
+            for (int i = 1; i < 8; ++i) {
+                const int v = idx[i];
+                int j = i - 1;
+                while (j >= 0 && idx[j] > v) { idx[j + 1] = idx[j]; --j; }
+                idx[j + 1] = v;
+            }
+            double p1[8][2], p2[8][2];
+            for (int i = 0; i < 8; ++i) {
+                const int a = job.corr[2 * idx[i]], b = job.corr[2 * idx[i] + 1];
+                p1[i][0] = job.pos1[2 * a]; p1[i][1] = job.pos1[2 * a + 1];
+                p2[i][0] = job.pos2[2 * b]; p2[i][1] = job.pos2[2 * b + 1];
+            }
+            valid[h] = eight_point(p1, p2, F[h]);
+        }
+        // inlier counts of this thread's hypotheses over all matches
+        for (int c0 = 0; c0 < k; c0 += kChunk) {
+            __syncthreads();
+            for (int i = tid; i < kChunk && c0 + i < k; i += 256) {
+                const int a = job.corr[2 * (c0 + i)], b = job.corr[2 * (c0 + i) + 1];
+                mx1[i] = job.pos1[2 * a]; my1[i] = job.pos1[2 * a + 1];
+                mx2[i] = job.pos2[2 * b]; my2[i] = job.pos2[2 * b + 1];
+            }
+            __syncthreads();
+            const int lim = min(kChunk, k - c0);
+            for (int i = 0; i < lim; ++i) {
+                const double x1 = mx1[i], y1 = my1[i], x2 = mx2[i], y2 = my2[i];
+#pragma unroll
+                for (int h = 0; h < kHyp; ++h)
+                    if (valid[h] && sampson(F[h], x1, y1, x2, y2) < thr2) cnt[h]++;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < kHyp; ++h) {
+            const int it = base + h * 256 + tid;
+            // strictly more inliers wins; equal counts keep the earlier iteration (:47)
+            if (valid[h] && (cnt[h] > best_count || (cnt[h] == best_count && cnt[h] > 0 && it < best_iter))) {
+                best_count = cnt[h]; best_iter = it;
+                for (int i = 0; i < 9; ++i) bestF[i] = F[h][i];
+            }
+        }
+    }
+    // block argmax: (count desc, iteration asc)
+    s_count[tid] = best_count; s_iter[tid] = best_iter;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (tid < st) {
+            const int c2 = s_count[tid + st], i2 = s_iter[tid + st];
+            if (c2 > s_count[tid] || (c2 == s_count[tid] && i2 < s_iter[tid])) { s_count[tid] = c2; s_iter[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    const int win_count = s_count[0], win_iter = s_iter[0];
+    if (best_count == win_count && best_iter == win_iter && win_count > 0)
+        for (int i = 0; i < 9; ++i) s_F[i] = bestF[i];
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    if (win_count == 0) {
+        if (tid == 0) { *job.count_out = 0; if (job.F_out) for (int i = 0; i < 9; ++i) job.F_out[i] = 0.0; }
+        return;
+    }
+    double Fw[9];
+    for (int i = 0; i < 9; ++i) Fw[i] = s_F[i];
+    if (tid == 0 && job.F_out) for (int i = 0; i < 9; ++i) job.F_out[i] = Fw[i];
+    // ordered list of the inlier ids of the winning hypothesis
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int c0 = 0; c0 < k; c0 += 256) {
+        const int i = c0 + tid;
+        bool in = false;
+        if (i < k) {
+            const int a = job.corr[2 * i], b = job.corr[2 * i + 1];
+            in = sampson(Fw, job.pos1[2 * a], job.pos1[2 * a + 1], job.pos2[2 * b], job.pos2[2 * b + 1]) < thr2;
+        }
+        const unsigned long long bal = __ballot(in);
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int off = s_run;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (in) job.inliers_out[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (tid == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (tid == 0) *job.count_out = s_run;
+}
+
+void launch_ransac(const RansacJob *d_jobs, int num_jobs, int max_iterations, double threshold,
+    uint64_t seed, hipStream_t s)
+{
+    if (num_jobs <= 0) return;
+    hipLaunchKernelGGL(ransac_kernel, dim3(num_jobs), dim3(256), 0, s, d_jobs, max_iterations,
+        threshold * threshold, seed);
+}
+
+}  // namespace osfm

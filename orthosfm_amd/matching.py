@@ -31,6 +31,7 @@ class TwoViewMatching:
     status: int = 0
     lowres_matches: int = -1
     num_matches: int = 0
+    num_inliers: int = -1
 
 
 class HipExhaustiveMatching:
@@ -66,6 +67,11 @@ class HipExhaustiveMatching:
         capi.check(capi.lib.osfm_match_set_view(
             self._h, view, capi._ptr(sift, C.c_uint16), sift.shape[0],
             capi._ptr(surf, C.c_int16), surf.shape[0]))
+
+    def set_positions(self, view, xy):
+        """FeatureSet::positions (normalised x, y per feature) for RANSAC-F."""
+        xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+        capi.check(capi.lib.osfm_match_set_positions(self._h, view, capi._ptr(xy, C.c_float), xy.shape[0]))
 
     def view_size(self, view):
         a, b = C.c_int(), C.c_int()
@@ -124,10 +130,27 @@ class HipExhaustiveMatching:
         out = []
         for k, (a, b) in enumerate(pairs):
             r = res[k]
-            m = (corr[r.offset:r.offset + r.num_matches].copy() if r.status == capi.PAIR_MATCHED
+            cnt = r.num_inliers if self.opts.geometric_verification else r.num_matches
+            m = (corr[r.offset:r.offset + cnt].copy() if r.status == capi.PAIR_MATCHED
                  else np.zeros((0, 2), np.int32))
-            out.append(TwoViewMatching(a, b, m, r.status, r.lowres_matches, r.num_matches))
+            out.append(TwoViewMatching(a, b, m, r.status, r.lowres_matches, r.num_matches, r.num_inliers))
         return out
+
+    @staticmethod
+    def ransac_fundamental(pos1, pos2, corr, max_iterations=1000, threshold=0.0015, seed=0, pair_id=0, device=0):
+        """sfm::RansacFundamental::estimate for one pair; returns (inlier ids, F)."""
+        pos1 = np.ascontiguousarray(pos1, dtype=np.float32).reshape(-1, 2)
+        pos2 = np.ascontiguousarray(pos2, dtype=np.float32).reshape(-1, 2)
+        corr = np.ascontiguousarray(corr, dtype=np.int32).reshape(-1, 2)
+        o = capi.RansacOptions(max_iterations, 0, threshold, seed)
+        inl = np.zeros(max(corr.shape[0], 1), dtype=np.int32)
+        n = C.c_int32()
+        F = np.zeros(9)
+        capi.check(capi.lib.osfm_ransac_fundamental(
+            device, capi._ptr(pos1, C.c_float), pos1.shape[0], capi._ptr(pos2, C.c_float), pos2.shape[0],
+            capi._ptr(corr, C.c_int32), corr.shape[0], C.byref(o), C.c_uint64(pair_id),
+            capi._ptr(inl, C.c_int32), C.byref(n), capi._ptr(F, C.c_double)))
+        return n.value, inl[:max(n.value, 0)].copy(), F.reshape(3, 3)
 
     def stats(self) -> capi.MatchStats:
         s = capi.MatchStats()
