@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the extra pass with RANSAC-F")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = auto (about 15 s of CPU work)")
+    ap.add_argument("--no-lowres-gate", action="store_true",
+                    help="kernel experiments only: match every pair in full whatever the results are")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsal)")
     return ap.parse_args()
 
@@ -161,7 +163,11 @@ def main():
     all_pairs = [capi.pair_from_index(i) for i in range(V * (V - 1) // 2)]
     my_pairs = D.shard_pairs(all_pairs, rank, world)
 
-    m = HipExhaustiveMatching(V, device=device_index)
+    o1 = capi.default_match_options()
+    if args.no_lowres_gate:
+        o1.use_lowres_matching = 0
+        o1.min_feature_matches = 0
+    m = HipExhaustiveMatching(V, device=device_index, options=o1, copy_results=False)
     t0 = time.perf_counter()
     for v in range(V):
         m.set_view(v, iset.sift[v])
@@ -207,7 +213,7 @@ def main():
     if not args.no_verify:
         o2 = capi.default_match_options()
         o2.geometric_verification = 1
-        m2 = HipExhaustiveMatching(V, device=device_index, options=o2)
+        m2 = HipExhaustiveMatching(V, device=device_index, options=o2, copy_results=False)
         for v in range(V):
             m2.set_view(v, iset.sift[v])
             xy = (iset.pos[v] + 0.5 - np.array([iset.width / 2, iset.height / 2])) / max(iset.width, iset.height)
@@ -255,7 +261,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_MFMA_PEAK_TOPS,
                          "unit": "TFLOP/s", "frac": achieved / I8_MFMA_PEAK_TOPS,
                          "traffic": pmc_traffic_per_launch(len(my_pairs) * args.steps / max(kern_launches, 1)),
-                         "kernel": "match_tile_kernel<8>", "launches_per_step": kern_launches / args.steps,
+                         "kernel": "match_tile_kernel<8, false>", "launches_per_step": kern_launches / args.steps,
                          "avg_launch_ms": avg_launch_s * 1e3,
                          "hbm_algorithmic_GBs": (st.algorithmic_bytes / max(st.tile_kernel_launches, 1))
                                                 / max(avg_launch_s, 1e-12) / 1e9},

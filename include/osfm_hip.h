@@ -180,11 +180,15 @@ OSFM_API int osfm_pair_from_index(int64_t index, int32_t *view_1, int32_t *view_
  * this matcher, for bench.py's live roofline: device time of the dominant
  * kernel (HIP events on the launch stream) and its launch count. */
 typedef struct osfm_match_stats {
-    double tile_kernel_ms;     /* sum over launches of the score-tile kernel */
+    double tile_kernel_ms;     /* sum over the full-matching launches of the score-tile kernel */
     int32_t tile_kernel_launches;
     int32_t exact_scan_queries;  /* queries re-done by the wrap-exact kernel */
-    int64_t mac_count;           /* sum of n1*n2*D over the launches */
+    int64_t mac_count;           /* sum of n1*n2*D over those launches */
     int64_t algorithmic_bytes;   /* descriptors read once + results written */
+    double lowres_kernel_ms;     /* same, launches of the low-res gate (limited variant) */
+    int32_t lowres_kernel_launches;
+    int32_t reserved;
+    int64_t lowres_mac_count;
 } osfm_match_stats;
 OSFM_API int osfm_match_get_stats(const osfm_matcher *m, osfm_match_stats *out);
 

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libosfm_hip.so")
+# OSFM_HIP_LIBRARY: another build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("OSFM_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libosfm_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -60,7 +61,9 @@ class PairResult(C.Structure):
 class MatchStats(C.Structure):
     _fields_ = [("tile_kernel_ms", C.c_double), ("tile_kernel_launches", C.c_int32),
                 ("exact_scan_queries", C.c_int32), ("mac_count", C.c_int64),
-                ("algorithmic_bytes", C.c_int64)]
+                ("algorithmic_bytes", C.c_int64), ("lowres_kernel_ms", C.c_double),
+                ("lowres_kernel_launches", C.c_int32), ("reserved", C.c_int32),
+                ("lowres_mac_count", C.c_int64)]
 
 
 class BaProblem(C.Structure):

@@ -314,12 +314,21 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
         if (!timed[type]) continue;
         float ms = 0.f;
         OSFM_HIP_CHECK(hipEventElapsedTime(&ms, m->ev[type][0], m->ev[type][1]));
-        m->stats.tile_kernel_ms += ms;
-        m->stats.tile_kernel_launches += 1;
+        if (mode.limit > 0) {
+            m->stats.lowres_kernel_ms += ms;
+            m->stats.lowres_kernel_launches += 1;
+        } else {
+            m->stats.tile_kernel_ms += ms;
+            m->stats.tile_kernel_launches += 1;
+        }
     }
     m->stats.exact_scan_queries += hexact[0] + hexact[1];
-    m->stats.mac_count += macs;
-    m->stats.algorithmic_bytes += alg_bytes;
+    if (mode.limit > 0) {
+        m->stats.lowres_mac_count += macs;
+    } else {
+        m->stats.mac_count += macs;
+        m->stats.algorithmic_bytes += alg_bytes;
+    }
     return OSFM_OK;
 }
 

@@ -24,7 +24,18 @@
 
 #include "match_kernels.h"
 
+#ifndef OSFM_EXP
+#define OSFM_EXP 0   // kernel-timing experiments (bit mask), 0 in product builds
+#endif
+
 namespace osfm {
+
+#if OSFM_EXP & 32
+__device__ unsigned long long g_prof[8];
+#define OSFM_STAMP(i) { unsigned long long now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)); pseg[i] += now_ - pprev; pprev = now_; }
+#else
+#define OSFM_STAMP(i)
+#endif
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -103,15 +114,23 @@ __device__ __forceinline__ void top2_quad(int &b, int &s, int x0, int x1, int x2
 //   * scores are first reduced to GROUP bests with v_max3 (0.5 op / score):
 //     row direction  - a (lane, register) slot sees 2 columns per tile; a group
 //                      is kGroupTiles tiles = 16 columns of that slot;
-//     column direction - a lane sees 32 rows of a column per tile; a group is
-//                      the 8 rows of half an accumulator fragment;
+//     column direction - a lane sees 32 rows of a column per tile (both row
+//                      fragments of its half-wave): that is the group;
 //   * only group bests enter the exact (best, second) update (v_med3 + v_max).
 // Hence best / index are exact, while "second" is the second largest GROUP
 // best: the true second largest can only be larger if it sits in the same
 // group as the best.  The finish kernel closes that gap exactly: a query that
 // passes the ratio test against this lower bound gets its best group (16
-// columns / 8 rows) re-scored and re-tested; one that fails it is rejected for
+// columns / 32 rows) re-scored and re-tested; one that fails it is rejected for
 // good (the test is monotone in the second-best value).
+//
+// Software pipeline: the wave's 64 x 64 tile is produced and consumed in two
+// PHASES of one 32-row fragment (x both 32-column fragments) each.  While the
+// VALU reduces the accumulators of one phase, the MFMAs of the next phase are
+// already in flight into the other accumulator pair: every epilogue chunk is
+// preceded by exactly one MFMA (fenced with sched_barrier so the order
+// survives the compiler), so matrix and vector pipes overlap inside one wave
+// instead of relying on the other resident wave to fill the gaps.
 //
 // MASKED = false: rows >= n1 / columns >= n2 are PADDING descriptors whose
 // stored bytes and corrections make their inner products come out at
@@ -121,6 +140,8 @@ __device__ __forceinline__ void top2_quad(int &b, int &s, int x0, int x1, int x2
 // per-element masks.
 constexpr int kGroupTiles = 8;          // tiles per row-direction group (16 columns per slot)
 constexpr int kValNone = -(1 << 28);    // "no candidate" for un-keyed column scores
+
+template <int V> struct IntC { static constexpr int value = V; };
 
 // RAW = true: row operand in raw form (see MatchProblem): the accumulator IS
 // the inner product, no key is built per score in either direction (group keys
@@ -140,16 +161,25 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
     constexpr int CPT = CHUNKS / 256;             // chunks per thread (2 or 1)
     constexpr int BBUF_BYTES = 2 * TILE_BYTES > 16384 ? 2 * TILE_BYTES : 16384;
     constexpr int kCurNone = RAW ? -(1 << 26) : kKeyNone;   // (-2^26 << 4) == kKeyNone
+    constexpr int NCHUNK = 2 * KS;        // MFMAs (= epilogue chunks) per phase
+    constexpr int RPC = 16 / NCHUNK;      // row-direction registers per chunk
+    constexpr int CPC = 16 / KS;          // column-direction registers per chunk
 
     char *bbuf = smem;                                              // [2][TILE_BYTES] (>= 16 KB)
     int *corrbuf = reinterpret_cast<int *>(smem + BBUF_BYTES);      // [2][64]
-    ColPart *colbuf = reinterpret_cast<ColPart *>(smem + BBUF_BYTES + 2 * 64 * 4);  // [2][4][64]
-    int *rsecbuf = reinterpret_cast<int *>(smem + BBUF_BYTES + 2 * 64 * 4 + 2 * 4 * 64 * 8);  // [32][256]
+    ColPart *colbuf = reinterpret_cast<ColPart *>(smem + BBUF_BYTES + 2 * 64 * 4);  // [8 tiles][4 waves][64]
+    int *rsecbuf = reinterpret_cast<int *>(smem + BBUF_BYTES + 2 * 64 * 4 + 8 * 4 * 64 * 8);  // [32][256]
 
-    const int n1 = pd.n1, n2 = pd.n2;
+    // problem fields used inside the tile loop, read once (the loop's LDS
+    // traffic would otherwise force scalar re-loads and lgkmcnt(0) waits)
+    const int n1 = pd.n1, n2 = pd.n2, n2stride = pd.n2stride;
+    const int8_t *const Bbase = pd.B;
+    const int32_t *const corrBbase = pd.corrB;
+    ColPart *const colout = colparts + pd.colpart_off + (int64_t)rb * pd.n2stride;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     const int row0 = rb * kRowsPerBlock + wave * 64;      // row slot (partials, validity)
+    const int gcode = wave * 2 + lh;                      // column-direction group of this lane
 
     // --- resident A fragments and row corrections -------------------------
     const int8_t *Abase = pd.A;
@@ -204,7 +234,7 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
     auto stage_tile = [&](int t, int buf) {
-        const int8_t *src = pd.B + (size_t)(col_begin + t * kTileCols) * D;
+        const int8_t *src = Bbase + (size_t)(col_begin + t * kTileCols) * D;
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
             const int q0 = (c * 4 + wave) * 64;           // first chunk of this wave-instruction
@@ -217,151 +247,210 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
         }
         if (!RAW && wave == 0)
             __builtin_amdgcn_global_load_lds(
-                (glb_void *)(pd.corrB + col_begin + t * kTileCols + lane),
+                (glb_void *)(corrBbase + col_begin + t * kTileCols + lane),
                 (lds_void *)(uintptr_t)(corrbuf + buf * 64), 4, 0, 0);
     };
 
-    stage_tile(0, 0);
-    __syncthreads();
+    // B fragments (and column corrections) of one 32-column group, LDS -> registers
+    v4i b[2][KS];
+    int cb_next[2] = {0, 0};
+    auto load_b = [&](int buf, int cf) {
+        const int col = cf * 32 + lr;
+        const int swz = (col / RPB) % CH;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            b[cf][ks] = *reinterpret_cast<const v4i *>(
+                bbuf + buf * TILE_BYTES + col * D + (((ks * 2 + lh) ^ swz) * 16));
+        if (!RAW) cb_next[cf] = corrbuf[buf * 64 + col];
+    };
 
+    // per-tile epilogue inputs (set at the top of each iteration)
+    int cbj[2] = {0, 0}, cjt[2] = {0, 0};
+    bool col_valid[2] = {true, true};
+    int g[2] = {kValNone, kValNone};      // column direction: best of this lane's 32 rows
+
+    v16i acc0[2], acc1[2];                // accumulators of row fragment 0 / 1 (x 2 column groups)
+
+    // One phase: reduce the finished accumulators `cur` (row fragment PH) while
+    // the MFMAs of the other fragment are issued into `nxt`, one per chunk.
+    auto phase = [&](auto ph_c, v16i (&cur)[2], v16i (&nxt)[2], int buf_next) {
+        constexpr int PH = decltype(ph_c)::value;
+#pragma unroll
+        for (int i = 0; i < NCHUNK; ++i) {
+            const int cf = i / KS, ks = i % KS;
+            if (ks == 0)
+                nxt[cf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[PH ^ 1][0], b[cf][0], ra[PH ^ 1], 0, 0, 0);
+            else
+                nxt[cf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[PH ^ 1][ks], b[cf][ks], nxt[cf], 0, 0, 0);
+            // The B registers of a column group are free once phase 0 (second half
+            // of tile t) has issued that group's chain; they take the fragments of
+            // tile t+1.  Group 0 is fetched right there, group 1 behind the first
+            // MFMA of phase 1, so that the LDS wait in front of phase 1 (the compiler
+            // drains the whole counter) never covers reads issued a moment ago.
+            if (PH == 0 && i == KS - 1) load_b(buf_next, 0);
+            if (PH == 1 && i == 0) {
+                __builtin_amdgcn_sched_barrier(0);      // keep the reads behind the MFMA
+                load_b(buf_next, 1);
+            }
+
+            // row direction: the two column groups feed the same (lane, reg) slot
+#pragma unroll
+            for (int r = i * RPC; r < (i + 1) * RPC; ++r) {
+                if (RAW) {
+                    rcur[PH][r] = max(max(rcur[PH][r], cur[0][r]), cur[1][r]);
+                } else {
+                    int k0 = (int)(((unsigned)cur[0][r] << 8) + (unsigned)cjt[0]);
+                    int k1 = (int)(((unsigned)cur[1][r] << 8) + (unsigned)cjt[1]);
+                    if (MASKED) {
+                        k0 = col_valid[0] ? k0 : kKeyNone;
+                        k1 = col_valid[1] ? k1 : kKeyNone;
+                    }
+                    rcur[PH][r] = max3i(rcur[PH][r], k0, k1);
+                }
+            }
+            // column direction: un-keyed scores of column group cf, CPC registers
+            {
+                int x[CPC];
+#pragma unroll
+                for (int j = 0; j < CPC; ++j) {
+                    x[j] = cur[cf][ks * CPC + j];
+                    if (MASKED) x[j] = ((row_valid_bits >> (PH * 16 + ks * CPC + j)) & 1u) ? x[j] : kValNone;
+                }
+                int gg;
+                if (PH == 0 && ks == 0) gg = max(x[0], x[1]);
+                else gg = max(max(g[cf], x[0]), x[1]);
+#pragma unroll
+                for (int j = 2; j < CPC; j += 2) gg = max(max(gg, x[j]), x[j + 1]);
+                // pinned here: the optimiser would otherwise sink the whole chain to its
+                // only use after the loop body, keeping both accumulator pairs alive
+                asm volatile("" : "+v"(gg));
+                g[cf] = gg;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // --- prologue: tiles 0 and 1 into LDS, fragments of tile 0, first half of tile 0
+    stage_tile(0, 0);
+    stage_tile(ntiles > 1 ? 1 : 0, 1);
+    __syncthreads();
+    load_b(0, 0);
+    load_b(0, 1);
+#pragma unroll
+    for (int cf = 0; cf < 2; ++cf) {
+        acc0[cf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][0], b[cf][0], ra[0], 0, 0, 0);
+#pragma unroll
+        for (int ks = 1; ks < KS; ++ks)
+            acc0[cf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][ks], b[cf][ks], acc0[cf], 0, 0, 0);
+    }
+    __syncthreads();        // every wave holds tile 0 in registers: its LDS buffer may be refilled
+
+#if OSFM_EXP & 32
+    unsigned long long pseg[6] = {0, 0, 0, 0, 0, 0}, pprev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pprev));
+#endif
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
-        if (t + 1 < ntiles) stage_tile(t + 1, buf ^ 1);
-
-        // B fragments of the tile: 2 column groups x KS k-steps
-        v4i b[2][KS];
-        int cbj[2] = {0, 0}, cjt[2] = {0, 0};
-        bool col_valid[2];
+        // tile t+2 into the buffer tile t was read from (clamped: the extra
+        // refills of the last tile are never consumed)
+        if (!(OSFM_EXP & 1)) stage_tile(min(t + 2, ntiles - 1), buf);
 #pragma unroll
         for (int cf = 0; cf < 2; ++cf) {
-            const int col = cf * 32 + lr;
-            const int swz = (col / RPB) % CH;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                b[cf][ks] = *reinterpret_cast<const v4i *>(
-                    bbuf + buf * TILE_BYTES + col * D + (((ks * 2 + lh) ^ swz) * 16));
             if (!RAW) {
-                cbj[cf] = corrbuf[buf * 64 + col];
+                cbj[cf] = cb_next[cf];
                 cjt[cf] = (int)(((unsigned)cbj[cf] << 8) + (unsigned)(t * 2 + cf));
                 // opaque to the optimiser: otherwise it re-associates the key into
                 // ((acc + cb) << 8) + t, two ops per element instead of one v_lshl_add_u32
                 asm volatile("" : "+v"(cjt[cf]));
             }
-            col_valid[cf] = (col_begin + t * kTileCols + col) < n2;
+            col_valid[cf] = (col_begin + t * kTileCols + cf * 32 + lr) < n2;
         }
 
-        int cb[2] = {kKeyNone, kKeyNone}, cs[2] = {kKeyNone, kKeyNone};
-#pragma unroll
-        for (int rf = 0; rf < 2; ++rf) {
-            v16i acc[2];
-#pragma unroll
-            for (int cf = 0; cf < 2; ++cf) {
-                acc[cf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rf][0], b[cf][0], ra[rf], 0, 0, 0);
-#pragma unroll
-                for (int ks = 1; ks < KS; ++ks)
-                    acc[cf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[rf][ks], b[cf][ks], acc[cf], 0, 0, 0);
-            }
-            // row direction: the two column groups feed the same (lane, reg) slot
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int k0, k1;
-                if (RAW) {
-                    // plain C++ (not the asm max3): these are the first readers of
-                    // the MFMA results and must stay visible to the hazard recogniser
-                    k0 = acc[0][r];
-                    k1 = acc[1][r];
-                    rcur[rf][r] = max(max(rcur[rf][r], k0), k1);
-                } else {
-                    k0 = (int)(((unsigned)acc[0][r] << 8) + (unsigned)cjt[0]);
-                    k1 = (int)(((unsigned)acc[1][r] << 8) + (unsigned)cjt[1]);
-                    if (MASKED) {
-                        k0 = col_valid[0] ? k0 : kKeyNone;
-                        k1 = col_valid[1] ? k1 : kKeyNone;
-                    }
-                    rcur[rf][r] = max3i(rcur[rf][r], k0, k1);
-                }
-            }
-            // column direction: un-keyed scores, groups of 8 rows (half a fragment)
-#pragma unroll
-            for (int cf = 0; cf < 2; ++cf) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    int x[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        x[i] = acc[cf][h * 8 + i];
-                        if (MASKED) x[i] = ((row_valid_bits >> (rf * 16 + h * 8 + i)) & 1u) ? x[i] : kValNone;
-                    }
-                    int g = max(x[0], x[1]);
-                    g = max3i(g, x[2], x[3]);
-                    g = max3i(g, x[4], x[5]);
-                    g = max3i(g, x[6], x[7]);
-                    const int gk = (int)(((unsigned)g << 2) | (unsigned)(rf * 2 + h));
-                    cs[cf] = med3a(cb[cf], cs[cf], gk);
-                    cb[cf] = max(cb[cf], gk);
-                }
-            }
-        }
+        phase(IntC<0>(), acc0, acc1, buf ^ 1);   // reduce (rf 0, t), produce (rf 1, t), fetch B(t+1)
+        phase(IntC<1>(), acc1, acc0, buf ^ 1);   // reduce (rf 1, t), produce (rf 0, t+1)
 
         // close a row-direction group: fold the group bests into (best, second)
-        if ((t % kGroupTiles) == kGroupTiles - 1 || t == ntiles - 1) {
+        if (!(OSFM_EXP & 2) && ((t % kGroupTiles) == kGroupTiles - 1 || t == ntiles - 1)) {
             const int gidx = t / kGroupTiles;
+            // all LDS reads first (one exposed latency instead of 32): the
+            // accumulator pair consumed by phase 1 is dead here and lends its registers
+            int sv[2][16];
+#pragma unroll
+            for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sv[rf][r] = rsecbuf[(rf * 16 + r) * 256 + tid];
 #pragma unroll
             for (int rf = 0; rf < 2; ++rf)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    int *sp = rsecbuf + (rf * 16 + r) * 256 + tid;
                     const int gk = RAW ? (int)(((unsigned)rcur[rf][r] << 4) | (unsigned)gidx) : rcur[rf][r];
-                    *sp = med3a(rbest[rf][r], *sp, gk);
+                    rsecbuf[(rf * 16 + r) * 256 + tid] = med3a(rbest[rf][r], sv[rf][r], gk);
                     rbest[rf][r] = max(rbest[rf][r], gk);
                     rcur[rf][r] = kCurNone;
                 }
         }
 
-        // column direction: lane-local keys -> (ip << 8 | group code), merge the
-        // two half-waves (same column, other rows), hand to LDS.
-        // group code = wave * 8 + half-wave * 4 + (fragment * 2 + register half)
-        int kb[2], ksd[2];
+        // column direction: this lane's group best as (ip << 8 | group code); the two
+        // half-waves of a column are exchanged with one v_permlane32_swap so that
+        // lane == column within the tile, then the wave's (best, second) goes to LDS.
+        // group code = wave * 2 + half-wave (32 rows: both fragments of the half-wave)
+        if (!(OSFM_EXP & 16)) {
+            int kk[2];
 #pragma unroll
-        for (int cf = 0; cf < 2; ++cf) {
-            const int code = wave * 8 + lh * 4 + (cb[cf] & 3);
-            int k1 = (int)((unsigned)((cb[cf] >> 2) + cbj[cf]) << 8) | code;
-            int k2 = (int)((unsigned)((cs[cf] >> 2) + cbj[cf]) << 8);
-            k1 = cb[cf] < -(1 << 29) ? kKeyNone : k1;      // no valid row in this lane
-            k2 = cs[cf] < -(1 << 29) ? kKeyNone : k2;
-            const int o1 = __shfl_xor(k1, 32);
-            const int o2 = __shfl_xor(k2, 32);
-            kb[cf] = max(k1, o1);
-            ksd[cf] = max(min(k1, o1), max(k2, o2));
-        }
-        {
+            for (int cf = 0; cf < 2; ++cf) {
+                kk[cf] = (int)((unsigned)(g[cf] + cbj[cf]) << 8) | gcode;
+                if (MASKED) kk[cf] = g[cf] < -(1 << 27) ? kKeyNone : kk[cf];   // no valid row in this lane
+            }
+            const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)kk[0], (unsigned)kk[1], false, false);
+            const int x0 = (int)sw[0], x1 = (int)sw[1];
             ColPart cp;
-            cp.key_best = lh ? kb[1] : kb[0];
-            cp.key_second = lh ? ksd[1] : ksd[0];
-            colbuf[(buf * 4 + wave) * 64 + lane] = cp;   // lane == column within tile
+            cp.key_best = max(x0, x1);
+            cp.key_second = min(x0, x1);
+            colbuf[((t & 7) * 4 + wave) * 64 + lane] = cp;
         }
 
-        __syncthreads();
+        if (OSFM_EXP & 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (OSFM_EXP & 32) {
+            OSFM_STAMP(0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            OSFM_STAMP(1)
+            __syncthreads();
+            OSFM_STAMP(2)
+        }
+        else __syncthreads();
 
-        // one wave per tile (round robin) merges the four wave partials
-        if (wave == (t & 3)) {
-            int k1 = kKeyNone, k2 = kKeyNone;
+        // every fourth tile all four waves merge one tile each of the last batch
+        // (the same work in every wave: nobody is waited for at the next barrier)
+        if (!(OSFM_EXP & 4) && ((t & 3) == 3 || t == ntiles - 1)) {
+            const int tm = (t & ~3) + wave;
+            if (tm <= t) {
+                int k1 = kKeyNone, k2 = kKeyNone;
+                ColPart cp[4];
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const ColPart cp = colbuf[(buf * 4 + w) * 64 + lane];
-                k2 = max(min(k1, cp.key_best), max(k2, cp.key_second));
-                k1 = max(k1, cp.key_best);
-            }
-            const int col = col_begin + t * kTileCols + lane;
-            if (col < pd.n2stride) {
-                ColPart out;
-                out.key_best = k1;
-                out.key_second = k2;
-                colparts[pd.colpart_off + (int64_t)rb * pd.n2stride + col] = out;
+                for (int w = 0; w < 4; ++w) cp[w] = colbuf[((tm & 7) * 4 + w) * 64 + lane];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    k2 = max(max(min(k1, cp[w].key_best), k2), cp[w].key_second);
+                    k1 = max(k1, cp[w].key_best);
+                }
+                const int col = col_begin + tm * kTileCols + lane;
+                if (col < n2stride) {
+                    ColPart out;
+                    out.key_best = k1;
+                    out.key_second = k2;
+                    colout[col] = out;
+                }
             }
         }
+        OSFM_STAMP(3)
     }
 
+#if OSFM_EXP & 32
+    if (lane == 0 && (blockIdx.x & 255) == 77) {
+        atomicAdd(&g_prof[0], pseg[0]); atomicAdd(&g_prof[1], pseg[1]); atomicAdd(&g_prof[2], pseg[2]);
+        atomicAdd(&g_prof[3], pseg[3]); atomicAdd(&g_prof[4], (unsigned long long)ntiles);
+    }
+#endif
     // --- row direction: merge the 32 lanes that hold the same row -------------
     // Through LDS (the tile buffers are free now): each of 32 threads per wave
     // walks the 32 source lanes of one row.  (ip, column) composites keep
@@ -422,12 +511,19 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
         tile_body<CH, MASKED, false>(pd, rb, seg, rowparts, colparts, smem);
 }
 
+#if OSFM_EXP & 32
+extern "C" __attribute__((visibility("default"))) int osfm_debug_read_prof(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 8);
+}
+#endif
+
 void launch_match_tiles(int ch, bool masked, const MatchProblem *d_problems, int num_problems,
     int total_blocks, RowPart *rowparts, ColPart *colparts, hipStream_t s)
 {
     if (total_blocks <= 0) return;
     const int d = ch * 16;
-    const size_t lds = std::max<size_t>(2 * (size_t)kTileCols * d, 16384) + 2 * 64 * 4 + 2 * 4 * 64 * sizeof(ColPart) + 32 * 256 * 4;
+    const size_t lds = std::max<size_t>(2 * (size_t)kTileCols * d, 16384) + 2 * 64 * 4 + 8 * 4 * 64 * sizeof(ColPart) + 32 * 256 * 4;
     const dim3 grid(total_blocks), block(256);
     if (ch == 8 && !masked)
         hipLaunchKernelGGL((match_tile_kernel<8, false>), grid, block, lds, s, d_problems, num_problems, total_blocks, rowparts, colparts);
@@ -500,7 +596,7 @@ __device__ __forceinline__ int exact_ip(const int8_t *q, const int8_t *c)
 // Re-scores the group that produced the best match and returns the exact
 // (best index, second-best value) of the query.
 //   dir 0: query = row q, group = 16 columns of one (lane, tile-group) stream
-//   dir 1: query = column q, group = 8 rows of one (wave, half-wave, fragment half)
+//   dir 1: query = column q, group = 32 rows of one (wave, half-wave)
 template <int DIM, bool SIGNED>
 __device__ void
 rescan_group(const MatchProblem &pd, int dir, int q, int ip1, int idx1, int code, int m_other,
@@ -522,10 +618,10 @@ rescan_group(const MatchProblem &pd, int dir, int q, int ip1, int idx1, int code
     } else {
         const int8_t *qrow = pd.B + (size_t)q * DIM;
         const int rb = idx1;   // row block of the winning group
-        const int wave = code >> 3, lh = (code >> 2) & 1, gid = code & 3;
-        for (int i = 0; i < 8; ++i) {
-            const int r = (gid & 1) * 8 + i;
-            int row = rb * kRowsPerBlock + wave * 64 + (gid >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int wave = code >> 1, lh = code & 1;
+        for (int i = 0; i < 32; ++i) {
+            const int r = i & 15;
+            int row = rb * kRowsPerBlock + wave * 64 + (i >> 4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (rb >= pd.nrb_main) {
                 // a block of gathered special rows: back to the original row
                 const int sidx = row - pd.nrb_main * kRowsPerBlock;

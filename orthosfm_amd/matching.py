@@ -38,8 +38,13 @@ class HipExhaustiveMatching:
     """Drop-in for sfm::ExhaustiveMatching (src/mve/sfm/exhaustive_matching.h:26-66)
     backed by the gfx950 kernels."""
 
-    def __init__(self, num_views: int, device: int = 0, options: capi.MatchOptions | None = None):
+    def __init__(self, num_views: int, device: int = 0, options: capi.MatchOptions | None = None,
+                 copy_results: bool = True):
+        """copy_results=False: the lists compute() returns are views into a buffer
+        the matcher reuses -- valid until the next compute() (no second pass over
+        the results on the host)."""
         self.opts = options if options is not None else capi.default_match_options()
+        self._copy_results = bool(copy_results)
         self._h = C.c_void_p()
         capi.check(capi.lib.osfm_match_create(device, num_views, C.byref(self.opts), C.byref(self._h)))
         self.num_views = num_views
@@ -118,22 +123,32 @@ class HipExhaustiveMatching:
             pairs = [capi.pair_from_index(i) for i in range(self.num_views * (self.num_views - 1) // 2)]
         n = len(pairs)
         arr = (capi.Pair * max(n, 1))()
-        for k, (a, b) in enumerate(pairs):
-            arr[k].view_1, arr[k].view_2 = a, b
+        flat = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
+        if n:
+            np.ctypeslib.as_array(C.cast(arr, C.POINTER(C.c_int32)), shape=(n, 2))[:] = flat
         res = (capi.PairResult * max(n, 1))()
         if capacity is None:
             capacity = sum(min(sum(self.view_size(a)), sum(self.view_size(b))) for a, b in pairs)
-        corr = np.zeros((max(capacity, 1), 2), dtype=np.int32)
+        # One result buffer per call, taken from a pool the matcher keeps (its pages
+        # stay mapped, so the device-to-host copy does not fault them in again);
+        # the per-pair lists are views into it.
+        corr = self._take_buffer(max(capacity, 1))
         total = C.c_int64()
         capi.check(capi.lib.osfm_match_all(self._h, arr, n, res, capi._ptr(corr, C.c_int32),
                                            C.c_int64(capacity), C.byref(total)))
+        corr = corr[:max(int(total.value), 0)].copy() if self._copy_results else corr
+        empty = np.zeros((0, 2), np.int32)
+        verify = bool(self.opts.geometric_verification)
         out = []
-        for k, (a, b) in enumerate(pairs):
+        for k in range(n):
             r = res[k]
-            cnt = r.num_inliers if self.opts.geometric_verification else r.num_matches
-            m = (corr[r.offset:r.offset + cnt].copy() if r.status == capi.PAIR_MATCHED
-                 else np.zeros((0, 2), np.int32))
-            out.append(TwoViewMatching(a, b, m, r.status, r.lowres_matches, r.num_matches, r.num_inliers))
+            if r.status == capi.PAIR_MATCHED:
+                cnt = r.num_inliers if verify else r.num_matches
+                m = corr[r.offset:r.offset + cnt]
+            else:
+                m = empty
+            out.append(TwoViewMatching(int(flat[k, 0]), int(flat[k, 1]), m, r.status, r.lowres_matches,
+                                       r.num_matches, r.num_inliers))
         return out
 
     @staticmethod
@@ -151,6 +166,13 @@ class HipExhaustiveMatching:
             capi._ptr(corr, C.c_int32), corr.shape[0], C.byref(o), C.c_uint64(pair_id),
             capi._ptr(inl, C.c_int32), C.byref(n), capi._ptr(F, C.c_double)))
         return n.value, inl[:max(n.value, 0)].copy(), F.reshape(3, 3)
+
+    def _take_buffer(self, rows):
+        buf = getattr(self, "_corr_buf", None)
+        if buf is None or buf.shape[0] < rows:
+            buf = np.empty((rows, 2), dtype=np.int32)
+            self._corr_buf = buf
+        return buf[:rows]
 
     def stats(self) -> capi.MatchStats:
         s = capi.MatchStats()
