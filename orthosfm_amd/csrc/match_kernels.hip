@@ -593,55 +593,125 @@ __device__ __forceinline__ int exact_ip(const int8_t *q, const int8_t *c)
     return SIGNED ? acc : acc + 128 * (sq + sc) + 128 * 128 * DIM;
 }
 
-// Re-scores the group that produced the best match and returns the exact
-// (best index, second-best value) of the query.
-//   dir 0: query = row q, group = 16 columns of one (lane, tile-group) stream
-//   dir 1: query = column q, group = 32 rows of one (wave, half-wave)
-template <int DIM, bool SIGNED>
-__device__ void
-rescan_group(const MatchProblem &pd, int dir, int q, int ip1, int idx1, int code, int m_other,
-    int *idx_out, int *best_out, int *second_out)
+// DPP helpers: data movement inside the wave without LDS traffic.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_mov(int v, int old)
 {
-    int best = INT_MIN, best_idx = 0, second = INT_MIN;
-    if (dir == 0) {
-        const int8_t *qrow = pd.A + (size_t)q * DIM;
-        const int seg = idx1 / kSegCols, off = idx1 - seg * kSegCols;
-        const int lr = off & 31, tile = (off >> 5) >> 1, g = tile / kGroupTiles;
-        for (int u = 0; u < kGroupTiles; ++u)
-            for (int cf = 0; cf < 2; ++cf) {
-                const int col = seg * kSegCols + (g * kGroupTiles + u) * kTileCols + cf * 32 + lr;
-                if (col >= pd.n2) continue;
-                const int v = exact_ip<DIM, SIGNED>(qrow, pd.B + (size_t)col * DIM);
-                if (v >= best) { second = best; best = v; best_idx = col; }   // later index wins ties
-                else if (v > second) second = v;
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false);
+}
+constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // lane i <-> 7 - i inside 8 lanes
+constexpr int kDppMirror = 0x140;      // lane i <-> 15 - i inside a row of 16
+constexpr int kDppBcast15 = 0x142;     // lane 15 of a row -> the next row
+constexpr int kDppBcast31 = 0x143;     // lane 31 -> rows 2 and 3
+
+// maximum over the 64 lanes, returned uniformly
+__device__ __forceinline__ int wave_max(int v)
+{
+    v = max(v, dpp_mov<kDppXor1>(v, INT_MIN));
+    v = max(v, dpp_mov<kDppXor2>(v, INT_MIN));
+    v = max(v, dpp_mov<kDppHalfMirror>(v, INT_MIN));
+    v = max(v, dpp_mov<kDppMirror>(v, INT_MIN));
+    v = max(v, dpp_mov<kDppBcast15, 0xa>(v, INT_MIN));
+    v = max(v, dpp_mov<kDppBcast31, 0xc>(v, INT_MIN));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Re-scores the groups that produced the best matches of TWO queries with the
+// whole wave (the two independent chains hide each other's load latency; all
+// loads of both are issued before the first use) and returns, uniformly, the
+// exact best index / value and the exact second-best value of each group.
+//   DIR 0: query = row q, group = 16 columns of one (lane, tile-group) stream
+//   DIR 1: query = column q, group = 32 rows of one (wave, half-wave)
+// Each candidate descriptor is read by DIM/16 neighbouring lanes, 16 bytes each
+// (full cache lines per wave instruction -- one candidate per lane would touch
+// 64 lines for the same bytes); v_dot4 partial sums are folded with DPP adds.
+// Exact inner product = sum of stored bytes products + both corrections
+// (SIFT bytes hold value - 128, see prepare_sift_kernel; SURF corrections are 0).
+template <int DIM, int DIR>
+__device__ __forceinline__ void
+rescan_groups(const MatchProblem &pd, const int (&q)[2], const int (&idx1)[2], const int (&code)[2],
+    int lane, int (&idx_out)[2], int (&best_out)[2], int (&second_out)[2])
+{
+    constexpr int LPC = DIM / 16;       // lanes per candidate (8: SIFT, 4: SURF)
+    constexpr int CPL = 64 / LPC;       // candidates per wave-wide load
+    constexpr int NCAND = DIR == 0 ? 2 * kGroupTiles : 32;
+    constexpr int J = NCAND / CPL;      // wave-wide loads per query
+    const int c = lane % LPC, k = lane / LPC;
+    const int8_t *Q = DIR == 0 ? pd.A : pd.B;
+    const int8_t *Cm = DIR == 0 ? pd.B : pd.A;
+    const int32_t *corrQ = DIR == 0 ? pd.corrA : pd.corrB;
+    const int32_t *corrC = DIR == 0 ? pd.corrB : pd.corrA;
+
+    int cand[2][J], corr_c[2][J], corr_q[2];
+    int4 qv[2], cv[2][J];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        qv[u] = *reinterpret_cast<const int4 *>(Q + (size_t)q[u] * DIM + c * 16);
+        corr_q[u] = corrQ[q[u]];
+        int base0 = 0, lr = 0, rbase = 0, lh = 0;
+        if (DIR == 0) {
+            // first column of the group's first tile, lane slot inside the tiles
+            const int seg = idx1[u] / kSegCols, off = idx1[u] - seg * kSegCols;
+            lr = off & 31;
+            base0 = seg * kSegCols + ((off >> 6) / kGroupTiles) * kGroupTiles * kTileCols;
+        } else {
+            // first row of the wave's 64-row strip, half-wave
+            rbase = idx1[u] * kRowsPerBlock + (code[u] >> 1) * 64;
+            lh = code[u] & 1;
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int n = j * CPL + k;
+            int cd;
+            if (DIR == 0) {
+                cd = base0 + (n >> 1) * kTileCols + (n & 1) * 32 + lr;
+                if (cd >= pd.n2) cd = -1;
+            } else {
+                const int r = n & 15;
+                cd = rbase + (n >> 4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (idx1[u] >= pd.nrb_main) {
+                    // a block of gathered special rows: back to the original row
+                    const int sidx = cd - pd.nrb_main * kRowsPerBlock;
+                    cd = sidx < pd.n_special ? pd.special_map[sidx] : -1;
+                } else if (cd >= pd.n1) cd = -1;
             }
-    } else {
-        const int8_t *qrow = pd.B + (size_t)q * DIM;
-        const int rb = idx1;   // row block of the winning group
-        const int wave = code >> 1, lh = code & 1;
-        for (int i = 0; i < 32; ++i) {
-            const int r = i & 15;
-            int row = rb * kRowsPerBlock + wave * 64 + (i >> 4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (rb >= pd.nrb_main) {
-                // a block of gathered special rows: back to the original row
-                const int sidx = row - pd.nrb_main * kRowsPerBlock;
-                if (sidx >= pd.n_special) continue;
-                row = pd.special_map[sidx];
-            } else if (row >= pd.n1) continue;
-            const int v = exact_ip<DIM, SIGNED>(qrow, pd.A + (size_t)row * DIM);
-            // later ORIGINAL row wins ties (the gathered order need not be monotone)
-            if (v > best || (v == best && row > best_idx)) { second = best; best = v; best_idx = row; }
-            else if (v > second) second = v;
+            cand[u][j] = cd;
+            const int cs = max(cd, 0);          // padding candidates read row 0, masked below
+            cv[u][j] = *reinterpret_cast<const int4 *>(Cm + (size_t)cs * DIM + c * 16);
+            corr_c[u][j] = corrC[cs];
         }
     }
-    (void)ip1;
-    *idx_out = best_idx;
-    *best_out = best;
-    *second_out = max(second, m_other);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int vbest = INT_MIN, vidx = -1, vsec = INT_MIN;     // over this lane group's candidates
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            int acc = __builtin_amdgcn_sdot4(qv[u].x, cv[u][j].x, 0, false);
+            acc = __builtin_amdgcn_sdot4(qv[u].y, cv[u][j].y, acc, false);
+            acc = __builtin_amdgcn_sdot4(qv[u].z, cv[u][j].z, acc, false);
+            acc = __builtin_amdgcn_sdot4(qv[u].w, cv[u][j].w, acc, false);
+            acc += dpp_mov<kDppXor1>(acc, 0);
+            acc += dpp_mov<kDppXor2>(acc, 0);
+            if (LPC == 8) acc += dpp_mov<kDppHalfMirror>(acc, 0);
+            const int v = cand[u][j] >= 0 ? acc + corr_q[u] + corr_c[u][j] : INT_MIN;
+            // larger index wins ties (later column / later ORIGINAL row: the gathered
+            // order of special rows need not be monotone)
+            if (v > vbest || (v == vbest && cand[u][j] > vidx)) { vsec = vbest; vbest = v; vidx = cand[u][j]; }
+            else if (v > vsec) vsec = v;
+        }
+        const int best = wave_max(vbest);
+        const int widx = wave_max(vbest == best ? vidx : -1);
+        const bool winner = vbest == best && vidx == widx;
+        second_out[u] = wave_max(winner ? vsec : vbest);
+        idx_out[u] = max(widx, 0);
+        best_out[u] = best;
+    }
 }
 
 template <int DIM, bool SIGNED>
-__global__ void
+__global__ __launch_bounds__(128) void
 match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__restrict__ rowparts,
     const ColPart *__restrict__ colparts, LoweTable tab, int force_exact,
     ExactItem *__restrict__ exact_items, int32_t *__restrict__ exact_count, int exact_cap)
@@ -649,59 +719,77 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
     const MatchProblem &pd = problems[blockIdx.y];
     const int dir = blockIdx.z;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int nq = dir == 0 ? pd.n1 : pd.n2;
-    if (q >= nq) return;
     const int nc = dir == 0 ? pd.n2 : pd.n1;
+    if (blockIdx.x * blockDim.x >= nq) return;           // whole block out of range
     int32_t *out = dir == 0 ? pd.m12 : pd.m21;
-    if (nc == 0) { out[q] = -1; return; }
+    const bool active = q < nq;
 
     // ip1 / idx1: exact best; ip2: second largest GROUP best (lower bound of the
     // true second); code: group of the best (dir 1), idx1 = its row block there
     int ip1 = INT_MIN, ip2 = INT_MIN, idx1 = 0, code = 0;
-    if (dir == 0) {
-        const int64_t stride = (int64_t)pd.nrb * kRowsPerBlock;
-        // special rows keep their partials behind the main row blocks
-        int slot = q;
-        if (pd.special_slot) {
-            const int sidx = pd.special_slot[q];
-            if (sidx >= 0) slot = pd.nrb_main * kRowsPerBlock + sidx;
-        }
-        for (int sgi = 0; sgi < pd.nseg; ++sgi) {
-            const RowPart p = rowparts[pd.rowpart_off + sgi * stride + slot];
-            // later segment wins ties (its columns have larger indices)
-            ip2 = max(max(ip2, p.ip_second), min(ip1, p.ip_best));
-            if (p.ip_best >= ip1 && p.ip_best != INT_MIN) { ip1 = p.ip_best; idx1 = p.idx_best; }
-        }
-    } else {
-        for (int rb = 0; rb < pd.nrb; ++rb) {
-            const ColPart p = colparts[pd.colpart_off + (int64_t)rb * pd.n2stride + q];
-            const int pb = p.key_best == kKeyNone ? INT_MIN : (p.key_best >> 8);
-            const int ps = p.key_second == kKeyNone ? INT_MIN : (p.key_second >> 8);
-            ip2 = max(max(ip2, ps), min(ip1, pb));
-            if (pb >= ip1 && pb != INT_MIN) { ip1 = pb; idx1 = rb; code = p.key_best & 255; }
+    if (active && nc > 0) {
+        if (dir == 0) {
+            const int64_t stride = (int64_t)pd.nrb * kRowsPerBlock;
+            // special rows keep their partials behind the main row blocks
+            int slot = q;
+            if (pd.special_slot) {
+                const int sidx = pd.special_slot[q];
+                if (sidx >= 0) slot = pd.nrb_main * kRowsPerBlock + sidx;
+            }
+            for (int sgi = 0; sgi < pd.nseg; ++sgi) {
+                const RowPart p = rowparts[pd.rowpart_off + sgi * stride + slot];
+                // later segment wins ties (its columns have larger indices)
+                ip2 = max(max(ip2, p.ip_second), min(ip1, p.ip_best));
+                if (p.ip_best >= ip1 && p.ip_best != INT_MIN) { ip1 = p.ip_best; idx1 = p.idx_best; }
+            }
+        } else {
+            for (int rb = 0; rb < pd.nrb; ++rb) {
+                const ColPart p = colparts[pd.colpart_off + (int64_t)rb * pd.n2stride + q];
+                const int pb = p.key_best == kKeyNone ? INT_MIN : (p.key_best >> 8);
+                const int ps = p.key_second == kKeyNone ? INT_MIN : (p.key_second >> 8);
+                ip2 = max(max(ip2, ps), min(ip1, pb));
+                if (pb >= ip1 && pb != INT_MIN) { ip1 = pb; idx1 = rb; code = p.key_best & 255; }
+            }
         }
     }
     const int limit = tab.is_signed ? 32767 : 65535;
-    bool exact = force_exact || pd.force_exact || ip1 > limit;
+    bool exact = active && nc > 0 && (force_exact || pd.force_exact || ip1 > limit);
+    bool refine = false;
     int res = -1;
-    if (!exact) {
+    if (active && nc > 0 && !exact) {
         // optimistic test against the lower bound of the second best
         res = accept_match(ip1, ip2, 0, tab);
         if (res >= 0) {
-            if (ip1 < 0) {
-                res = 0;                      // reference state (0, 0, idx 0): nothing to refine
-            } else if (ip2 == ip1) {
-                exact = true;                 // accepted despite a tie for best (NaN accept /
-                                              // ratio >= 1): defer to the sequential-scan kernel
-            } else {
-                // the rescan also yields the exact best of the group: it differs from
-                // ip1 only when ip1 = 0 came from a padding column (raw path), i.e.
-                // when no real candidate reaches 0 -- then it is the value to test
-                int idx, found, second;
-                rescan_group<DIM, SIGNED>(pd, dir, q, ip1, idx1, code, ip2, &idx, &found, &second);
-                res = accept_match(found, second, idx, tab);
-            }
+            if (ip1 < 0) res = 0;             // reference state (0, 0, idx 0): nothing to refine
+            else if (ip2 == ip1) exact = true;  // accepted despite a tie for best (NaN accept /
+                                                // ratio >= 1): defer to the sequential-scan kernel
+            else refine = true;
         }
+    }
+    // Queries that pass get their best group re-scored, one query at a time by
+    // the whole wave.  The rescan also yields the exact best of the group: it
+    // differs from ip1 only when ip1 = 0 came from a padding column (raw path),
+    // i.e. when no real candidate reaches 0 -- then it is the value to test.
+    unsigned long long todo = (OSFM_EXP & 64) ? 0ull : __ballot(refine);
+    while (todo) {
+        int src[2], qs[2], is[2], cs[2], idx[2], found[2], second[2];
+        src[0] = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        src[1] = todo ? __ffsll((long long)todo) - 1 : src[0];     // odd count: the last one twice
+        todo &= todo - 1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            qs[u] = __builtin_amdgcn_readlane(q, src[u]);
+            is[u] = __builtin_amdgcn_readlane(idx1, src[u]);
+            cs[u] = __builtin_amdgcn_readlane(code, src[u]);
+        }
+        if (dir == 0) rescan_groups<DIM, 0>(pd, qs, is, cs, lane, idx, found, second);
+        else rescan_groups<DIM, 1>(pd, qs, is, cs, lane, idx, found, second);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (lane == src[u]) res = accept_match(found[u], max(second[u], ip2), idx[u], tab);
     }
     if (exact) {
         const int slot = atomicAdd(exact_count, 1);
@@ -711,7 +799,7 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
             exact_items[slot] = it;
         }
     }
-    out[q] = res;
+    if (active) out[q] = res;
 }
 
 void launch_match_finish(const MatchProblem *d_problems, int num_problems, int max_n,
