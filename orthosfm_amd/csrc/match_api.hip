@@ -159,6 +159,7 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
     int64_t out_ints = 0, rowpart_recs = 0, colpart_recs = 0, keep_bytes = 0, total_queries = 0;
     int total_blocks[2] = {0, 0}, max_n[2] = {0, 0};
     bool needs_mask[2] = {false, false};   // some problem is limited below its view size
+    bool any_special[2] = {false, false};  // some problem has gathered special rows
     int64_t macs = 0, alg_bytes = 0;
 
     for (int p = 0; p < num_pairs; ++p) {
@@ -207,6 +208,7 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
             pr.special_slot = n_special > 0 ? a.special_slot.as<int32_t>() : nullptr;
             const bool empty = pr.n1 == 0 || pr.n2 == 0;
             if (limited) needs_mask[type] = true;
+            if (!empty && n_special > 0) any_special[type] = true;
             pr.nrb_main = empty ? 0 : (pr.n1 + kRowsPerBlock - 1) / kRowsPerBlock;
             pr.nrb = pr.nrb_main + (empty ? 0 : (n_special + kRowsPerBlock - 1) / kRowsPerBlock);
             pr.nseg = empty ? 0 : (pr.n2 + kSegCols - 1) / kSegCols;
@@ -278,7 +280,7 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
         int32_t *ecount = m->exact_count.as<int32_t>() + type;
 
         if (total_blocks[type] > 0) { OSFM_HIP_CHECK(hipEventRecord(m->ev[type][0], s)); timed[type] = true; }
-        launch_match_tiles(type == 0 ? 8 : 4, needs_mask[type], dp, np, total_blocks[type],
+        launch_match_tiles(type == 0 ? 8 : 4, needs_mask[type], any_special[type], dp, np, total_blocks[type],
             m->rowparts.as<RowPart>(), m->colparts.as<ColPart>(), s);
         if (timed[type]) OSFM_HIP_CHECK(hipEventRecord(m->ev[type][1], s));
         launch_match_finish(dp, np, max_n[type], m->rowparts.as<RowPart>(),

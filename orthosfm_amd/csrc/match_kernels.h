@@ -58,8 +58,9 @@ struct LoweTable {
 // wrap-around arithmetic (nearest_neighbor.cc:75-84 and the T-typed state).
 struct ExactItem { int32_t problem; int32_t dir; int32_t query; };
 
-void launch_match_tiles(int ch, bool masked, const MatchProblem *d_problems, int num_problems,
-    int total_blocks, RowPart *rowparts, ColPart *colparts, hipStream_t s);
+// any_special: some problem has row blocks behind nrb_main (gathered special rows)
+void launch_match_tiles(int ch, bool masked, bool any_special, const MatchProblem *d_problems,
+    int num_problems, int total_blocks, RowPart *rowparts, ColPart *colparts, hipStream_t s);
 
 void launch_match_finish(const MatchProblem *d_problems, int num_problems,
     int max_n, const RowPart *rowparts, const ColPart *colparts, LoweTable tab,

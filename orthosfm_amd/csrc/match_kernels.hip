@@ -24,18 +24,8 @@
 
 #include "match_kernels.h"
 
-#ifndef OSFM_EXP
-#define OSFM_EXP 0   // kernel-timing experiments (bit mask), 0 in product builds
-#endif
-
 namespace osfm {
 
-#if OSFM_EXP & 32
-__device__ unsigned long long g_prof[8];
-#define OSFM_STAMP(i) { unsigned long long now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)); pseg[i] += now_ - pprev; pprev = now_; }
-#else
-#define OSFM_STAMP(i)
-#endif
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -345,15 +335,11 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
     }
     __syncthreads();        // every wave holds tile 0 in registers: its LDS buffer may be refilled
 
-#if OSFM_EXP & 32
-    unsigned long long pseg[6] = {0, 0, 0, 0, 0, 0}, pprev;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pprev));
-#endif
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         // tile t+2 into the buffer tile t was read from (clamped: the extra
         // refills of the last tile are never consumed)
-        if (!(OSFM_EXP & 1)) stage_tile(min(t + 2, ntiles - 1), buf);
+        stage_tile(min(t + 2, ntiles - 1), buf);
 #pragma unroll
         for (int cf = 0; cf < 2; ++cf) {
             if (!RAW) {
@@ -370,7 +356,7 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
         phase(IntC<1>(), acc1, acc0, buf ^ 1);   // reduce (rf 1, t), produce (rf 0, t+1)
 
         // close a row-direction group: fold the group bests into (best, second)
-        if (!(OSFM_EXP & 2) && ((t % kGroupTiles) == kGroupTiles - 1 || t == ntiles - 1)) {
+        if ((t % kGroupTiles) == kGroupTiles - 1 || t == ntiles - 1) {
             const int gidx = t / kGroupTiles;
             // all LDS reads first (one exposed latency instead of 32): the
             // accumulator pair consumed by phase 1 is dead here and lends its registers
@@ -394,7 +380,7 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
         // half-waves of a column are exchanged with one v_permlane32_swap so that
         // lane == column within the tile, then the wave's (best, second) goes to LDS.
         // group code = wave * 2 + half-wave (32 rows: both fragments of the half-wave)
-        if (!(OSFM_EXP & 16)) {
+        {
             int kk[2];
 #pragma unroll
             for (int cf = 0; cf < 2; ++cf) {
@@ -409,19 +395,11 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
             colbuf[((t & 7) * 4 + wave) * 64 + lane] = cp;
         }
 
-        if (OSFM_EXP & 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else if (OSFM_EXP & 32) {
-            OSFM_STAMP(0)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            OSFM_STAMP(1)
-            __syncthreads();
-            OSFM_STAMP(2)
-        }
-        else __syncthreads();
+        __syncthreads();
 
         // every fourth tile all four waves merge one tile each of the last batch
         // (the same work in every wave: nobody is waited for at the next barrier)
-        if (!(OSFM_EXP & 4) && ((t & 3) == 3 || t == ntiles - 1)) {
+        if ((t & 3) == 3 || t == ntiles - 1) {
             const int tm = (t & ~3) + wave;
             if (tm <= t) {
                 int k1 = kKeyNone, k2 = kKeyNone;
@@ -442,15 +420,8 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
                 }
             }
         }
-        OSFM_STAMP(3)
     }
 
-#if OSFM_EXP & 32
-    if (lane == 0 && (blockIdx.x & 255) == 77) {
-        atomicAdd(&g_prof[0], pseg[0]); atomicAdd(&g_prof[1], pseg[1]); atomicAdd(&g_prof[2], pseg[2]);
-        atomicAdd(&g_prof[3], pseg[3]); atomicAdd(&g_prof[4], (unsigned long long)ntiles);
-    }
-#endif
     // --- row direction: merge the 32 lanes that hold the same row -------------
     // Through LDS (the tile buffers are free now): each of 32 threads per wave
     // walks the 32 source lanes of one row.  (ip, column) composites keep
@@ -488,7 +459,11 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
     }
 }
 
-template <int CH, bool MASKED>
+// RAW = true runs the row blocks [0, nrb_main) of every problem, RAW = false the
+// blocks of gathered special rows behind them (and everything of a MASKED
+// launch); a block of the other kind returns at once.  Two kernels rather than
+// one with both bodies: the register budget of each is its own.
+template <int CH, bool MASKED, bool RAW>
 __global__ __launch_bounds__(256, 2) void
 match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, int total_blocks,
     RowPart *__restrict__ rowparts, ColPart *__restrict__ colparts)
@@ -505,34 +480,28 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
     const int local = lin - pd.block_start;
     const int rb = local / pd.nseg;
     const int seg = local - rb * pd.nseg;
-    if (!MASKED && rb < pd.nrb_main)
-        tile_body<CH, MASKED, true>(pd, rb, seg, rowparts, colparts, smem);
-    else
-        tile_body<CH, MASKED, false>(pd, rb, seg, rowparts, colparts, smem);
+    if (!MASKED && (rb < pd.nrb_main) != RAW) return;
+    tile_body<CH, MASKED, RAW>(pd, rb, seg, rowparts, colparts, smem);
 }
 
-#if OSFM_EXP & 32
-extern "C" __attribute__((visibility("default"))) int osfm_debug_read_prof(unsigned long long *out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 8);
-}
-#endif
-
-void launch_match_tiles(int ch, bool masked, const MatchProblem *d_problems, int num_problems,
-    int total_blocks, RowPart *rowparts, ColPart *colparts, hipStream_t s)
+void launch_match_tiles(int ch, bool masked, bool any_special, const MatchProblem *d_problems,
+    int num_problems, int total_blocks, RowPart *rowparts, ColPart *colparts, hipStream_t s)
 {
     if (total_blocks <= 0) return;
     const int d = ch * 16;
     const size_t lds = std::max<size_t>(2 * (size_t)kTileCols * d, 16384) + 2 * 64 * 4 + 8 * 4 * 64 * sizeof(ColPart) + 32 * 256 * 4;
     const dim3 grid(total_blocks), block(256);
-    if (ch == 8 && !masked)
-        hipLaunchKernelGGL((match_tile_kernel<8, false>), grid, block, lds, s, d_problems, num_problems, total_blocks, rowparts, colparts);
-    else if (ch == 8)
-        hipLaunchKernelGGL((match_tile_kernel<8, true>), grid, block, lds, s, d_problems, num_problems, total_blocks, rowparts, colparts);
-    else if (!masked)
-        hipLaunchKernelGGL((match_tile_kernel<4, false>), grid, block, lds, s, d_problems, num_problems, total_blocks, rowparts, colparts);
-    else
-        hipLaunchKernelGGL((match_tile_kernel<4, true>), grid, block, lds, s, d_problems, num_problems, total_blocks, rowparts, colparts);
+#define OSFM_LAUNCH_TILES(CHV, MASKEDV, RAWV) \
+    hipLaunchKernelGGL((match_tile_kernel<CHV, MASKEDV, RAWV>), grid, block, lds, s, d_problems, num_problems, total_blocks, rowparts, colparts)
+    if (masked) {
+        if (ch == 8) OSFM_LAUNCH_TILES(8, true, false); else OSFM_LAUNCH_TILES(4, true, false);
+    } else {
+        if (ch == 8) OSFM_LAUNCH_TILES(8, false, true); else OSFM_LAUNCH_TILES(4, false, true);
+        if (any_special) {
+            if (ch == 8) OSFM_LAUNCH_TILES(8, false, false); else OSFM_LAUNCH_TILES(4, false, false);
+        }
+    }
+#undef OSFM_LAUNCH_TILES
 }
 
 // ---------------------------------------------------------------------------
@@ -772,7 +741,7 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
     // the whole wave.  The rescan also yields the exact best of the group: it
     // differs from ip1 only when ip1 = 0 came from a padding column (raw path),
     // i.e. when no real candidate reaches 0 -- then it is the value to test.
-    unsigned long long todo = (OSFM_EXP & 64) ? 0ull : __ballot(refine);
+    unsigned long long todo = __ballot(refine);
     while (todo) {
         int src[2], qs[2], is[2], cs[2], idx[2], found[2], second[2];
         src[0] = __ffsll((long long)todo) - 1;

@@ -1,0 +1,42 @@
+"""HBM traffic of the dominant matching kernel from two rocprofv3 --pmc passes
+(FETCH_SIZE and WRITE_SIZE, collected separately as MI355X_MICROARCH.md
+prescribes) -> profiles/<round>_match_traffic_pmc.json, read by bench.py.
+usage: python tools/pmc_traffic.py fetch.csv write.csv pairs_in_launch out.json"""
+import csv
+import json
+import sys
+
+KERNEL = "match_tile_kernel<8, false, true>"
+
+
+def total(path, counter):
+    best = 0.0
+    for row in csv.DictReader(open(path)):
+        if KERNEL in row["Kernel_Name"] and row["Counter_Name"] == counter:
+            best = max(best, float(row["Counter_Value"]))     # the full-matching launch
+    return best
+
+
+def main():
+    fetch_kb = total(sys.argv[1], "FETCH_SIZE")
+    write_kb = total(sys.argv[2], "WRITE_SIZE")
+    pairs = int(sys.argv[3])
+    hbm = (2.0 * fetch_kb + write_kb) * 1024.0
+    rec = {
+        "kernel": KERNEL,
+        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py "
+                   "--steps 1 --warmup 0 --no-ba --no-verify --no-cpu-baseline",
+        "pairs_in_launch": pairs,
+        "FETCH_SIZE_KB": fetch_kb,
+        "WRITE_SIZE_KB": write_kb,
+        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads -> doubled "
+                      "(MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
+        "hbm_bytes_per_launch": hbm,
+        "hbm_bytes_per_pair": hbm / pairs,
+    }
+    json.dump(rec, open(sys.argv[4], "w"), indent=1)
+    print(json.dumps(rec))
+
+
+if __name__ == "__main__":
+    main()
