@@ -123,6 +123,30 @@ def ba_cpu_baseline(iterations=2):
                       "(residual/Jacobian evaluation and the dense Cholesky trailing updates OpenMP-parallel, Schur accumulation serial)"}
 
 
+def outlier_filter_bench(device, with_cpu):
+    """filterOutlierTracks on the 100k points of the global-BA config: the
+    O(P^2) nearest-neighbour search is the kernel, the rest is O(P) host work."""
+    from orthosfm_amd import filters, synth
+    sc = synth.make_ba_scene(synth.MODEL_QUATERNION, 200, 100000, config_id=4)
+    has = np.ones(sc.points.shape[0], dtype=bool)
+    filters.outlier_track_flags(sc.points, has, device)
+    t0 = time.perf_counter()
+    keep, st = filters.outlier_track_flags(sc.points, has, device)
+    dt = time.perf_counter() - t0
+    out = {"workload": "filterOutlierTracks, 100000 points (1e10 distance evaluations, f64)",
+           "ms": dt * 1e3, "kept": int(keep.sum()), "mean_nn": st.mean, "sigma": st.sigma}
+    if with_cpu:
+        import oracle_lib
+        n = 20000
+        t0 = time.perf_counter()
+        oracle_lib.oracle_nn_distances(sc.points[:n])
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": dtc * 1e3 * (sc.points.shape[0] / n) ** 2, "unit": "ms (extrapolated to 100000 points)",
+                               "cores": int(oracle_lib.oracle().oracle_num_threads()), "kind": "port",
+                               "sample": f"nearest-neighbour search over the first {n} points, {dtc:.2f} s, scaled by (100000/{n})^2"}
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -240,6 +264,12 @@ def main():
 
     if ba is not None and "error" not in ba and not args.no_cpu_baseline and rank == 0:
         ba["cpu_baseline"] = ba_cpu_baseline()
+
+    if ba is not None and "error" not in ba and rank == 0:
+        try:
+            ba["outlier_filter"] = outlier_filter_bench(device_index, not args.no_cpu_baseline)
+        except Exception as e:
+            ba["outlier_filter"] = {"error": str(e)}
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3

@@ -322,6 +322,42 @@ OSFM_API int osfm_ba_reprojection_errors(const osfm_ba_problem *p, int device,
 OSFM_API int osfm_ba_triangulate(const osfm_ba_problem *p, int device,
     uint8_t *point_valid);
 
+/* ---- outlier filters around the bundle adjustment ---- */
+
+/* orthosfm::getNearestNeighbourDistance
+ * (src/triangulation/outlier_filtering.cpp:14-38): nn[i] = min over j != i of
+ * the 2-norm of the difference of the HOMOGENEOUS 4-vectors, 1000000 when no
+ * point is closer.  points: [num_points][4]. */
+OSFM_API int osfm_nn_distances(int device, const double *points, int32_t num_points,
+    double *nn);
+
+typedef struct osfm_outlier_stats {
+    double mean;               /* of the nearest-neighbour distances */
+    double sigma;              /* as the reference computes it (:80-98), after the 1e-3 floor */
+    int32_t num_with_point;
+    int32_t num_kept;
+} osfm_outlier_stats;
+
+/* orthosfm::filterOutlierTracks (outlier_filtering.cpp:40-125) on flattened
+ * tracks: points [num_tracks][4] (Track::getPoint), has_point [num_tracks]
+ * (Track::hasPoint); keep[t] = 1 when the track is in the returned list.
+ * stats may be NULL. */
+OSFM_API int osfm_filter_outlier_tracks(int device, const double *points,
+    const uint8_t *has_point, int32_t num_tracks, uint8_t *keep,
+    osfm_outlier_stats *stats);
+
+/* The device part of orthosfm::filterTracksWithReprojectionError
+ * (outlier_filtering.cpp:127-192).  p holds the FULL-SIZE tracks (the
+ * caller's filterTracksToAvailableCameras(cameras, tracks, true, true)
+ * selection, :131) flattened as for osfm_ba_solve.  They are re-triangulated
+ * (triangulateTracks(cameras, fullSizeTracks, true), :134; p->points is
+ * overwritten, point_valid[j] = 0 where fewer than two rays exist and the input
+ * point is kept), every observation is evaluated against its track's point
+ * (:158) and obs_keep[k] = err[k] < max_error (1.5 px in the reference, :140).
+ * err and point_valid may be NULL. */
+OSFM_API int osfm_filter_reprojection(const osfm_ba_problem *p, int device,
+    double max_error, uint8_t *obs_keep, uint8_t *point_valid, double *err);
+
 #ifdef __cplusplus
 }
 #endif

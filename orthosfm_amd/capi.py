@@ -86,6 +86,11 @@ class BaOptions(C.Structure):
                 ("device", C.c_int32), ("verbose", C.c_int32)]
 
 
+class OutlierStats(C.Structure):
+    _fields_ = [("mean", C.c_double), ("sigma", C.c_double),
+                ("num_with_point", C.c_int32), ("num_kept", C.c_int32)]
+
+
 class BaSummary(C.Structure):
     _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double),
                 ("num_iterations", C.c_int32), ("num_successful_steps", C.c_int32),
@@ -108,6 +113,7 @@ EXPORTS = [
     "osfm_pair_from_index", "osfm_match_get_stats",
     "osfm_ba_options_default", "osfm_ba_solve", "osfm_ba_reprojection_errors",
     "osfm_ba_triangulate",
+    "osfm_nn_distances", "osfm_filter_outlier_tracks", "osfm_filter_reprojection",
 ]
 
 lib.osfm_last_error.restype = C.c_char_p

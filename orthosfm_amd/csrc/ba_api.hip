@@ -494,4 +494,40 @@ int osfm_ba_triangulate(const osfm_ba_problem *p, int device, uint8_t *point_val
     return OSFM_OK;
 }
 
+int osfm_filter_reprojection(const osfm_ba_problem *p, int device, double max_error,
+    uint8_t *obs_keep, uint8_t *point_valid, double *err)
+{
+    OSFM_RETURN_IF(validate_problem(p, "filter_reprojection"));
+    if (!obs_keep && p->num_observations > 0) { set_error("filter_reprojection: obs_keep is null"); return OSFM_E_ARG; }
+    OSFM_RETURN_IF(select_device(device));
+    StreamGuard sg;
+    OSFM_HIP_CHECK(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
+    Layout L;
+    build_layout(p, &L);
+    DeviceProblem D;
+    OSFM_RETURN_IF(upload_problem(p, L, 1.0, 3, sg.s, &D));
+    const int M = p->num_points, O = p->num_observations;
+    DevArray d_valid, d_err, d_res;
+    OSFM_RETURN_IF(d_valid.alloc((size_t)std::max(M, 1)));
+    OSFM_RETURN_IF(d_err.alloc((size_t)std::max(O, 1) * 8));
+    OSFM_RETURN_IF(d_res.alloc((size_t)2 * std::max(O, 1) * 8));
+    // triangulate into the spare point array (tracks with fewer than two rays
+    // keep their input point), then evaluate against the triangulated points
+    OSFM_HIP_CHECK(hipMemcpyAsync(D.points[1].ptr, D.points[0].ptr, (size_t)4 * M * 8, hipMemcpyDeviceToDevice, sg.s));
+    launch_triangulate(D.dev, D.points[1].as<double>(), d_valid.as<uint8_t>(), sg.s);
+    OSFM_HIP_CHECK(hipMemcpyAsync(D.points[0].ptr, D.points[1].ptr, (size_t)4 * M * 8, hipMemcpyDeviceToDevice, sg.s));
+    launch_reproj(D.dev, d_err.as<double>(), d_res.as<double>(), sg.s);
+    OSFM_HIP_CHECK(hipGetLastError());
+    std::vector<double> herr((size_t)std::max(O, 1));
+    if (O) OSFM_HIP_CHECK(hipMemcpyAsync(herr.data(), d_err.ptr, (size_t)O * 8, hipMemcpyDeviceToHost, sg.s));
+    if (M) OSFM_HIP_CHECK(hipMemcpyAsync(p->points, D.points[1].ptr, (size_t)4 * M * 8, hipMemcpyDeviceToHost, sg.s));
+    if (point_valid && M) OSFM_HIP_CHECK(hipMemcpyAsync(point_valid, d_valid.ptr, (size_t)M, hipMemcpyDeviceToHost, sg.s));
+    OSFM_HIP_CHECK(hipStreamSynchronize(sg.s));
+    for (int k = 0; k < O; ++k) {
+        obs_keep[k] = herr[k] < max_error ? 1 : 0;
+        if (err) err[k] = herr[k];
+    }
+    return OSFM_OK;
+}
+
 }  // extern "C"

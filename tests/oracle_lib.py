@@ -431,3 +431,29 @@ def oracle_ransac(pos1, pos2, corr, max_iterations=1000, threshold=0.0015, seed=
           corr.reshape(-1) if corr.size else np.zeros(2, np.int32), corr.shape[0], max_iterations, threshold,
           seed, pair_id, inl, F)
     return n, inl[:max(n, 0)].copy(), F.reshape(3, 3)
+
+
+# ---------------------------------------------------------------------------
+# outlier filter oracle (oracle/filter_oracle.c)
+# ---------------------------------------------------------------------------
+def oracle_nn_distances(points):
+    lib = oracle()
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 4)
+    nn = np.zeros(max(pts.shape[0], 1))
+    lib.oracle_nn_distances.argtypes = [_f64p, C.c_int, _f64p]
+    lib.oracle_nn_distances.restype = None
+    lib.oracle_nn_distances(pts.reshape(-1), pts.shape[0], nn)
+    return nn[:pts.shape[0]]
+
+
+def oracle_filter_outlier_tracks(points, has_point):
+    lib = oracle()
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 4)
+    hp = np.ascontiguousarray(has_point, dtype=np.uint8).reshape(-1)
+    keep = np.zeros(max(hp.shape[0], 1), dtype=np.uint8)
+    stats = np.zeros(2)
+    lib.oracle_filter_outlier_tracks.argtypes = [_f64p, np.ctypeslib.ndpointer(np.uint8), C.c_int,
+                                                 np.ctypeslib.ndpointer(np.uint8), _f64p]
+    lib.oracle_filter_outlier_tracks.restype = None
+    lib.oracle_filter_outlier_tracks(pts.reshape(-1), hp, hp.shape[0], keep, stats)
+    return keep[:hp.shape[0]].astype(bool), stats[0], stats[1]
