@@ -44,6 +44,34 @@ sampson(const double *F, double x1, double y1, double x2, double y2)
     return n / sum;
 }
 
+// sampson(...) < thr2 decided without the division wherever a product test is
+// safe: n < sum * thr2 (1 - 2^-49) implies fl(n / sum) < thr2 and
+// n >= sum * thr2 (1 + 2^-49) implies fl(n / sum) >= thr2 (the roundings of the
+// products and of the quotient, 2^-53 each, cannot bridge 2^-49); only the
+// sliver in between takes the reference's division (fundamental.cc:245).  Same
+// decisions as the oracle, bit for bit.  thr_lo / thr_hi are those two bounds.
+__device__ __forceinline__ bool
+sampson_below(const double *F, double x1, double y1, double x2, double y2, double thr2,
+    double thr_lo, double thr_hi)
+{
+    const double a = x1 * F[0] + y1 * F[1] + F[2];
+    const double b = x1 * F[3] + y1 * F[4] + F[5];
+    const double c = x1 * F[6] + y1 * F[7] + F[8];
+    double n = 0.0;
+    n += x2 * a;
+    n += y2 * b;
+    n += c;                        // the reference's 1.0 * c, an exact identity
+    n *= n;
+    double sum = 0.0, t;
+    sum += a * a;
+    sum += b * b;
+    t = x2 * F[0] + y2 * F[3] + F[6]; sum += t * t;
+    t = x2 * F[1] + y2 * F[4] + F[7]; sum += t * t;
+    if (n < sum * thr_lo) return true;                    // strict: sum == 0 never passes here
+    if (n >= sum * thr_hi) return false;                  // 0/0 and x/0 of the reference: not below
+    return n / sum < thr2;                                // the sliver, and NaN operands
+}
+
 __device__ void eig3_fixed(double A[3][3], double V[3][3], double w[3])
 {
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
@@ -136,7 +164,7 @@ constexpr int kChunk = 1024;       // matches staged in LDS at a time
 __global__ __launch_bounds__(256) void
 ransac_kernel(const RansacJob *__restrict__ jobs, int max_iterations, double thr2, uint64_t seed)
 {
-    __shared__ float mx1[kChunk], my1[kChunk], mx2[kChunk], my2[kChunk];
+    __shared__ double4 mpt[kChunk];           // (x1, y1, x2, y2) of the staged matches, widened once
     __shared__ int s_count[256], s_iter[256];
     __shared__ double s_F[9];
     __shared__ int s_wave[4], s_run;
@@ -147,6 +175,8 @@ ransac_kernel(const RansacJob *__restrict__ jobs, int max_iterations, double thr
         if (tid == 0) *job.count_out = -1;
         return;
     }
+    const double thr_lo = thr2 * (1.0 - 1.7763568394002505e-15);     // 2^-49
+    const double thr_hi = thr2 * (1.0 + 1.7763568394002505e-15);
     int best_count = 0, best_iter = 0x7fffffff;
     double bestF[9];
     for (int i = 0; i < 9; ++i) bestF[i] = 0.0;
@@ -188,16 +218,17 @@ ransac_kernel(const RansacJob *__restrict__ jobs, int max_iterations, double thr
             __syncthreads();
             for (int i = tid; i < kChunk && c0 + i < k; i += 256) {
                 const int a = job.corr[2 * (c0 + i)], b = job.corr[2 * (c0 + i) + 1];
-                mx1[i] = job.pos1[2 * a]; my1[i] = job.pos1[2 * a + 1];
-                mx2[i] = job.pos2[2 * b]; my2[i] = job.pos2[2 * b + 1];
+                mpt[i] = make_double4(job.pos1[2 * a], job.pos1[2 * a + 1], job.pos2[2 * b], job.pos2[2 * b + 1]);
             }
             __syncthreads();
             const int lim = min(kChunk, k - c0);
             for (int i = 0; i < lim; ++i) {
-                const double x1 = mx1[i], y1 = my1[i], x2 = mx2[i], y2 = my2[i];
+                const double4 m = mpt[i];
+                // invalid hypotheses (all-zero F) are evaluated too and discarded below:
+                // no divergence inside the loop
 #pragma unroll
                 for (int h = 0; h < kHyp; ++h)
-                    if (valid[h] && sampson(F[h], x1, y1, x2, y2) < thr2) cnt[h]++;
+                    cnt[h] += sampson_below(F[h], m.x, m.y, m.z, m.w, thr2, thr_lo, thr_hi) ? 1 : 0;
             }
         }
 #pragma unroll
