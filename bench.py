@@ -123,6 +123,36 @@ def ba_cpu_baseline(iterations=2):
                       "(residual/Jacobian evaluation and the dense Cholesky trailing updates OpenMP-parallel, Schur accumulation serial)"}
 
 
+def tracks_bench(out, V, F, with_cpu):
+    """Tracks::compute (bundler_tracks.cc:49-145) over the match lists this run
+    produced: host code in the reference and here; the CPU baseline is the
+    reference's own file when oracle/_ref travelled, the oracle port otherwise."""
+    from orthosfm_amd import tracks as T
+    matched = [tv for tv in out if tv.matches.shape[0] > 0]
+    sizes = np.full(V, F, dtype=np.int32)
+    pairs, offsets, corr = T.flatten_matching(matched)
+    T.compute_flat(sizes, None, pairs, offsets, corr)
+    t0 = time.perf_counter()
+    ids, toff, tfeat, tcol, summary = T.compute_flat(sizes, None, pairs, offsets, corr)
+    dt = time.perf_counter() - t0
+    res = {"workload": f"Tracks::compute over {len(matched)} pairs / {int(offsets[-1])} matches (host code)",
+           "ms": dt * 1e3, "tracks": int(summary.num_tracks), "invalid_tracks": int(summary.num_invalid_tracks),
+           "track_features": int(summary.num_features)}
+    if with_cpu:
+        import oracle_lib
+        parr = np.array([(tv.view_1_id, tv.view_2_id) for tv in matched], dtype=np.int32).reshape(-1, 2)
+        kind = "reference" if oracle_lib.ref_tracks() is not None else "port"
+        fn = oracle_lib.ref_tracks_compute if kind == "reference" else oracle_lib.oracle_tracks
+        t0 = time.perf_counter()
+        ref = fn(sizes, None, parr, offsets, corr)
+        dtc = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": dtc * 1e3, "unit": "ms", "cores": 1, "kind": kind,
+                               "sample": "the same match lists, whole job",
+                               "identical_output": bool(np.array_equal(ref["track_features"], tfeat)
+                                                        and np.array_equal(ref["track_ids"], ids))}
+    return res
+
+
 def outlier_filter_bench(device, with_cpu):
     """filterOutlierTracks on the 100k points of the global-BA config: the
     O(P^2) nearest-neighbour search is the kernel, the rest is O(P) host work."""
@@ -254,6 +284,13 @@ def main():
                     "inliers_rank0": int(sum(tv.num_inliers for tv in outv if tv.status == capi.PAIR_MATCHED))}
         m2.close()
 
+    tracks = None
+    if rank == 0 and world == 1 and not args.no_ba:
+        try:
+            tracks = tracks_bench(out, V, F, not args.no_cpu_baseline)
+        except Exception as e:
+            tracks = {"error": str(e)}
+
     ba = None
     if not args.no_ba and rank == 0:
         try:
@@ -299,6 +336,8 @@ def main():
             "correspondences_rank0": int(n_corr),
             "upload_s": upload_s,
         }
+        if tracks is not None:
+            line["tracks"] = tracks
         if verified is not None:
             line["with_geometric_verification"] = verified
         if ba is not None:

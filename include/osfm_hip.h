@@ -358,6 +358,35 @@ OSFM_API int osfm_filter_outlier_tracks(int device, const double *points,
 OSFM_API int osfm_filter_reprojection(const osfm_ba_problem *p, int device,
     double max_error, uint8_t *obs_keep, uint8_t *point_valid, double *err);
 
+/* ---- track building ---- */
+
+typedef struct osfm_tracks_summary {
+    int32_t num_tracks;           /* tracks in the output */
+    int32_t num_invalid_tracks;   /* removed for holding two features of one view (bundler_tracks.cc:166-171) */
+    int64_t num_features;         /* feature references in the output */
+} osfm_tracks_summary;
+
+/* sfm::bundler::Tracks::compute (src/mve/sfm/bundler_tracks.cc:49-145, with
+ * unify_tracks :23-45 and remove_invalid_tracks :149-203) on flat arrays; host
+ * code, like the reference's.
+ *   view_sizes   [num_views]          features per view (positions.size())
+ *   colors       [sum sizes][3]       FeatureSet::colors, views concatenated (NULL: black)
+ *   pairs        [num_pairs]          TwoViewMatching::view_1_id / view_2_id, PairwiseMatching order
+ *   pair_offsets [num_pairs + 1]      match range of each pair in corr (osfm_match_all's
+ *                                     results give them: offset .. offset + num_inliers)
+ *   corr         [..][2]              (feature in view_1, feature in view_2)
+ * out:
+ *   track_ids    [sum sizes]          Viewport::track_ids, views concatenated, -1 = none
+ *   track_offsets[num_tracks + 1], track_features [..][2] = (view_id, feature_id)
+ *                                     in the reference's order, track_colors [num_tracks][3]
+ * Capacities count tracks / feature references; a safe bound for both is the
+ * number of matches resp. twice that.  OSFM_E_CAPACITY leaves summary filled in. */
+OSFM_API int osfm_tracks_compute(int32_t num_views, const int32_t *view_sizes,
+    const uint8_t *colors, int32_t num_pairs, const osfm_pair *pairs,
+    const int64_t *pair_offsets, const int32_t *corr, int32_t *track_ids,
+    int64_t track_capacity, int64_t feature_capacity, int64_t *track_offsets,
+    int32_t *track_features, uint8_t *track_colors, osfm_tracks_summary *summary);
+
 #ifdef __cplusplus
 }
 #endif

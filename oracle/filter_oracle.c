@@ -59,7 +59,7 @@ oracle_filter_outlier_tracks(const double *points, const uint8_t *has_point, int
     /* reduced list of the tracks with a point (:46-52) */
     int n = 0;
     int *ids = (int *)malloc(sizeof(int) * (num_tracks > 0 ? num_tracks : 1));
-    double *red = (double *)malloc(sizeof(double) * 4 * (num_tracks > 0 ? num_tracks : 1));
+    double *red = (double *)calloc(4 * (size_t)(num_tracks > 0 ? num_tracks : 1), sizeof(double));
     for (int t = 0; t < num_tracks; ++t)
         if (has_point[t]) {
             for (int k = 0; k < 4; ++k) red[4 * n + k] = points[4 * t + k];

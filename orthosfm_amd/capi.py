@@ -86,6 +86,10 @@ class BaOptions(C.Structure):
                 ("device", C.c_int32), ("verbose", C.c_int32)]
 
 
+class TracksSummary(C.Structure):
+    _fields_ = [("num_tracks", C.c_int32), ("num_invalid_tracks", C.c_int32), ("num_features", C.c_int64)]
+
+
 class OutlierStats(C.Structure):
     _fields_ = [("mean", C.c_double), ("sigma", C.c_double),
                 ("num_with_point", C.c_int32), ("num_kept", C.c_int32)]
@@ -114,6 +118,7 @@ EXPORTS = [
     "osfm_ba_options_default", "osfm_ba_solve", "osfm_ba_reprojection_errors",
     "osfm_ba_triangulate",
     "osfm_nn_distances", "osfm_filter_outlier_tracks", "osfm_filter_reprojection",
+    "osfm_tracks_compute",
 ]
 
 lib.osfm_last_error.restype = C.c_char_p

@@ -1,0 +1,134 @@
+// Track building: sfm::bundler::Tracks::compute
+// (src/mve/sfm/bundler_tracks.cc:49-145) on flat arrays.  Host code, as in the
+// reference -- the merge is a sequential, order-defining union over the match
+// lists (the feature order inside a track and the track order are part of the
+// result), so it is restated with cheaper data structures rather than moved to
+// the device: every feature is a node of a singly linked list per track
+// (head / tail / size), unify_tracks (:23-45) splices the smaller list behind
+// the larger one in O(1) after relabelling its nodes, and nothing is
+// reallocated.  The output order is the reference's, element for element.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "osfm_common.h"
+
+using namespace osfm;
+
+extern "C" {
+
+int osfm_tracks_compute(int32_t num_views, const int32_t *view_sizes, const uint8_t *colors,
+    int32_t num_pairs, const osfm_pair *pairs, const int64_t *pair_offsets, const int32_t *corr,
+    int32_t *track_ids, int64_t track_capacity, int64_t feature_capacity,
+    int64_t *track_offsets, int32_t *track_features, uint8_t *track_colors,
+    osfm_tracks_summary *summary)
+{
+    if (num_views < 0 || num_pairs < 0 || (num_views > 0 && !view_sizes) ||
+        (num_pairs > 0 && (!pairs || !pair_offsets)) || !track_offsets ||
+        (track_capacity > 0 && !track_colors) || (feature_capacity > 0 && !track_features)) {
+        set_error("tracks_compute: null array / negative count");
+        return OSFM_E_ARG;
+    }
+    std::vector<int64_t> voff((size_t)num_views + 1, 0);
+    for (int v = 0; v < num_views; ++v) {
+        if (view_sizes[v] < 0) { set_error("tracks_compute: negative view size"); return OSFM_E_ARG; }
+        voff[v + 1] = voff[v] + view_sizes[v];
+    }
+    const int64_t G = voff[num_views];
+    if (G > 0 && !track_ids) { set_error("tracks_compute: track_ids is null"); return OSFM_E_ARG; }
+    const int64_t total_matches = num_pairs > 0 ? pair_offsets[num_pairs] : 0;
+    if (total_matches > 0 && !corr) { set_error("tracks_compute: corr is null"); return OSFM_E_ARG; }
+
+    // node g = voff[view] + feature; nxt[g] = next feature of the same track
+    std::vector<int32_t> tid((size_t)G, -1);
+    std::vector<int64_t> nxt((size_t)G, -1);
+    std::vector<int64_t> head, tail;
+    std::vector<int32_t> size;
+
+    for (int p = 0; p < num_pairs; ++p) {                                       // :66-119
+        const int v1 = pairs[p].view_1, v2 = pairs[p].view_2;
+        if (v1 < 0 || v1 >= num_views || v2 < 0 || v2 >= num_views) {
+            set_error("tracks_compute: pair %d names view %d / %d of %d", p, v1, v2, num_views);
+            return OSFM_E_ARG;
+        }
+        for (int64_t k = pair_offsets[p]; k < pair_offsets[p + 1]; ++k) {
+            const int f1 = corr[2 * k], f2 = corr[2 * k + 1];
+            if (f1 < 0 || f1 >= view_sizes[v1] || f2 < 0 || f2 >= view_sizes[v2]) {
+                set_error("tracks_compute: match %lld of pair %d out of range", (long long)k, p);
+                return OSFM_E_RANGE;
+            }
+            const int64_t g1 = voff[v1] + f1, g2 = voff[v2] + f2;
+            const int32_t t1 = tid[g1], t2 = tid[g2];
+            if (t1 == -1 && t2 == -1) {
+                const int32_t t = (int32_t)head.size();
+                head.push_back(g1); tail.push_back(g2); size.push_back(2);
+                nxt[g1] = g2;
+                tid[g1] = t; tid[g2] = t;
+            } else if (t1 == -1) {
+                tid[g1] = t2; nxt[tail[t2]] = g1; tail[t2] = g1; size[t2]++;
+            } else if (t2 == -1) {
+                tid[g2] = t1; nxt[tail[t1]] = g2; tail[t1] = g2; size[t1]++;
+            } else if (t1 != t2) {
+                // unify into the larger track, the first one on a draw (:28-31)
+                int32_t a = t1, b = t2;
+                if (size[a] < size[b]) { a = t2; b = t1; }
+                for (int64_t g = head[b]; g >= 0; g = nxt[g]) tid[g] = a;
+                nxt[tail[a]] = head[b]; tail[a] = tail[b]; size[a] += size[b];
+                head[b] = -1; tail[b] = -1; size[b] = 0;
+            }
+        }
+    }
+
+    // remove_invalid_tracks (:149-203): empty tracks, tracks with two features of one view
+    const int64_t nt = (int64_t)head.size();
+    std::vector<int32_t> map((size_t)nt, -1);
+    std::vector<int64_t> seen((size_t)num_views, -1);
+    int32_t invalid = 0, valid = 0;
+    int64_t kept_features = 0;
+    for (int64_t t = 0; t < nt; ++t) {
+        if (size[t] == 0) continue;
+        bool bad = false;
+        for (int64_t g = head[t]; g >= 0 && !bad; g = nxt[g]) {
+            // view of node g: the last voff entry <= g (views are few: binary search)
+            int lo = 0, hi = num_views - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (voff[mid] <= g) lo = mid; else hi = mid - 1; }
+            if (seen[lo] == t) bad = true;
+            seen[lo] = t;
+        }
+        if (bad) { invalid++; continue; }
+        map[t] = valid++;
+        kept_features += size[t];
+    }
+    for (int64_t g = 0; g < G; ++g) track_ids[g] = tid[g] >= 0 ? map[tid[g]] : -1;
+    if (summary) {
+        summary->num_tracks = valid;
+        summary->num_invalid_tracks = invalid;
+        summary->num_features = kept_features;
+    }
+    if (valid > track_capacity || kept_features > feature_capacity) {
+        set_error("tracks_compute: %d tracks / %lld features exceed the output capacity (%lld / %lld)",
+            valid, (long long)kept_features, (long long)track_capacity, (long long)feature_capacity);
+        return OSFM_E_CAPACITY;
+    }
+    int64_t nf = 0;
+    for (int64_t t = 0; t < nt; ++t) {
+        if (map[t] < 0) continue;
+        const int32_t o = map[t];
+        track_offsets[o] = nf;
+        float col[4] = {0.0f, 0.0f, 0.0f, 0.0f};                                // :133-143
+        for (int64_t g = head[t]; g >= 0; g = nxt[g]) {
+            int lo = 0, hi = num_views - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (voff[mid] <= g) lo = mid; else hi = mid - 1; }
+            track_features[2 * nf] = lo;
+            track_features[2 * nf + 1] = (int32_t)(g - voff[lo]);
+            ++nf;
+            for (int c = 0; c < 3; ++c) col[c] += colors ? (float)colors[3 * g + c] : 0.0f;
+            col[3] += 1.0f;
+        }
+        for (int c = 0; c < 3; ++c) track_colors[3 * o + c] = (uint8_t)(col[c] / col[3] + 0.5f);
+    }
+    track_offsets[valid] = nf;
+    return OSFM_OK;
+}
+
+}  // extern "C"

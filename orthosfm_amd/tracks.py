@@ -1,0 +1,102 @@
+"""Host-side mirror of sfm::bundler::Tracks (src/mve/sfm/bundler_tracks.h:23-66,
+bundler_tracks.cc:49-203): compute(matching, viewports) -> tracks, with the
+per-feature track ids written back to the viewports.  The work is done by
+osfm_tracks_compute behind the C ABI."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import capi
+
+
+@dataclass
+class Viewport:
+    """The part of sfm::bundler::Viewport (bundler_common.h:37-59) that track
+    building touches: the feature count, FeatureSet::colors and track_ids."""
+    num_features: int
+    colors: np.ndarray | None = None            # (n, 3) uint8
+    track_ids: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+
+
+@dataclass
+class MveTrack:
+    """sfm::bundler::Track (bundler_common.h:79-88) without the 3-D position."""
+    features: np.ndarray                         # (k, 2) int32: view_id, feature_id
+    color: np.ndarray                            # (3,) uint8
+
+
+def flatten_matching(matching):
+    """matching: sequence of objects with view_1_id, view_2_id, matches ((k, 2)
+    int32) -- e.g. what HipExhaustiveMatching.compute returns.  Pairs without
+    matches are kept (they are no-ops for the merge)."""
+    n = len(matching)
+    pairs = (capi.Pair * max(n, 1))()
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    chunks = []
+    for i, tvm in enumerate(matching):
+        pairs[i].view_1, pairs[i].view_2 = int(tvm.view_1_id), int(tvm.view_2_id)
+        m = np.ascontiguousarray(tvm.matches, dtype=np.int32).reshape(-1, 2)
+        chunks.append(m)
+        offsets[i + 1] = offsets[i] + m.shape[0]
+    corr = np.concatenate(chunks) if chunks else np.zeros((0, 2), np.int32)
+    return pairs, offsets, np.ascontiguousarray(corr, dtype=np.int32)
+
+
+def compute_flat(view_sizes, colors, pairs, pair_offsets, corr):
+    """Thin wrapper of osfm_tracks_compute; returns (track_ids, track_offsets,
+    track_features, track_colors, summary)."""
+    view_sizes = np.ascontiguousarray(view_sizes, dtype=np.int32)
+    total = int(view_sizes.sum())
+    n_matches = int(pair_offsets[-1]) if len(pair_offsets) else 0
+    track_ids = np.full(max(total, 1), -1, dtype=np.int32)
+    tcap, fcap = max(n_matches, 1), max(2 * n_matches, 1)
+    track_offsets = np.zeros(tcap + 1, dtype=np.int64)
+    track_features = np.zeros((fcap, 2), dtype=np.int32)
+    track_colors = np.zeros((tcap, 3), dtype=np.uint8)
+    summary = capi.TracksSummary()
+    col_ptr = None
+    if colors is not None:
+        colors = np.ascontiguousarray(colors, dtype=np.uint8).reshape(-1, 3)
+        assert colors.shape[0] == total
+        col_ptr = capi._ptr(colors, C.c_uint8)
+    pair_offsets = np.ascontiguousarray(pair_offsets, dtype=np.int64)
+    capi.check(capi.lib.osfm_tracks_compute(
+        len(view_sizes), capi._ptr(view_sizes, C.c_int32), col_ptr, len(pair_offsets) - 1, pairs,
+        capi._ptr(pair_offsets, C.c_int64), capi._ptr(corr, C.c_int32), capi._ptr(track_ids, C.c_int32),
+        C.c_int64(tcap), C.c_int64(fcap), capi._ptr(track_offsets, C.c_int64),
+        capi._ptr(track_features, C.c_int32), capi._ptr(track_colors, C.c_uint8), C.byref(summary)))
+    nt = summary.num_tracks
+    return (track_ids[:total], track_offsets[:nt + 1], track_features[:summary.num_features],
+            track_colors[:nt], summary)
+
+
+class Tracks:
+    """sfm::bundler::Tracks."""
+
+    def __init__(self, verbose_output: bool = False):
+        self.verbose_output = verbose_output
+
+    def compute(self, matching, viewports):
+        """Tracks::compute(matching, &viewports, &tracks): returns the track
+        list; viewports[i].track_ids is (re)written."""
+        sizes = [vp.num_features for vp in viewports]
+        colors = None
+        if any(vp.colors is not None for vp in viewports):
+            colors = np.concatenate([
+                np.zeros((vp.num_features, 3), np.uint8) if vp.colors is None
+                else np.asarray(vp.colors, dtype=np.uint8).reshape(-1, 3) for vp in viewports])
+        pairs, offsets, corr = flatten_matching(matching)
+        if self.verbose_output:
+            print("Propagating track IDs...")
+        ids, toff, tfeat, tcol, summary = compute_flat(sizes, colors, pairs, offsets, corr)
+        if self.verbose_output:
+            print(f"Removing tracks with conflicts... deleted {summary.num_invalid_tracks} tracks.")
+            print("Colorizing tracks...")
+        start = 0
+        for vp in viewports:
+            vp.track_ids = ids[start:start + vp.num_features].copy()
+            start += vp.num_features
+        return [MveTrack(tfeat[toff[t]:toff[t + 1]], tcol[t]) for t in range(summary.num_tracks)]

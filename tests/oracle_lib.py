@@ -457,3 +457,57 @@ def oracle_filter_outlier_tracks(points, has_point):
     lib.oracle_filter_outlier_tracks.restype = None
     lib.oracle_filter_outlier_tracks(pts.reshape(-1), hp, hp.shape[0], keep, stats)
     return keep[:hp.shape[0]].astype(bool), stats[0], stats[1]
+
+
+# ---------------------------------------------------------------------------
+# track building: oracle (oracle/tracks_oracle.c) and the reference's own
+# bundler_tracks.cc behind oracle/_ref/libref_tracks.so
+# ---------------------------------------------------------------------------
+REF_TRACKS_SO = os.path.join(ORACLE_DIR, "_ref", "libref_tracks.so")
+_ref_tracks = None
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+
+
+def ref_tracks():
+    global _ref_tracks
+    if _ref_tracks is None and os.path.exists(REF_TRACKS_SO):
+        _ref_tracks = C.CDLL(REF_TRACKS_SO)
+    return _ref_tracks
+
+
+def _tracks_call(fn, view_sizes, colors, pairs, pair_offsets, corr, with_invalid):
+    view_sizes = np.ascontiguousarray(view_sizes, dtype=np.int32)
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    pair_offsets = np.ascontiguousarray(pair_offsets, dtype=np.int64)
+    corr = np.ascontiguousarray(corr, dtype=np.int32).reshape(-1, 2)
+    total = int(view_sizes.sum())
+    nm = corr.shape[0]
+    ids = np.zeros(max(total, 1), dtype=np.int32)
+    toff = np.zeros(max(nm, 1) + 1, dtype=np.int64)
+    tfeat = np.zeros((max(2 * nm, 1), 2), dtype=np.int32)
+    tcol = np.zeros((max(nm, 1), 3), dtype=np.uint8)
+    col = None if colors is None else np.ascontiguousarray(colors, dtype=np.uint8).reshape(-1, 3)
+    args = [len(view_sizes), view_sizes.ctypes.data_as(C.c_void_p),
+            None if col is None else col.ctypes.data_as(C.c_void_p),
+            pairs.shape[0], pairs.ctypes.data_as(C.c_void_p), pair_offsets.ctypes.data_as(C.c_void_p),
+            corr.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p),
+            C.c_int64(max(nm, 1)), C.c_int64(max(2 * nm, 1)), toff.ctypes.data_as(C.c_void_p),
+            tfeat.ctypes.data_as(C.c_void_p), tcol.ctypes.data_as(C.c_void_p)]
+    inv = C.c_int32(-1)
+    if with_invalid:
+        args.append(C.byref(inv))
+    fn.restype = C.c_int
+    nt = fn(*args)
+    assert nt >= 0
+    nf = int(toff[nt])
+    return {"track_ids": ids[:total], "track_offsets": toff[:nt + 1], "track_features": tfeat[:nf],
+            "track_colors": tcol[:nt], "num_invalid": inv.value}
+
+
+def oracle_tracks(view_sizes, colors, pairs, pair_offsets, corr):
+    return _tracks_call(oracle().oracle_tracks_compute, view_sizes, colors, pairs, pair_offsets, corr, True)
+
+
+def ref_tracks_compute(view_sizes, colors, pairs, pair_offsets, corr):
+    return _tracks_call(ref_tracks().ref_tracks_compute, view_sizes, colors, pairs, pair_offsets, corr, False)

@@ -1,0 +1,105 @@
+"""Track building: sfm::bundler::Tracks::compute.
+
+Host code on both sides, so everything here runs without a GPU:
+  * the oracle (oracle/tracks_oracle.c) is PINNED against the reference's own
+    bundler_tracks.cc (oracle/_ref/libref_tracks.so, live and randomised, when
+    /root/reference was present at build time) and against golden vectors the
+    reference produced (tests/golden/tracks_*.npz, generator committed);
+  * the product (osfm_tracks_compute, linked lists instead of per-track
+    vectors) is compared with goldens and oracle element for element: track
+    order, feature order inside tracks, per-feature track ids, colours."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import track_cases
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+KEYS = ("track_ids", "track_offsets", "track_features", "track_colors")
+
+
+def product(m):
+    from orthosfm_amd import capi, tracks
+    pairs = (capi.Pair * max(len(m["pairs"]), 1))()
+    for i, (a, b) in enumerate(m["pairs"]):
+        pairs[i].view_1, pairs[i].view_2 = int(a), int(b)
+    ids, toff, tfeat, tcol, summary = tracks.compute_flat(m["view_sizes"], m["colors"], pairs, m["pair_offsets"],
+                                                           np.ascontiguousarray(m["corr"], dtype=np.int32))
+    return {"track_ids": ids, "track_offsets": toff, "track_features": tfeat, "track_colors": tcol,
+            "num_invalid": summary.num_invalid_tracks}
+
+
+def same(a, b):
+    for k in KEYS:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+@pytest.mark.parametrize("name", sorted(track_cases.CASES))
+def test_oracle_and_product_match_reference_golden(name):
+    g = np.load(os.path.join(GOLDEN, f"tracks_{name}.npz"))
+    m = {k: g[k] for k in ("view_sizes", "colors", "pairs", "pair_offsets", "corr")}
+    want = {k: g["out_" + k] for k in KEYS}
+    # the golden inputs are what the generator builds today
+    regen = track_cases.random_matching(**track_cases.CASES[name])
+    for k in m:
+        np.testing.assert_array_equal(m[k], regen[k])
+    same(oracle_lib.oracle_tracks(**m), want)
+    same(product(m), want)
+
+
+@pytest.mark.skipif(oracle_lib.ref_tracks() is None, reason="oracle/_ref/libref_tracks.so not built")
+@pytest.mark.parametrize("seed", range(12))
+def test_oracle_pinned_against_reference_live(seed):
+    rng = np.random.default_rng(100 + seed)
+    m = track_cases.random_matching(num_views=int(rng.integers(2, 12)), feats_per_view=int(rng.integers(5, 150)),
+                                    num_scene_points=int(rng.integers(5, 250)), p_seen=float(rng.uniform(0.2, 0.9)),
+                                    p_false=float(rng.choice([0.0, 0.05, 0.3])), seed=seed)
+    ref = oracle_lib.ref_tracks_compute(**m)
+    orc = oracle_lib.oracle_tracks(**m)
+    same(orc, ref)
+    got = product(m)
+    same(got, ref)
+    assert got["num_invalid"] == orc["num_invalid"]
+
+
+def test_edge_cases():
+    from orthosfm_amd import capi
+    empty = {"view_sizes": np.array([3, 4], np.int32), "colors": None, "pairs": np.zeros((0, 2), np.int32),
+             "pair_offsets": np.zeros(1, np.int64), "corr": np.zeros((0, 2), np.int32)}
+    out = product(empty)
+    assert (out["track_ids"] == -1).all() and len(out["track_offsets"]) == 1
+    # a chain 0-1, 1-2 and a conflicting second feature of view 0: the merged track is invalid
+    m = {"view_sizes": np.array([2, 1, 1], np.int32), "colors": np.arange(12, dtype=np.uint8).reshape(4, 3),
+         "pairs": np.array([[1, 0], [2, 1], [2, 0]], np.int32), "pair_offsets": np.array([0, 1, 2, 3], np.int64),
+         "corr": np.array([[0, 0], [0, 0], [0, 1]], np.int32)}
+    out, orc = product(m), oracle_lib.oracle_tracks(**m)
+    same(out, orc)
+    assert out["num_invalid"] == 1 and len(out["track_offsets"]) == 1 and (out["track_ids"] == -1).all()
+    # a draw in unify_tracks keeps the FIRST track's features in front (bundler_tracks.cc:28-31)
+    m = {"view_sizes": np.array([1, 1, 1, 1], np.int32), "colors": None,
+         "pairs": np.array([[1, 0], [3, 2], [2, 1]], np.int32), "pair_offsets": np.array([0, 1, 2, 3], np.int64),
+         "corr": np.zeros((3, 2), np.int32)}
+    out = product(m)
+    same(out, oracle_lib.oracle_tracks(**m))
+    np.testing.assert_array_equal(out["track_features"][:, 0], [3, 2, 1, 0])   # view1_tid = track of view 2
+    # out-of-range input is refused, not read
+    bad = dict(m, corr=np.array([[0, 0], [0, 0], [5, 0]], np.int32))
+    with pytest.raises(capi.OsfmError):
+        product(bad)
+
+
+def test_mirror_class_and_scale():
+    from orthosfm_amd.matching import TwoViewMatching
+    from orthosfm_amd.tracks import Tracks, Viewport
+    m = track_cases.random_matching(num_views=30, feats_per_view=4000, num_scene_points=6000, p_seen=0.4, seed=9)
+    viewports = [Viewport(4000, m["colors"][v * 4000:(v + 1) * 4000]) for v in range(30)]
+    matching = [TwoViewMatching(int(a), int(b), m["corr"][m["pair_offsets"][i]:m["pair_offsets"][i + 1]])
+                for i, (a, b) in enumerate(m["pairs"])]
+    tracks = Tracks().compute(matching, viewports)
+    orc = oracle_lib.oracle_tracks(**m)
+    assert len(tracks) == len(orc["track_offsets"]) - 1 > 1000
+    np.testing.assert_array_equal(np.concatenate([vp.track_ids for vp in viewports]), orc["track_ids"])
+    np.testing.assert_array_equal(np.concatenate([t.features for t in tracks]), orc["track_features"])
+    np.testing.assert_array_equal(np.stack([t.color for t in tracks]), orc["track_colors"])
