@@ -328,7 +328,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_MFMA_PEAK_TOPS,
                          "unit": "TFLOP/s", "frac": achieved / I8_MFMA_PEAK_TOPS,
                          "traffic": pmc_traffic_per_launch(len(my_pairs) * args.steps / max(kern_launches, 1)),
-                         "kernel": "match_tile_kernel<8, false, true>", "launches_per_step": kern_launches / args.steps,
+                         "kernel": "match_tile_kernel<8, false, true, true>", "launches_per_step": kern_launches / args.steps,
                          "avg_launch_ms": avg_launch_s * 1e3,
                          "hbm_algorithmic_GBs": (st.algorithmic_bytes / max(st.tile_kernel_launches, 1))
                                                 / max(avg_launch_s, 1e-12) / 1e9},

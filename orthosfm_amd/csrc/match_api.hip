@@ -160,6 +160,7 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
     int total_blocks[2] = {0, 0}, max_n[2] = {0, 0};
     bool needs_mask[2] = {false, false};   // some problem is limited below its view size
     bool any_special[2] = {false, false};  // some problem has gathered special rows
+    bool any_c0[2] = {false, false}, any_corrected[2] = {false, false};
     int64_t macs = 0, alg_bytes = 0;
 
     for (int p = 0; p < num_pairs; ++p) {
@@ -209,6 +210,11 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
             const bool empty = pr.n1 == 0 || pr.n2 == 0;
             if (limited) needs_mask[type] = true;
             if (!empty && n_special > 0) any_special[type] = true;
+            // correction-free column operand: SURF bytes are the values; SIFT views
+            // without a value > 127 (the raw copy then holds every descriptor)
+            pr.B_raw = (type == 0 ? b.sift_raw : b.surf).as<int8_t>();
+            pr.c0 = (type == 1 || b.n_special == 0) ? 1 : 0;
+            if (!empty && !limited) (pr.c0 ? any_c0 : any_corrected)[type] = true;
             pr.nrb_main = empty ? 0 : (pr.n1 + kRowsPerBlock - 1) / kRowsPerBlock;
             pr.nrb = pr.nrb_main + (empty ? 0 : (n_special + kRowsPerBlock - 1) / kRowsPerBlock);
             pr.nseg = empty ? 0 : (pr.n2 + kSegCols - 1) / kSegCols;
@@ -280,7 +286,8 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
         int32_t *ecount = m->exact_count.as<int32_t>() + type;
 
         if (total_blocks[type] > 0) { OSFM_HIP_CHECK(hipEventRecord(m->ev[type][0], s)); timed[type] = true; }
-        launch_match_tiles(type == 0 ? 8 : 4, needs_mask[type], any_special[type], dp, np, total_blocks[type],
+        launch_match_tiles(type == 0 ? 8 : 4, needs_mask[type], any_special[type], any_c0[type],
+            any_corrected[type], dp, np, total_blocks[type],
             m->rowparts.as<RowPart>(), m->colparts.as<ColPart>(), s);
         if (timed[type]) OSFM_HIP_CHECK(hipEventRecord(m->ev[type][1], s));
         launch_match_finish(dp, np, max_n[type], m->rowparts.as<RowPart>(),

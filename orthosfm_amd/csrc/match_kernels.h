@@ -41,7 +41,12 @@ struct MatchProblem {
     const int32_t *special_map;    // [n_special] original row of a special slot
     const int32_t *special_slot;   // [n1] slot of a row or -1 (null when n_special == 0)
     int32_t n_special;
-    int32_t pad_;
+    // c0 != 0: every descriptor of set 2 fits int8 as it is (SURF always; SIFT
+    // when the view has no value > 127, the normal case: MVE's SIFT bytes stay
+    // below 128).  Then the RAW row blocks take B_raw as column operand as well,
+    // ip = sum(a * b) needs no correction at all and the MFMA C operand is 0.
+    int32_t c0;
+    const int8_t *B_raw;
 };
 
 struct RowPart { int32_t ip_best, idx_best, ip_second, pad; };
@@ -58,8 +63,10 @@ struct LoweTable {
 // wrap-around arithmetic (nearest_neighbor.cc:75-84 and the T-typed state).
 struct ExactItem { int32_t problem; int32_t dir; int32_t query; };
 
-// any_special: some problem has row blocks behind nrb_main (gathered special rows)
-void launch_match_tiles(int ch, bool masked, bool any_special, const MatchProblem *d_problems,
+// any_special: some problem has row blocks behind nrb_main (gathered special rows);
+// any_c0 / any_corrected: some problem has / lacks the correction-free column operand
+void launch_match_tiles(int ch, bool masked, bool any_special, bool any_c0, bool any_corrected,
+    const MatchProblem *d_problems,
     int num_problems, int total_blocks, RowPart *rowparts, ColPart *colparts, hipStream_t s);
 
 void launch_match_finish(const MatchProblem *d_problems, int num_problems,

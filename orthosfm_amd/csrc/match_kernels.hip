@@ -138,11 +138,13 @@ template <int V> struct IntC { static constexpr int value = V; };
 // only), and the best column is recovered by the group rescan of the finish
 // kernel.  RAW = false: value-128 row operand with per-score keys
 // (ip << 8 | tile) carrying the column correction.
-template <int CH, bool MASKED, bool RAW>
+// C0 (RAW only): both operands in raw form, no correction anywhere, C = 0.
+template <int CH, bool MASKED, bool RAW, bool C0>
 __device__ __forceinline__ void
 tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowparts,
     ColPart *__restrict__ colparts, char *smem)
 {
+    static_assert(!C0 || RAW, "the correction-free form needs the raw row operand");
     constexpr int D = CH * 16;
     constexpr int KS = CH / 2;            // MFMA k-steps (K = 32 bytes each)
     constexpr int RPB = 16 / CH;          // descriptor rows per 256-B LDS bank row
@@ -163,7 +165,7 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
     // problem fields used inside the tile loop, read once (the loop's LDS
     // traffic would otherwise force scalar re-loads and lgkmcnt(0) waits)
     const int n1 = pd.n1, n2 = pd.n2, n2stride = pd.n2stride;
-    const int8_t *const Bbase = pd.B;
+    const int8_t *const Bbase = C0 ? pd.B_raw : pd.B;
     const int32_t *const corrBbase = pd.corrB;
     ColPart *const colout = colparts + pd.colpart_off + (int64_t)rb * pd.n2stride;
     const int tid = threadIdx.x;
@@ -190,8 +192,9 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
             a[rf][ks] = *reinterpret_cast<const v4i *>(arow + (ks * 2 + lh) * 16);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            ra[rf][r] = corrA[arow0 + rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+            ra[rf][r] = C0 ? 0 : corrA[arow0 + rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
     }
+    const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned row_valid_bits = 0xffffffffu;
     if (MASKED) {
         row_valid_bits = 0;
@@ -269,7 +272,7 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
         for (int i = 0; i < NCHUNK; ++i) {
             const int cf = i / KS, ks = i % KS;
             if (ks == 0)
-                nxt[cf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[PH ^ 1][0], b[cf][0], ra[PH ^ 1], 0, 0, 0);
+                nxt[cf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[PH ^ 1][0], b[cf][0], C0 ? zero16 : ra[PH ^ 1], 0, 0, 0);
             else
                 nxt[cf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[PH ^ 1][ks], b[cf][ks], nxt[cf], 0, 0, 0);
             // The B registers of a column group are free once phase 0 (second half
@@ -328,7 +331,7 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
     load_b(0, 1);
 #pragma unroll
     for (int cf = 0; cf < 2; ++cf) {
-        acc0[cf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][0], b[cf][0], ra[0], 0, 0, 0);
+        acc0[cf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][0], b[cf][0], C0 ? zero16 : ra[0], 0, 0, 0);
 #pragma unroll
         for (int ks = 1; ks < KS; ++ks)
             acc0[cf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0][ks], b[cf][ks], acc0[cf], 0, 0, 0);
@@ -461,9 +464,10 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
 
 // RAW = true runs the row blocks [0, nrb_main) of every problem, RAW = false the
 // blocks of gathered special rows behind them (and everything of a MASKED
-// launch); a block of the other kind returns at once.  Two kernels rather than
-// one with both bodies: the register budget of each is its own.
-template <int CH, bool MASKED, bool RAW>
+// launch); C0 selects the problems whose column operand is correction-free.  A
+// block of another kind returns at once.  Separate kernels rather than one
+// with all bodies: the register budget of each is its own.
+template <int CH, bool MASKED, bool RAW, bool C0>
 __global__ __launch_bounds__(256, 2) void
 match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, int total_blocks,
     RowPart *__restrict__ rowparts, ColPart *__restrict__ colparts)
@@ -481,26 +485,27 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
     const int rb = local / pd.nseg;
     const int seg = local - rb * pd.nseg;
     if (!MASKED && (rb < pd.nrb_main) != RAW) return;
-    tile_body<CH, MASKED, RAW>(pd, rb, seg, rowparts, colparts, smem);
+    if (RAW && (pd.c0 != 0) != C0) return;
+    tile_body<CH, MASKED, RAW, C0>(pd, rb, seg, rowparts, colparts, smem);
 }
 
-void launch_match_tiles(int ch, bool masked, bool any_special, const MatchProblem *d_problems,
-    int num_problems, int total_blocks, RowPart *rowparts, ColPart *colparts, hipStream_t s)
+void launch_match_tiles(int ch, bool masked, bool any_special, bool any_c0, bool any_corrected,
+    const MatchProblem *d_problems, int num_problems, int total_blocks, RowPart *rowparts,
+    ColPart *colparts, hipStream_t s)
 {
     if (total_blocks <= 0) return;
     const int d = ch * 16;
     const size_t lds = std::max<size_t>(2 * (size_t)kTileCols * d, 16384) + 2 * 64 * 4 + 8 * 4 * 64 * sizeof(ColPart) + 32 * 256 * 4;
     const dim3 grid(total_blocks), block(256);
-#define OSFM_LAUNCH_TILES(CHV, MASKEDV, RAWV) \
-    hipLaunchKernelGGL((match_tile_kernel<CHV, MASKEDV, RAWV>), grid, block, lds, s, d_problems, num_problems, total_blocks, rowparts, colparts)
+#define OSFM_LAUNCH_TILES(CHV, MASKEDV, RAWV, C0V) \
+    hipLaunchKernelGGL((match_tile_kernel<CHV, MASKEDV, RAWV, C0V>), grid, block, lds, s, d_problems, num_problems, total_blocks, rowparts, colparts)
     if (masked) {
-        if (ch == 8) OSFM_LAUNCH_TILES(8, true, false); else OSFM_LAUNCH_TILES(4, true, false);
-    } else {
-        if (ch == 8) OSFM_LAUNCH_TILES(8, false, true); else OSFM_LAUNCH_TILES(4, false, true);
-        if (any_special) {
-            if (ch == 8) OSFM_LAUNCH_TILES(8, false, false); else OSFM_LAUNCH_TILES(4, false, false);
-        }
+        if (ch == 8) OSFM_LAUNCH_TILES(8, true, false, false); else OSFM_LAUNCH_TILES(4, true, false, false);
+        return;
     }
+    if (any_c0) { if (ch == 8) OSFM_LAUNCH_TILES(8, false, true, true); else OSFM_LAUNCH_TILES(4, false, true, true); }
+    if (any_corrected) { if (ch == 8) OSFM_LAUNCH_TILES(8, false, true, false); else OSFM_LAUNCH_TILES(4, false, true, false); }
+    if (any_special) { if (ch == 8) OSFM_LAUNCH_TILES(8, false, false, false); else OSFM_LAUNCH_TILES(4, false, false, false); }
 #undef OSFM_LAUNCH_TILES
 }
 

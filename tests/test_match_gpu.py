@@ -280,3 +280,34 @@ def test_special_rows_large_values(hm):
     got = m.pairwise_match(1, 0)
     assert np.array_equal(got.matches_1_2, c21) and np.array_equal(got.matches_2_1, c12)
     m.close()
+
+
+def test_mixed_operand_forms_in_one_batch(hm):
+    """One compute() over views with and without entries > 127: the launch then
+    holds problems for all three kernel kinds (correction-free raw operands,
+    raw rows against corrected columns, gathered special rows), and SURF rides
+    along.  Every pair against the oracle."""
+    from orthosfm_amd import capi
+    iset = synth.make_image_set(4, 1200, n_surf=150, config_id=12)
+    r = np.random.default_rng(21)
+    for v in (1, 3):                                   # views 1 and 3 get large values, 0 and 2 stay plain
+        rows = r.choice(1200, 150, replace=False)
+        for k in rows:
+            d = iset.sift[v][k].copy()
+            d[r.choice(128, 2, replace=False)] = [int(r.integers(128, 256)), int(r.integers(128, 200))]
+            iset.sift[v][k] = d
+    o = capi.default_match_options()
+    o.use_lowres_matching = 0
+    o.min_feature_matches = 0
+    m = hm(4, options=o)
+    for v in range(4):
+        m.set_view(v, iset.sift[v], iset.surf[v])
+    out = m.compute()
+    assert len(out) == 6
+    for tv in out:
+        a, b = tv.view_1_id, tv.view_2_id
+        e12, _ = oracle_lib.oracle_pairwise_match(iset.sift[a], iset.surf[a], iset.sift[b], iset.surf[b])
+        idx = np.nonzero(e12 >= 0)[0]
+        exp = np.stack([idx, e12[idx]], axis=1).astype(np.int32)
+        assert tv.status == capi.PAIR_MATCHED and np.array_equal(tv.matches, exp), (a, b)
+    m.close()

@@ -6,7 +6,7 @@ import csv
 import json
 import sys
 
-KERNEL = "match_tile_kernel<8, false, true>"
+KERNEL = "match_tile_kernel<8, false, true, true>"
 
 
 def total(path, counter):
