@@ -511,3 +511,145 @@ def oracle_tracks(view_sizes, colors, pairs, pair_offsets, corr):
 
 def ref_tracks_compute(view_sizes, colors, pairs, pair_offsets, corr):
     return _tracks_call(ref_tracks().ref_tracks_compute, view_sizes, colors, pairs, pair_offsets, corr, False)
+
+
+# ---------------------------------------------------------------------------
+# cascade hashing: oracle (oracle/cashash_oracle.c) and the reference's own
+# cascade_hashing.{h,cc} behind oracle/_ref/libref_cashash.so
+# ---------------------------------------------------------------------------
+REF_CASHASH_SO = os.path.join(ORACLE_DIR, "_ref", "libref_cashash.so")
+_ref_cashash = None
+CASHASH_GROUPS, CASHASH_BITS, CASHASH_MIN, CASHASH_MAX = 6, 8, 6, 10   # CascadeHashing::Options defaults
+
+
+def ref_cashash():
+    global _ref_cashash
+    if _ref_cashash is None and os.path.exists(REF_CASHASH_SO):
+        _ref_cashash = C.CDLL(REF_CASHASH_SO)
+        _ref_cashash.ref_cashash_create.restype = C.c_void_p
+    return _ref_cashash
+
+
+class RefCasHash:
+    """The reference's sfm::CascadeHashing on u16 / s16 descriptor arrays."""
+
+    def __init__(self, sifts, surfs):
+        lib = ref_cashash()
+        self.lib = lib
+        self.n_sift = [s.shape[0] for s in sifts]
+        self.n_surf = [s.shape[0] for s in surfs]
+        self.h = C.c_void_p(lib.ref_cashash_create(len(sifts)))
+        for v, (s, u) in enumerate(zip(sifts, surfs)):
+            # exact inverse of the reference's quantisation (exhaustive_matching.cc:17-38)
+            sf = np.ascontiguousarray(s.astype(np.float32) / np.float32(255.0))
+            uf = np.ascontiguousarray(u.astype(np.float32) / np.float32(127.0))
+            lib.ref_cashash_set_view(self.h, v, sf.ctypes.data_as(C.c_void_p), s.shape[0],
+                                     uf.ctypes.data_as(C.c_void_p), u.shape[0])
+        lib.ref_cashash_init(self.h)
+
+    def proj(self, type_):
+        dim = 128 if type_ == 0 else 64
+        prim = np.zeros((dim, dim), np.float32)
+        sec = np.zeros((CASHASH_GROUPS, CASHASH_BITS, dim), np.float32)
+        self.lib.ref_cashash_get_proj(self.h, type_, prim.ctypes.data_as(C.c_void_p), sec.ctypes.data_as(C.c_void_p))
+        return prim, sec
+
+    def local(self, type_, view):
+        n = (self.n_sift if type_ == 0 else self.n_surf)[view]
+        words = 2 if type_ == 0 else 1
+        hashes = np.zeros((max(n, 1), words), np.uint64)
+        ids = np.zeros((CASHASH_GROUPS, max(n, 1)), np.uint16)
+        if n:
+            tmp = np.zeros((CASHASH_GROUPS, n), np.uint16)
+            self.lib.ref_cashash_get_local(self.h, type_, view, hashes.ctypes.data_as(C.c_void_p),
+                                           tmp.ctypes.data_as(C.c_void_p))
+            ids = tmp
+        return hashes[:n], ids[:, :n]
+
+    def pairwise_match(self, v1, v2):
+        n1 = self.n_sift[v1] + self.n_surf[v1]
+        n2 = self.n_sift[v2] + self.n_surf[v2]
+        o12 = np.full(max(n1, 1), -7, np.int32)
+        o21 = np.full(max(n2, 1), -7, np.int32)
+        l12, l21 = C.c_int(), C.c_int()
+        self.lib.ref_cashash_pairwise_match(self.h, v1, v2, o12.ctypes.data_as(C.c_void_p), C.byref(l12),
+                                            o21.ctypes.data_as(C.c_void_p), C.byref(l21))
+        return o12[:l12.value].copy(), o21[:l21.value].copy()
+
+    def close(self):
+        if self.h:
+            self.lib.ref_cashash_destroy(self.h)
+            self.h = None
+
+
+def oracle_cashash_proj(dim):
+    lib = oracle()
+    prim = np.zeros((dim, dim), np.float32)
+    sec = np.zeros((CASHASH_GROUPS, CASHASH_BITS, dim), np.float32)
+    lib.oracle_cashash_proj_matrices(dim, CASHASH_GROUPS, CASHASH_BITS, prim.ctypes.data_as(C.c_void_p),
+                                     sec.ctypes.data_as(C.c_void_p))
+    return prim, sec
+
+
+def oracle_cashash_avg(desc_list, dim, div):
+    lib = oracle()
+    cat = np.ascontiguousarray(np.concatenate([d.reshape(-1, dim) for d in desc_list]).astype(np.int32))
+    avg = np.zeros(dim, np.float32)
+    lib.oracle_cashash_avg(cat.ctypes.data_as(C.c_void_p), C.c_int64(cat.shape[0]), dim, C.c_float(div),
+                           avg.ctypes.data_as(C.c_void_p))
+    return avg
+
+
+def oracle_cashash_hashes(desc, dim, div, avg, prim, sec):
+    lib = oracle()
+    d = np.ascontiguousarray(desc.reshape(-1, dim).astype(np.int32))
+    n = d.shape[0]
+    hashes = np.zeros((max(n, 1), dim // 64), np.uint64)
+    ids = np.zeros((CASHASH_GROUPS, max(n, 1)), np.uint16)
+    if n:
+        ids = np.zeros((CASHASH_GROUPS, n), np.uint16)
+        lib.oracle_cashash_hashes(d.ctypes.data_as(C.c_void_p), n, dim, C.c_float(div), avg.ctypes.data_as(C.c_void_p),
+                                  prim.ctypes.data_as(C.c_void_p), sec.ctypes.data_as(C.c_void_p), CASHASH_GROUPS,
+                                  CASHASH_BITS, hashes.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p))
+    return hashes[:n], ids[:, :n]
+
+
+def oracle_cashash_oneway(is_signed, d1, h1, b1, d2, h2, b2, lowe, dist=np.finfo(np.float32).max):
+    lib = oracle()
+    dim = 64 if is_signed else 128
+    dt = np.int16 if is_signed else np.uint16
+    d1 = np.ascontiguousarray(d1.reshape(-1, dim).astype(dt))
+    d2 = np.ascontiguousarray(d2.reshape(-1, dim).astype(dt))
+    h1, h2 = np.ascontiguousarray(h1), np.ascontiguousarray(h2)
+    b1, b2 = np.ascontiguousarray(b1), np.ascontiguousarray(b2)
+    res = np.full(max(d1.shape[0], 1), -1, np.int32)
+    lib.oracle_cashash_oneway(int(is_signed), dim, CASHASH_GROUPS, CASHASH_BITS,
+                              d1.ctypes.data_as(C.c_void_p), d1.shape[0], h1.ctypes.data_as(C.c_void_p),
+                              b1.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p), d2.shape[0],
+                              h2.ctypes.data_as(C.c_void_p), b2.ctypes.data_as(C.c_void_p), C.c_float(lowe),
+                              C.c_float(dist), CASHASH_MIN, CASHASH_MAX, res.ctypes.data_as(C.c_void_p))
+    return res[:d1.shape[0]]
+
+
+class OracleCasHash:
+    """All stages of the oracle chained like CascadeHashing::init / pairwise_match."""
+
+    def __init__(self, sifts, surfs, sift_lowe=0.8, surf_lowe=0.7):
+        self.sifts, self.surfs = sifts, surfs
+        self.lowe = (sift_lowe, surf_lowe)
+        self.proj = [oracle_cashash_proj(128), oracle_cashash_proj(64)]
+        self.avg = [oracle_cashash_avg(sifts, 128, 255.0), oracle_cashash_avg(surfs, 64, 127.0)]
+        self.local = [[oracle_cashash_hashes(s, 128, 255.0, self.avg[0], *self.proj[0]) for s in sifts],
+                      [oracle_cashash_hashes(u, 64, 127.0, self.avg[1], *self.proj[1]) for u in surfs]]
+
+    def pairwise_match(self, v1, v2):
+        """cascade_hashing.cc:73-104 (sizes as the exhaustive matcher reports them)."""
+        om = oracle_matcher()
+        parts = []
+        for t, descs in enumerate((self.sifts, self.surfs)):
+            a, b = descs[v1], descs[v2]
+            (h1, b1), (h2, b2) = self.local[t][v1], self.local[t][v2]
+            m12 = oracle_cashash_oneway(t, a, h1, b1, b, h2, b2, self.lowe[t])
+            m21 = oracle_cashash_oneway(t, b, h2, b2, a, h1, b1, self.lowe[t])
+            parts.append(om.remove_inconsistent(m12, m21))
+        return om.combine(parts[0][0], parts[0][1], parts[1][0], parts[1][1])
