@@ -123,6 +123,54 @@ def ba_cpu_baseline(iterations=2):
                       "(residual/Jacobian evaluation and the dense Cholesky trailing updates OpenMP-parallel, Schur accumulation serial)"}
 
 
+def cascade_bench(iset, V, pairs, capacity, device_index, with_cpu):
+    """The same pairs through the cascade-hashing mode (sfm::CascadeHashing, the
+    application's default, approximate matcher).  CPU baseline: the reference's
+    own cascade_hashing.cc when oracle/_ref travelled (its pairwise_match on a
+    sample of pairs, all host threads via its OpenMP init, matching single
+    threaded per pair as in one iteration of bundler::Matching::compute's loop)."""
+    from orthosfm_amd.matching import HipCascadeHashing
+    m = HipCascadeHashing(V, device=device_index, copy_results=False)
+    for v in range(V):
+        m.set_view(v, iset.sift[v])
+    t0 = time.perf_counter()
+    m.cascade_hashes(0, 0)
+    init_s = time.perf_counter() - t0
+    m.compute(pairs, capacity=capacity)
+    t0 = time.perf_counter()
+    out = m.compute(pairs, capacity=capacity)
+    dt = time.perf_counter() - t0
+    st = m.stats()
+    res = {"workload": f"{len(pairs)} pairs, cascade hashing (6 bucket groups x 256 buckets, 6..10 candidates)",
+           "pairs_per_s": len(pairs) / dt, "ms_per_step": dt * 1e3, "hash_init_ms": init_s * 1e3,
+           "kernel_ms": st.cashash_kernel_ms,
+           "correspondences": int(sum(tv.num_matches for tv in out if tv.status == capi_mod().PAIR_MATCHED))}
+    m.close()
+    if with_cpu:
+        import oracle_lib
+        if oracle_lib.ref_cashash() is not None:
+            nv = min(V, 6)
+            empty = [np.zeros((0, 64), np.int16)] * nv
+            t0 = time.perf_counter()
+            ref = oracle_lib.RefCasHash(iset.sift[:nv], empty)
+            t_init = time.perf_counter() - t0
+            sample = [(a, b) for a in range(nv) for b in range(a)]
+            t0 = time.perf_counter()
+            for a, b in sample:
+                ref.pairwise_match(a, b)
+            dtc = time.perf_counter() - t0
+            ref.close()
+            res["cpu_baseline"] = {"value": len(sample) / dtc, "unit": "pairs/s", "cores": 1, "kind": "reference",
+                                   "sample": f"{len(sample)} pairs of the first {nv} views, {dtc:.1f} s "
+                                             f"(hash init of those views {t_init:.2f} s not included)"}
+    return res
+
+
+def capi_mod():
+    from orthosfm_amd import capi
+    return capi
+
+
 def tracks_bench(out, V, F, with_cpu):
     """Tracks::compute (bundler_tracks.cc:49-145) over the match lists this run
     produced: host code in the reference and here; the CPU baseline is the
@@ -284,6 +332,13 @@ def main():
                     "inliers_rank0": int(sum(tv.num_inliers for tv in outv if tv.status == capi.PAIR_MATCHED))}
         m2.close()
 
+    cascade = None
+    if rank == 0 and world == 1 and not args.no_ba and not args.no_verify:
+        try:
+            cascade = cascade_bench(iset, V, my_pairs, capacity, device_index, not args.no_cpu_baseline)
+        except Exception as e:
+            cascade = {"error": str(e)}
+
     tracks = None
     if rank == 0 and world == 1 and not args.no_ba:
         try:
@@ -338,6 +393,8 @@ def main():
         }
         if tracks is not None:
             line["tracks"] = tracks
+        if cascade is not None:
+            line["cascade_hashing"] = cascade
         if verified is not None:
             line["with_geometric_verification"] = verified
         if ba is not None:

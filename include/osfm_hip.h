@@ -48,6 +48,15 @@ OSFM_API int osfm_device_count(void);
  * with the values the application hard-codes
  * (src/matching/matching_mve.cpp:393-408).
  */
+/* Matcher behind pairwise_match (bundler_matching.cc:31-41).  Cascade hashing
+ * is sfm::CascadeHashing with its default Options (6 bucket groups of 2^8
+ * buckets, 6..10 candidates, cascade_hashing.h:35-47); its hashes are computed
+ * from ALL views (the descriptor average, cascade_hashing.cc:128-163), lazily
+ * at the first match call after a view was set.  pairwise_match_lowres stays
+ * exhaustive in both (CascadeHashing inherits it). */
+#define OSFM_MATCHER_EXHAUSTIVE 0
+#define OSFM_MATCHER_CASCADE_HASHING 1
+
 typedef struct osfm_match_options {
     float sift_lowe_ratio;          /* 0.8f   matching_base.h:27 */
     float sift_distance_threshold;  /* FLT_MAX                    */
@@ -63,7 +72,8 @@ typedef struct osfm_match_options {
     int32_t ransac_max_iterations;  /* 1000   ransac_fundamental.h:42 */
     double ransac_threshold;        /* 0.0015 matching_mve.cpp:395 */
     int32_t min_matching_inliers;   /* 30     matching_mve.cpp:402 */
-    int32_t reserved0;
+    int32_t matcher_type;      /* OSFM_MATCHER_EXHAUSTIVE (default) or OSFM_MATCHER_CASCADE_HASHING:
+                                * bundler::Matching::MatcherType, bundler_matching.h:52-56 */
     uint64_t ransac_seed;           /* stream seed of the counter-based sampler */
 } osfm_match_options;
 
@@ -189,8 +199,17 @@ typedef struct osfm_match_stats {
     int32_t lowres_kernel_launches;
     int32_t reserved;
     int64_t lowres_mac_count;
+    double cashash_kernel_ms;    /* cascade hashing mode: candidate search + NN kernel */
+    int32_t cashash_kernel_launches;
+    int32_t reserved1;
 } osfm_match_stats;
 OSFM_API int osfm_match_get_stats(const osfm_matcher *m, osfm_match_stats *out);
+
+/* CascadeHashing::LocalData of one view (cascade_hashing.h:146-168), computed on
+ * demand: hashes [n][2] (SIFT, type 0) or [n][1] (SURF, type 1) 64-bit words,
+ * bucket_ids [6][n] (ids < 256).  Either output may be NULL. */
+OSFM_API int osfm_match_get_cascade_hashes(osfm_matcher *m, int view, int type,
+    uint64_t *hashes, uint8_t *bucket_ids);
 
 /* RansacFundamental::Options (src/mve/sfm/ransac_fundamental.h:33-54). */
 typedef struct osfm_ransac_options {

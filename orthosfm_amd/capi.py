@@ -30,6 +30,7 @@ class OsfmError(RuntimeError):
 
 
 OK, E_ARG, E_DEVICE, E_RANGE, E_CAPACITY, E_STATE, E_NUMERIC = 0, -1, -2, -3, -4, -5, -6
+MATCHER_EXHAUSTIVE, MATCHER_CASCADE_HASHING = 0, 1
 PAIR_MATCHED, PAIR_REJECTED_LOWRES, PAIR_REJECTED_COUNT, PAIR_SKIPPED_EMPTY, PAIR_REJECTED_INLIERS = 0, 1, 2, 3, 4
 
 
@@ -41,7 +42,7 @@ class MatchOptions(C.Structure):
                 ("pairs_per_batch", C.c_int32),
                 ("geometric_verification", C.c_int32), ("ransac_max_iterations", C.c_int32),
                 ("ransac_threshold", C.c_double), ("min_matching_inliers", C.c_int32),
-                ("reserved0", C.c_int32), ("ransac_seed", C.c_uint64)]
+                ("matcher_type", C.c_int32), ("ransac_seed", C.c_uint64)]
 
 
 class RansacOptions(C.Structure):
@@ -63,7 +64,8 @@ class MatchStats(C.Structure):
                 ("exact_scan_queries", C.c_int32), ("mac_count", C.c_int64),
                 ("algorithmic_bytes", C.c_int64), ("lowres_kernel_ms", C.c_double),
                 ("lowres_kernel_launches", C.c_int32), ("reserved", C.c_int32),
-                ("lowres_mac_count", C.c_int64)]
+                ("lowres_mac_count", C.c_int64), ("cashash_kernel_ms", C.c_double),
+                ("cashash_kernel_launches", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class BaProblem(C.Structure):
@@ -114,7 +116,7 @@ EXPORTS = [
     "osfm_match_set_view", "osfm_match_set_view_float", "osfm_match_view_size", "osfm_match_set_positions",
     "osfm_ransac_options_default", "osfm_ransac_fundamental",
     "osfm_match_pair", "osfm_match_pair_lowres", "osfm_match_twoway", "osfm_match_all",
-    "osfm_pair_from_index", "osfm_match_get_stats",
+    "osfm_pair_from_index", "osfm_match_get_stats", "osfm_match_get_cascade_hashes",
     "osfm_ba_options_default", "osfm_ba_solve", "osfm_ba_reprojection_errors",
     "osfm_ba_triangulate",
     "osfm_nn_distances", "osfm_filter_outlier_tracks", "osfm_filter_reprojection",

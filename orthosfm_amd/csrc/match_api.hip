@@ -9,6 +9,8 @@
 #include <vector>
 
 #include "match_kernels.h"
+#include "cashash_kernels.h"
+#include <random>
 #include "osfm_common.h"
 #include "ransac_kernels.h"
 
@@ -40,6 +42,8 @@ struct ViewData {
     DeviceBuffer sift_raw, sift_raw_corr, special, special_corr, special_map, special_slot;
     int n_special = 0;
     int surf_norm2_max = 0;
+    // cascade hashing data per descriptor type (0: SIFT, 1: SURF), see cashash_kernels.h
+    DeviceBuffer cas_hash[2], cas_bucket[2], cas_start[2], cas_items[2], cas_rec[2];
     DeviceBuffer positions;      // [ns + nu][2] floats (geometric verification only)
     int n_positions = -1;
 };
@@ -103,6 +107,11 @@ struct osfm_matcher {
     DeviceBuffer d_jobs, d_inl, d_inl_count, d_corr2, d_gather_off;
     hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
 
+    // cascade hashing: projection matrices (transposed), running sums, average; the
+    // hashes depend on the average over ALL views, hence the dirty flag
+    DeviceBuffer cas_proj[2], cas_sum[2], cas_avg[2];
+    bool cas_dirty = true;
+
     osfm_match_stats stats;
 };
 
@@ -148,10 +157,16 @@ struct BatchMode {
     int type_mask = 3;        // bit 0: SIFT, bit 1: SURF
 };
 
+int ensure_cashash(osfm_matcher *m);
+
 int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const BatchMode &mode,
     BatchResult *res)
 {
     const int lowres_limit = mode.limit;
+    // CascadeHashing overrides pairwise_match only (cascade_hashing.h:49-56): limited
+    // (low-res / num_features) matching stays exhaustive
+    const bool cascade = m->opts.matcher_type == OSFM_MATCHER_CASCADE_HASHING && mode.limit == 0;
+    if (cascade) OSFM_RETURN_IF(ensure_cashash(m));
     res->plans.assign(num_pairs, PairPlan());
     res->counts.assign(num_pairs, 0);
     std::vector<MatchProblem> probs[2];
@@ -220,11 +235,21 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
             pr.nseg = empty ? 0 : (pr.n2 + kSegCols - 1) / kSegCols;
             pr.n2stride = round_up(pr.n2, 64);
             pr.block_start = total_blocks[type];
-            total_blocks[type] += pr.nrb * pr.nseg;
-            pr.rowpart_off = rowpart_recs;
-            rowpart_recs += (int64_t)pr.nseg * pr.nrb * kRowsPerBlock;
-            pr.colpart_off = colpart_recs;
-            colpart_recs += (int64_t)pr.nrb * pr.n2stride;
+            if (cascade) {
+                // no score tiles: the candidate search works on the hash data of the two views
+                const ViewData *vd[2] = {&a, &b};
+                for (int side = 0; side < 2; ++side) {
+                    pr.cas_rec[side] = vd[side]->cas_rec[type].ptr;
+                    pr.cas_start[side] = vd[side]->cas_start[type].as<int32_t>();
+                    pr.cas_items[side] = vd[side]->cas_items[type].as<int32_t>();
+                }
+            } else {
+                total_blocks[type] += pr.nrb * pr.nseg;
+                pr.rowpart_off = rowpart_recs;
+                rowpart_recs += (int64_t)pr.nseg * pr.nrb * kRowsPerBlock;
+                pr.colpart_off = colpart_recs;
+                colpart_recs += (int64_t)pr.nrb * pr.n2stride;
+            }
             // placed by offset into m->out after allocation (store offsets now)
             pr.m12 = reinterpret_cast<int32_t *>(pl.off12 + (type == 0 ? 0 : e1));
             pr.m21 = reinterpret_cast<int32_t *>(pl.off21 + (type == 0 ? 0 : e2));
@@ -285,15 +310,22 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
         const int ecap = (int)std::min<int64_t>(total_queries, 0x7fffffff);
         int32_t *ecount = m->exact_count.as<int32_t>() + type;
 
-        if (total_blocks[type] > 0) { OSFM_HIP_CHECK(hipEventRecord(m->ev[type][0], s)); timed[type] = true; }
-        launch_match_tiles(type == 0 ? 8 : 4, needs_mask[type], any_special[type], any_c0[type],
-            any_corrected[type], dp, np, total_blocks[type],
-            m->rowparts.as<RowPart>(), m->colparts.as<ColPart>(), s);
-        if (timed[type]) OSFM_HIP_CHECK(hipEventRecord(m->ev[type][1], s));
-        launch_match_finish(dp, np, max_n[type], m->rowparts.as<RowPart>(),
-            m->colparts.as<ColPart>(), tab, 0, m->exact_items.as<ExactItem>(), ecount, ecap, s);
-        launch_exact_scan(type == 0 ? 128 : 64, dp, m->exact_items.as<ExactItem>(), ecount, ecap,
-            tab, s);
+        if (cascade) {
+            OSFM_HIP_CHECK(hipEventRecord(m->ev[type][0], s));
+            timed[type] = true;
+            launch_cashash_match(type == 0 ? 128 : 64, dp, np, max_n[type], tab, s);
+            OSFM_HIP_CHECK(hipEventRecord(m->ev[type][1], s));
+        } else {
+            if (total_blocks[type] > 0) { OSFM_HIP_CHECK(hipEventRecord(m->ev[type][0], s)); timed[type] = true; }
+            launch_match_tiles(type == 0 ? 8 : 4, needs_mask[type], any_special[type], any_c0[type],
+                any_corrected[type], dp, np, total_blocks[type],
+                m->rowparts.as<RowPart>(), m->colparts.as<ColPart>(), s);
+            if (timed[type]) OSFM_HIP_CHECK(hipEventRecord(m->ev[type][1], s));
+            launch_match_finish(dp, np, max_n[type], m->rowparts.as<RowPart>(),
+                m->colparts.as<ColPart>(), tab, 0, m->exact_items.as<ExactItem>(), ecount, ecap, s);
+            launch_exact_scan(type == 0 ? 128 : 64, dp, m->exact_items.as<ExactItem>(), ecount, ecap,
+                tab, s);
+        }
         launch_cross_check_mark(dp, np, max_n[type], m->keep.as<uint8_t>(), m->keep.as<uint8_t>(),
             m->mark_off[type].as<int64_t>(), m->counts[type].as<int32_t>(), s);
         if (mode.apply)
@@ -323,7 +355,10 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
         if (!timed[type]) continue;
         float ms = 0.f;
         OSFM_HIP_CHECK(hipEventElapsedTime(&ms, m->ev[type][0], m->ev[type][1]));
-        if (mode.limit > 0) {
+        if (cascade) {
+            m->stats.cashash_kernel_ms += ms;
+            m->stats.cashash_kernel_launches += 1;
+        } else if (mode.limit > 0) {
             m->stats.lowres_kernel_ms += ms;
             m->stats.lowres_kernel_launches += 1;
         } else {
@@ -332,7 +367,9 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
         }
     }
     m->stats.exact_scan_queries += hexact[0] + hexact[1];
-    if (mode.limit > 0) {
+    if (cascade) {
+        // no dense products in this mode
+    } else if (mode.limit > 0) {
         m->stats.lowres_mac_count += macs;
     } else {
         m->stats.mac_count += macs;
@@ -413,6 +450,67 @@ int upload_view(osfm_matcher *m, int view, const uint16_t *sift, int n_sift, con
     }
     v.surf_norm2_max = h[1];
     v.set = true;
+    m->cas_dirty = true;           // the cascade hashes depend on the average over all views
+    return OSFM_OK;
+}
+
+// CascadeHashing::init (cascade_hashing.cc:33-70) for the views set so far.
+// The projection matrices are drawn on the host with the same standard-library
+// facilities the reference uses (std::mt19937(0) + std::normal_distribution<>,
+// cascade_hashing.h:225-254): the distribution's algorithm is the library's,
+// so the values equal the reference's when both are built against libstdc++.
+int ensure_cashash(osfm_matcher *m)
+{
+    if (!m->cas_dirty) return OSFM_OK;
+    hipStream_t s = m->stream;
+    for (int type = 0; type < 2; ++type) {
+        const int dim = type == 0 ? 128 : 64;
+        const int np = dim + kCasSecBits;
+        if (!m->cas_proj[type].ptr) {
+            std::mt19937 prng(0);
+            std::normal_distribution<> dis(0, 1);
+            std::vector<float> projT((size_t)dim * np);
+            for (int i = 0; i < dim; ++i)                    // primary: prim_hash[i][j]
+                for (int j = 0; j < dim; ++j) projT[(size_t)j * np + i] = (float)dis(prng);
+            for (int g = 0; g < kCasGroups; ++g)             // secondary: sec_hash[g][i][j]
+                for (int i = 0; i < kCasBits; ++i)
+                    for (int j = 0; j < dim; ++j) projT[(size_t)j * np + dim + g * kCasBits + i] = (float)dis(prng);
+            OSFM_RETURN_IF(m->cas_proj[type].reserve(projT.size() * 4));
+            OSFM_HIP_CHECK(hipMemcpy(m->cas_proj[type].ptr, projT.data(), projT.size() * 4, hipMemcpyHostToDevice));
+            OSFM_RETURN_IF(m->cas_sum[type].reserve(128 * 4));
+            OSFM_RETURN_IF(m->cas_avg[type].reserve(128 * 4));
+        }
+        // compute_avg_descriptors: one running float sum per dimension over all views in order
+        OSFM_HIP_CHECK(hipMemsetAsync(m->cas_sum[type].ptr, 0, 128 * 4, s));
+        int64_t total = 0;
+        for (auto &v : m->views) {
+            if (!v.set) continue;
+            const int n = type == 0 ? v.ns : v.nu;
+            total += n;
+            launch_cashash_accumulate((type == 0 ? v.sift : v.surf).as<int8_t>(), n, dim, type == 0 ? 128 : 0,
+                type == 0 ? 255.0f : 127.0f, m->cas_sum[type].as<float>(), s);
+        }
+        launch_cashash_average(m->cas_sum[type].as<float>(), dim, total, m->cas_avg[type].as<float>(), s);
+        for (auto &v : m->views) {
+            if (!v.set) continue;
+            const int n = type == 0 ? v.ns : v.nu;
+            OSFM_RETURN_IF(v.cas_hash[type].reserve((size_t)std::max(n, 1) * (dim / 64) * 8));
+            OSFM_RETURN_IF(v.cas_bucket[type].reserve((size_t)std::max(n, 1) * kCasGroups));
+            OSFM_RETURN_IF(v.cas_start[type].reserve((size_t)kCasGroups * (kCasBuckets + 1) * 4));
+            OSFM_RETURN_IF(v.cas_items[type].reserve((size_t)std::max(n, 1) * kCasGroups * 4));
+            launch_cashash_hash((type == 0 ? v.sift : v.surf).as<int8_t>(), n, dim, type == 0 ? 128 : 0,
+                type == 0 ? 255.0f : 127.0f, m->cas_avg[type].as<float>(), m->cas_proj[type].as<float>(),
+                v.cas_hash[type].as<uint64_t>(), v.cas_bucket[type].as<uint8_t>(), s);
+            launch_cashash_buckets(v.cas_bucket[type].as<uint8_t>(), n, v.cas_start[type].as<int32_t>(),
+                v.cas_items[type].as<int32_t>(), s);
+            OSFM_RETURN_IF(v.cas_rec[type].reserve((size_t)std::max(n, 1) * sizeof(CasRecord)));
+            launch_cashash_pack(v.cas_hash[type].as<uint64_t>(), v.cas_bucket[type].as<uint8_t>(), n, dim / 64,
+                static_cast<CasRecord *>(v.cas_rec[type].ptr), s);
+        }
+    }
+    OSFM_HIP_CHECK(hipGetLastError());
+    OSFM_HIP_CHECK(hipStreamSynchronize(s));
+    m->cas_dirty = false;
     return OSFM_OK;
 }
 
@@ -448,7 +546,7 @@ int osfm_match_options_default(osfm_match_options *o)
     o->ransac_max_iterations = 1000;
     o->ransac_threshold = 0.0015;
     o->min_matching_inliers = 30;
-    o->reserved0 = 0;
+    o->matcher_type = OSFM_MATCHER_EXHAUSTIVE;
     o->ransac_seed = 0;
     return OSFM_OK;
 }
@@ -917,6 +1015,24 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
             (long long)written, (long long)capacity);
         return OSFM_E_CAPACITY;
     }
+    return OSFM_OK;
+}
+
+int osfm_match_get_cascade_hashes(osfm_matcher *m, int view, int type, uint64_t *hashes,
+    uint8_t *bucket_ids)
+{
+    if (!m || type < 0 || type > 1) { set_error("get_cascade_hashes: bad arguments"); return OSFM_E_ARG; }
+    std::lock_guard<std::mutex> lock(m->mu);
+    OSFM_RETURN_IF(check_view(m, view, "get_cascade_hashes"));
+    OSFM_HIP_CHECK(hipSetDevice(m->device));
+    OSFM_RETURN_IF(ensure_cashash(m));
+    const ViewData &v = m->views[view];
+    const int n = type == 0 ? v.ns : v.nu;
+    const int words = type == 0 ? 2 : 1;
+    if (n > 0 && hashes)
+        OSFM_HIP_CHECK(hipMemcpy(hashes, v.cas_hash[type].ptr, (size_t)n * words * 8, hipMemcpyDeviceToHost));
+    if (n > 0 && bucket_ids)
+        OSFM_HIP_CHECK(hipMemcpy(bucket_ids, v.cas_bucket[type].ptr, (size_t)n * kCasGroups, hipMemcpyDeviceToHost));
     return OSFM_OK;
 }
 

@@ -47,6 +47,10 @@ struct MatchProblem {
     // ip = sum(a * b) needs no correction at all and the MFMA C operand is 0.
     int32_t c0;
     const int8_t *B_raw;
+    // cascade hashing mode (cashash_kernels.h): hash data of set 1 / set 2
+    const void *cas_rec[2];          // CasRecord[n]: hash words + packed bucket ids
+    const int32_t *cas_start[2];
+    const int32_t *cas_items[2];
 };
 
 struct RowPart { int32_t ip_best, idx_best, ip_second, pad; };

@@ -29,7 +29,10 @@ namespace osfm_adapter {
 class HipMatching : public sfm::MatchingBase
 {
 public:
-    explicit HipMatching (int device = 0) : device(device), handle(nullptr) {}
+    /* matcher_type: OSFM_MATCHER_EXHAUSTIVE (sfm::ExhaustiveMatching) or
+     * OSFM_MATCHER_CASCADE_HASHING (sfm::CascadeHashing, the application's default) */
+    explicit HipMatching (int device = 0, int matcher_type = OSFM_MATCHER_EXHAUSTIVE)
+        : device(device), matcher_type(matcher_type), handle(nullptr) {}
     HipMatching (HipMatching const&) = delete;
     HipMatching& operator= (HipMatching const&) = delete;
 
@@ -55,6 +58,7 @@ public:
         o.sift_distance_threshold = this->opts.sift_matching_opts.distance_threshold;
         o.surf_lowe_ratio = this->opts.surf_matching_opts.lowe_ratio_threshold;
         o.surf_distance_threshold = this->opts.surf_matching_opts.distance_threshold;
+        o.matcher_type = this->matcher_type;
         check(osfm_match_create(this->device, (int)viewports->size(), &o, &this->handle));
 
         std::vector<float> sift, surf;
@@ -109,6 +113,7 @@ private:
     }
 
     int device;
+    int matcher_type;
     osfm_matcher* handle;
 };
 

@@ -174,6 +174,19 @@ class HipExhaustiveMatching:
             self._corr_buf = buf
         return buf[:rows]
 
+    def cascade_hashes(self, view, type_=0):
+        """CascadeHashing::LocalData of a view: (hashes (n, words) uint64, bucket ids (6, n) uint8)."""
+        n = self.view_size(view)[type_]
+        words = 2 if type_ == 0 else 1
+        hashes = np.zeros((max(n, 1), words), np.uint64)
+        ids = np.zeros((6, max(n, 1)), np.uint8)
+        tmp = np.zeros(6 * max(n, 1), np.uint8)
+        capi.check(capi.lib.osfm_match_get_cascade_hashes(self._h, view, type_, capi._ptr(hashes, C.c_uint64),
+                                                          capi._ptr(tmp, C.c_uint8)))
+        if n:
+            ids = tmp[:6 * n].reshape(6, n)
+        return hashes[:n], ids[:, :n]
+
     def stats(self) -> capi.MatchStats:
         s = capi.MatchStats()
         capi.check(capi.lib.osfm_match_get_stats(self._h, C.byref(s)))
@@ -189,3 +202,16 @@ class HipExhaustiveMatching:
             self.close()
         except Exception:
             pass
+
+
+class HipCascadeHashing(HipExhaustiveMatching):
+    """Drop-in for sfm::CascadeHashing (src/mve/sfm/cascade_hashing.h:29-221), the
+    matcher the application selects (matching_mve.cpp:406-408): pairwise_match
+    is the approximate cascade-hashing search, pairwise_match_lowres the
+    exhaustive one it inherits."""
+
+    def __init__(self, num_views: int, device: int = 0, options: capi.MatchOptions | None = None,
+                 copy_results: bool = True):
+        opts = options if options is not None else capi.default_match_options()
+        opts.matcher_type = capi.MATCHER_CASCADE_HASHING
+        super().__init__(num_views, device, opts, copy_results)

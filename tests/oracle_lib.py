@@ -643,11 +643,17 @@ class OracleCasHash:
                       [oracle_cashash_hashes(u, 64, 127.0, self.avg[1], *self.proj[1]) for u in surfs]]
 
     def pairwise_match(self, v1, v2):
-        """cascade_hashing.cc:73-104 (sizes as the exhaustive matcher reports them)."""
+        """cascade_hashing.cc:73-104.  A descriptor type takes part iff view 1 has
+        descriptors of it (:82,95); with an empty set on side 2 the reference
+        leaves that part out of its vectors (oneway_match returns before resizing,
+        cascade_hashing.h:341-342) -- here, as at the flat boundary, it stays in as -1."""
         om = oracle_matcher()
         parts = []
         for t, descs in enumerate((self.sifts, self.surfs)):
             a, b = descs[v1], descs[v2]
+            if a.shape[0] == 0:
+                parts.append((np.zeros(0, np.int32), np.zeros(0, np.int32)))
+                continue
             (h1, b1), (h2, b2) = self.local[t][v1], self.local[t][v2]
             m12 = oracle_cashash_oneway(t, a, h1, b1, b, h2, b2, self.lowe[t])
             m21 = oracle_cashash_oneway(t, b, h2, b2, a, h1, b1, self.lowe[t])
