@@ -41,9 +41,10 @@ void launch_cashash_pack(const uint64_t *hashes, const uint8_t *bucket_ids, int 
 // build_buckets (cascade_hashing.cc:187-209)
 void launch_cashash_buckets(const uint8_t *bucket_ids, int n, int32_t *start, int32_t *items, hipStream_t s);
 
-// CascadeHashing::twoway_match for a batch of problems (MatchProblem::cas1 / cas2 set):
-// m12 / m21 written, ready for the cross-check kernels
+// CascadeHashing::twoway_match for a batch of problems (MatchProblem::cas_* set):
+// m12 / m21 written, ready for the cross-check kernels.  state: scratch of
+// kCasMaxCand ints per query of the batch (MatchProblem::cas_state_off)
 void launch_cashash_match(int dim, const MatchProblem *d_problems, int num_problems, int max_n,
-    LoweTable tab, hipStream_t s);
+    int32_t *state, LoweTable tab, hipStream_t s);
 
 }  // namespace osfm

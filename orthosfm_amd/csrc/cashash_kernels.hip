@@ -105,27 +105,46 @@ cashash_hash_kernel(const int8_t *__restrict__ desc, int n, int bias, float div,
 }
 
 // One block per bucket group; thread b collects the features of bucket b in
-// ascending order (two passes over the ids: count, then fill).
+// ascending order (two passes over the ids: count, then fill).  The ids pass
+// through LDS in chunks fetched by all threads, so that the per-thread scans
+// read LDS broadcasts instead of waiting on one global load per id.
+constexpr int kBucketChunk = 4096;
+
 __global__ __launch_bounds__(kCasBuckets) void
 cashash_buckets_kernel(const uint8_t *__restrict__ bucket_ids, int n, int32_t *__restrict__ start,
     int32_t *__restrict__ items)
 {
     __shared__ int32_t cnt[kCasBuckets + 1];
+    __shared__ uint8_t chunk[kBucketChunk];
     const int g = blockIdx.x, b = threadIdx.x;
     const uint8_t *ids = bucket_ids + (size_t)g * n;
-    int c = 0;
-    for (int i = 0; i < n; ++i) c += ids[i] == b;
-    cnt[b + 1] = c;
-    if (b == 0) cnt[0] = 0;
-    __syncthreads();
-    if (b == 0) for (int k = 0; k < kCasBuckets; ++k) cnt[k + 1] += cnt[k];
-    __syncthreads();
-    start[(size_t)g * (kCasBuckets + 1) + b] = cnt[b];
-    if (b == kCasBuckets - 1) start[(size_t)g * (kCasBuckets + 1) + kCasBuckets] = cnt[kCasBuckets];
-    int pos = cnt[b];
     int32_t *out = items + (size_t)g * n;
-    for (int i = 0; i < n; ++i)
-        if (ids[i] == b) out[pos++] = i;
+    int pos = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        int c = 0;
+        for (int base = 0; base < n; base += kBucketChunk) {
+            const int len = min(kBucketChunk, n - base);
+            __syncthreads();
+            for (int e = b; e < len; e += kCasBuckets) chunk[e] = ids[base + e];
+            __syncthreads();
+            if (pass == 0) {
+                for (int i = 0; i < len; ++i) c += chunk[i] == b;
+            } else {
+                for (int i = 0; i < len; ++i)
+                    if (chunk[i] == b) out[pos++] = base + i;
+            }
+        }
+        if (pass == 0) {
+            cnt[b + 1] = c;
+            if (b == 0) cnt[0] = 0;
+            __syncthreads();
+            if (b == 0) for (int k = 0; k < kCasBuckets; ++k) cnt[k + 1] += cnt[k];
+            __syncthreads();
+            start[(size_t)g * (kCasBuckets + 1) + b] = cnt[b];
+            if (b == kCasBuckets - 1) start[(size_t)g * (kCasBuckets + 1) + kCasBuckets] = cnt[kCasBuckets];
+            pos = cnt[b];
+        }
+    }
 }
 
 __global__ void
@@ -144,11 +163,99 @@ cashash_pack_kernel(const uint64_t *__restrict__ hashes, const uint8_t *__restri
     rec[i] = r;
 }
 
-// CascadeHashing::oneway_match (cascade_hashing.h:328-412) for query q of set
-// `dir` against the other set; one thread per query.
+// ---------------------------------------------------------------------------
+// CascadeHashing::oneway_match (cascade_hashing.h:328-412) in two steps.
+//
+// Scan (one launch per bucket group g): a workgroup takes one bucket; the
+// candidates of that bucket (set 2) go through LDS once and are scored by all
+// the queries of the same bucket (set 1), one query per thread -- the records
+// are read once per bucket instead of once per (query, candidate).  A query
+// keeps its ten best candidates so far as ten sorted keys
+//     Hamming distance << 20 | group << 17 | position in the bucket list,
+// which order exactly like (distance, order of first appearance) because
+// groups are visited in order and positions ascend (collect_features_from_buckets
+// h:414-444 appends in that order; duplicates are dropped at their later
+// appearance, decided from the packed bucket ids of the earlier groups).  The
+// keys live in global memory between the launches (the thread <-> query mapping
+// changes with the group).
+//
+// Finish (one thread per query): candidate ids back from the keys, the 6..10
+// rule (h:446-468), NearestNeighbor<T>::find over the survivors and the ratio
+// test.
+// ---------------------------------------------------------------------------
+constexpr int kCasPosBits = 17, kCasGroupShift = kCasPosBits, kCasDistShift = 20;
+constexpr int kCasKeyNone = 0x7fffffff;
+
+template <int DIM, int G>
+__global__ __launch_bounds__(128) void
+cashash_scan_kernel(const MatchProblem *__restrict__ problems, int32_t *__restrict__ state)
+{
+    constexpr int g = G;
+    const MatchProblem &pd = problems[blockIdx.y];
+    const int dir = blockIdx.z, beta = blockIdx.x;
+    const int nq = dir == 0 ? pd.n1 : pd.n2;
+    const int nc = dir == 0 ? pd.n2 : pd.n1;
+    if (nq == 0 || nc == 0) return;
+    const int s1 = dir, s2 = dir ^ 1;
+    const int32_t *st1 = pd.cas_start[s1] + (size_t)g * (kCasBuckets + 1);
+    const int32_t *it1 = pd.cas_items[s1] + (size_t)g * nq;
+    const int32_t *st2 = pd.cas_start[s2] + (size_t)g * (kCasBuckets + 1);
+    const int32_t *it2 = pd.cas_items[s2] + (size_t)g * nc;
+    const int qb = st1[beta], qe = st1[beta + 1];
+    const int cb = st2[beta], ce = st2[beta + 1];
+    if (qb == qe) return;
+    const CasRecord *rec1 = static_cast<const CasRecord *>(pd.cas_rec[s1]);
+    const CasRecord *rec2 = static_cast<const CasRecord *>(pd.cas_rec[s2]);
+    int32_t *st = state + pd.cas_state_off[dir] * kCasMaxCand;
+    __shared__ CasRecord crec[128];
+
+    for (int q0 = qb; q0 < qe; q0 += 128) {
+        const int qi = q0 + (int)threadIdx.x;
+        const bool act = qi < qe;
+        const int q = act ? it1[qi] : 0;
+        const CasRecord me = rec1[q];
+        int key[kCasMaxCand];
+#pragma unroll
+        for (int j = 0; j < kCasMaxCand; ++j) key[j] = (act && g > 0) ? st[(size_t)q * kCasMaxCand + j] : kCasKeyNone;
+        for (int c0 = cb; c0 < ce; c0 += 128) {
+            __syncthreads();
+            if (c0 + (int)threadIdx.x < ce) crec[threadIdx.x] = rec2[it2[c0 + threadIdx.x]];
+            __syncthreads();
+            const int cnt = min(128, ce - c0);
+            if (!act) continue;
+            for (int j = 0; j < cnt; ++j) {
+                const CasRecord r = crec[j];
+                // seen in an earlier group iff one of the first G bucket ids equals the
+                // query's: a zero byte in the xor (bytes >= G forced non-zero)
+                bool dup = false;
+                if (G > 0) {
+                    const uint32_t x = ((uint32_t)r.buckets ^ (uint32_t)me.buckets) | (G < 4 ? ~0u << (8 * (G & 3)) : 0u);
+                    dup = ((x - 0x01010101u) & ~x & 0x80808080u) != 0;
+                }
+                if (G == 5) dup |= (((uint32_t)(r.buckets >> 32) ^ (uint32_t)(me.buckets >> 32)) & 0xffu) == 0;
+                if (dup) continue;
+                const int hd = __popcll(me.h[0] ^ r.h[0]) + (DIM > 64 ? __popcll(me.h[1] ^ r.h[1]) : 0);
+                int k = (hd << kCasDistShift) | (g << kCasGroupShift) | (c0 - cb + j);
+                if (k >= key[kCasMaxCand - 1]) continue;
+#pragma unroll
+                for (int e = 0; e < kCasMaxCand; ++e) {             // sorted insertion
+                    const int lo = min(k, key[e]);
+                    k = max(k, key[e]);
+                    key[e] = lo;
+                }
+            }
+        }
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < kCasMaxCand; ++j) st[(size_t)q * kCasMaxCand + j] = key[j];
+        }
+    }
+}
+
 template <int DIM, bool SIGNED>
 __global__ __launch_bounds__(128) void
-cashash_match_kernel(const MatchProblem *__restrict__ problems, LoweTable tab)
+cashash_finish_kernel(const MatchProblem *__restrict__ problems, const int32_t *__restrict__ state,
+    LoweTable tab)
 {
     const MatchProblem &pd = problems[blockIdx.y];
     const int dir = blockIdx.z;
@@ -158,46 +265,20 @@ cashash_match_kernel(const MatchProblem *__restrict__ problems, LoweTable tab)
     if (q >= nq) return;
     int32_t *out = dir == 0 ? pd.m12 : pd.m21;
     if (nc == 0) { out[q] = -1; return; }
-    const int s1 = dir, s2 = dir ^ 1;                    // hash data sets: query side, candidate side
+    const int s1 = dir, s2 = dir ^ 1;
     const int8_t *Q = dir == 0 ? pd.A : pd.B;
     const int8_t *Cm = dir == 0 ? pd.B : pd.A;
-    const CasRecord *rec2 = static_cast<const CasRecord *>(pd.cas_rec[s2]);
     const CasRecord me = static_cast<const CasRecord *>(pd.cas_rec[s1])[q];
-
-    // the ten best (Hamming distance, order of first appearance), ascending
+    const int32_t *st = state + (pd.cas_state_off[dir] + q) * kCasMaxCand;
     int key[kCasMaxCand], cid[kCasMaxCand];
 #pragma unroll
-    for (int j = 0; j < kCasMaxCand; ++j) { key[j] = 0x7fffffff; cid[j] = -1; }
-    int order = 0;
-#pragma unroll 1
-    for (int g = 0; g < kCasGroups; ++g) {
-        const int32_t *st = pd.cas_start[s2] + (size_t)g * (kCasBuckets + 1);
-        const int32_t *it = pd.cas_items[s2] + (size_t)g * nc;
-        const int myb = (int)((me.buckets >> (8 * g)) & 0xffu);
-        const int pb = st[myb], pe = st[myb + 1];
-        // bytes of the earlier groups; the others are forced non-zero below
-        const uint64_t later = g == 0 ? ~0ull : ~0ull << (8 * g);
-        for (int p = pb; p < pe; ++p) {
-            const int c = it[p];
-            const CasRecord r = rec2[c];
-            // seen before iff it shares the query's bucket in an earlier group
-            // (data_index_used, cascade_hashing.h:432-433,441): a zero byte among
-            // the first g bytes of the xor of the packed bucket ids
-            const uint64_t x = (r.buckets ^ me.buckets) | later;
-            if ((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull) continue;
-            const int hd = __popcll(me.h[0] ^ r.h[0]) + (DIM > 64 ? __popcll(me.h[1] ^ r.h[1]) : 0);
-            int k = (hd << 20) | order;
-            ++order;
-            if (k >= key[kCasMaxCand - 1]) continue;
-            int ci = c;
-            // insertion into the sorted list (compare-exchange from the front)
-#pragma unroll
-            for (int j = 0; j < kCasMaxCand; ++j) {
-                const bool sw = k < key[j];
-                const int tk = key[j], tc = cid[j];
-                key[j] = sw ? k : tk; cid[j] = sw ? ci : tc;
-                k = sw ? tk : k; ci = sw ? tc : ci;
-            }
+    for (int j = 0; j < kCasMaxCand; ++j) {
+        key[j] = st[j];
+        cid[j] = -1;
+        if (key[j] != kCasKeyNone) {
+            const int g = (key[j] >> kCasGroupShift) & 7, pos = key[j] & ((1 << kCasPosBits) - 1);
+            const int myb = (int)((me.buckets >> (8 * g)) & 0xffu);
+            cid[j] = pd.cas_items[s2][(size_t)g * nc + pd.cas_start[s2][(size_t)g * (kCasBuckets + 1) + myb] + pos];
         }
     }
     // collect_top_ranked_candidates (h:446-468): whole distance levels until at
@@ -206,13 +287,12 @@ cashash_match_kernel(const MatchProblem *__restrict__ problems, LoweTable tab)
 #pragma unroll
     for (int j = 0; j < kCasMaxCand; ++j) {
         if (cid[j] < 0) break;
-        if (nt >= kCasMinCand && (key[j] >> 20) > (key[nt - 1] >> 20)) break;
+        if (nt >= kCasMinCand && (key[j] >> kCasDistShift) > (key[nt - 1] >> kCasDistShift)) break;
         nt = j + 1;
     }
     // NearestNeighbor<T>::find over the candidates in that order
     // (nearest_neighbor.cc:60-129,214-268): 8 lanes of 16-bit wrap-around sums,
-    // state held in T
-    // query descriptor once into registers, 16 bytes at a time
+    // state held in T; query descriptor once into registers, 16 bytes at a time
     const int4 *qrow = reinterpret_cast<const int4 *>(Q + (size_t)q * DIM);
     int4 qv[DIM / 16];
 #pragma unroll
@@ -256,7 +336,10 @@ cashash_match_kernel(const MatchProblem *__restrict__ problems, LoweTable tab)
         const int b = min(65025, best), s = min(65025, second);
         d1 = min(32767, 65025 - b) * 2; d2 = min(32767, 65025 - s) * 2;
     }
-    int res = nt > 0 ? cid[i1] : -1;
+    // i1 indexes the candidate list; the cid[] array is indexed dynamically only here
+    int res = -1;
+#pragma unroll
+    for (int j = 0; j < kCasMaxCand; ++j) if (j == i1 && j < nt) res = cid[j];
     if (d1 > tab.max_d1) res = -1;
     else if (d1 >= tab.reject_from[d2 >> 1]) res = -1;
     out[q] = res;
@@ -298,14 +381,21 @@ void launch_cashash_buckets(const uint8_t *bucket_ids, int n, int32_t *start, in
 }
 
 void launch_cashash_match(int dim, const MatchProblem *d_problems, int num_problems, int max_n,
-    LoweTable tab, hipStream_t s)
+    int32_t *state, LoweTable tab, hipStream_t s)
 {
     if (num_problems <= 0 || max_n <= 0) return;
+    const dim3 sgrid(kCasBuckets, num_problems, 2);
+#define OSFM_CAS_SCAN(G) \
+    if (dim == 128) hipLaunchKernelGGL((cashash_scan_kernel<128, G>), sgrid, dim3(128), 0, s, d_problems, state); \
+    else hipLaunchKernelGGL((cashash_scan_kernel<64, G>), sgrid, dim3(128), 0, s, d_problems, state)
+    static_assert(kCasGroups == 6, "one instantiation per bucket group");
+    OSFM_CAS_SCAN(0); OSFM_CAS_SCAN(1); OSFM_CAS_SCAN(2); OSFM_CAS_SCAN(3); OSFM_CAS_SCAN(4); OSFM_CAS_SCAN(5);
+#undef OSFM_CAS_SCAN
     const dim3 grid((max_n + 127) / 128, num_problems, 2);
     if (dim == 128)
-        hipLaunchKernelGGL((cashash_match_kernel<128, false>), grid, dim3(128), 0, s, d_problems, tab);
+        hipLaunchKernelGGL((cashash_finish_kernel<128, false>), grid, dim3(128), 0, s, d_problems, state, tab);
     else
-        hipLaunchKernelGGL((cashash_match_kernel<64, true>), grid, dim3(128), 0, s, d_problems, tab);
+        hipLaunchKernelGGL((cashash_finish_kernel<64, true>), grid, dim3(128), 0, s, d_problems, state, tab);
 }
 
 }  // namespace osfm

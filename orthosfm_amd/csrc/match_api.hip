@@ -109,7 +109,7 @@ struct osfm_matcher {
 
     // cascade hashing: projection matrices (transposed), running sums, average; the
     // hashes depend on the average over ALL views, hence the dirty flag
-    DeviceBuffer cas_proj[2], cas_sum[2], cas_avg[2];
+    DeviceBuffer cas_proj[2], cas_sum[2], cas_avg[2], cas_state;
     bool cas_dirty = true;
 
     osfm_match_stats stats;
@@ -177,6 +177,7 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
     bool any_special[2] = {false, false};  // some problem has gathered special rows
     bool any_c0[2] = {false, false}, any_corrected[2] = {false, false};
     int64_t macs = 0, alg_bytes = 0;
+    int64_t cas_queries[2] = {0, 0};
 
     for (int p = 0; p < num_pairs; ++p) {
         PairPlan &pl = res->plans[p];
@@ -243,6 +244,8 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
                     pr.cas_start[side] = vd[side]->cas_start[type].as<int32_t>();
                     pr.cas_items[side] = vd[side]->cas_items[type].as<int32_t>();
                 }
+                pr.cas_state_off[0] = cas_queries[type]; cas_queries[type] += pr.n1;
+                pr.cas_state_off[1] = cas_queries[type]; cas_queries[type] += pr.n2;
             } else {
                 total_blocks[type] += pr.nrb * pr.nseg;
                 pr.rowpart_off = rowpart_recs;
@@ -313,7 +316,8 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
         if (cascade) {
             OSFM_HIP_CHECK(hipEventRecord(m->ev[type][0], s));
             timed[type] = true;
-            launch_cashash_match(type == 0 ? 128 : 64, dp, np, max_n[type], tab, s);
+            OSFM_RETURN_IF(m->cas_state.reserve((size_t)std::max<int64_t>(cas_queries[type], 1) * kCasMaxCand * 4));
+            launch_cashash_match(type == 0 ? 128 : 64, dp, np, max_n[type], m->cas_state.as<int32_t>(), tab, s);
             OSFM_HIP_CHECK(hipEventRecord(m->ev[type][1], s));
         } else {
             if (total_blocks[type] > 0) { OSFM_HIP_CHECK(hipEventRecord(m->ev[type][0], s)); timed[type] = true; }

@@ -51,6 +51,7 @@ struct MatchProblem {
     const void *cas_rec[2];          // CasRecord[n]: hash words + packed bucket ids
     const int32_t *cas_start[2];
     const int32_t *cas_items[2];
+    int64_t cas_state_off[2];        // first query of direction 0 / 1 in the candidate-key scratch
 };
 
 struct RowPart { int32_t ip_best, idx_best, ip_second, pad; };
