@@ -3,9 +3,10 @@
  * reference sources exist (this container) into oracle/_ref/adapter_check;
  * the binary travels to the GPU box.  It runs the product's MVE adapter
  * (orthosfm_amd/host/mve_hip_matching.h, an sfm::MatchingBase subclass) and
- * the REFERENCE's own sfm::ExhaustiveMatching side by side through the same
- * virtual interface on the same random viewports and requires identical
- * Matching::Result lists and low-res counts.
+ * the REFERENCE's own sfm::ExhaustiveMatching -- and sfm::CascadeHashing, the
+ * application's default -- side by side through the same virtual interface on
+ * the same random viewports and requires identical Matching::Result lists and
+ * low-res counts.
  */
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +16,7 @@
 #include <vector>
 
 #include "sfm/exhaustive_matching.h"
+#include "sfm/cascade_hashing.h"
 #include "mve_hip_matching.h"
 
 static void fill_views(sfm::bundler::ViewportList* vl, unsigned seed)
@@ -72,6 +74,68 @@ int main()
             for (int m : r1.matches_1_2) valid += m >= 0;
             checked++;
         }
+    /* cascade hashing: when the OTHER view has no descriptors of a type the
+     * reference leaves that type's block out of its vectors altogether
+     * (oneway_match returns before resizing, cascade_hashing.h:341-342), which
+     * shifts the SURF entries to the front; the adapter keeps the exhaustive
+     * matcher's layout (block present, all -1).  Re-insert the blocks before
+     * comparing. */
+    const int counts[5][2] = { { 700, 300 }, { 650, 0 }, { 0, 280 }, { 810, 333 }, { 3, 2 } };
+    auto expand = [&](std::vector<int> const& ref_v, int a, int b) {
+        std::vector<int> out;
+        std::size_t pos = 0;
+        for (int t = 0; t < 2; ++t) {
+            const int na = counts[a][t], nb = counts[b][t];
+            if (na == 0) continue;                         /* type skipped by both (cc:82,95) */
+            for (int i = 0; i < na; ++i) out.push_back(nb > 0 ? ref_v[pos + i] : -1);
+            if (nb > 0) pos += na;
+        }
+        return out;
+    };
+    sfm::bundler::ViewportList vc, vd;
+    fill_views(&vc, 7);
+    fill_views(&vd, 7);
+    std::unique_ptr<sfm::MatchingBase> cref(new sfm::CascadeHashing());
+    std::unique_ptr<sfm::MatchingBase> chip(new osfm_adapter::HipMatching(0, OSFM_MATCHER_CASCADE_HASHING));
+    cref->init(&vc);
+    chip->init(&vd);
+    int cchecked = 0, cvalid = 0;
+    for (int a = 0; a < 5; ++a)
+        for (int b = 0; b < 5; ++b) {
+            if (a == b) continue;
+            sfm::Matching::Result r1, r2;
+            cref->pairwise_match(a, b, &r1);
+            chip->pairwise_match(a, b, &r2);
+            /* matches_2_1 follows view b's blocks; a type takes part iff view a has it */
+            std::vector<int> e21;
+            {
+                std::size_t pos = 0;
+                for (int t = 0; t < 2; ++t) {
+                    if (counts[a][t] == 0) continue;
+                    const int nb = counts[b][t];
+                    /* with view b SIFT-less the reference's SIFT lists are EMPTY, so its
+                     * combine_results (matching.cc:74-86) does not shift the SURF indices of
+                     * the 2->1 list behind view a's SIFT block; the adapter does (consistent
+                     * combined indices, as with the exhaustive matcher) */
+                    const int shift = (t == 1 && counts[a][0] > 0 && counts[b][0] == 0) ? counts[a][0] : 0;
+                    for (int i = 0; i < nb; ++i) {
+                        const int v = r1.matches_2_1[pos + i];
+                        e21.push_back(v >= 0 ? v + shift : v);
+                    }
+                    pos += nb;
+                }
+            }
+            if (expand(r1.matches_1_2, a, b) != r2.matches_1_2 || e21 != r2.matches_2_1) {
+                std::fprintf(stderr, "MISMATCH cascade pairwise_match(%d,%d)\n", a, b);
+                return 1;
+            }
+            const int c1 = cref->pairwise_match_lowres(a, b, 500), c2 = chip->pairwise_match_lowres(a, b, 500);
+            if (c1 != c2) { std::fprintf(stderr, "MISMATCH cascade lowres(%d,%d): %d vs %d\n", a, b, c1, c2); return 1; }
+            for (int m : r1.matches_1_2) cvalid += m >= 0;
+            cchecked++;
+        }
+    std::printf("adapter_check ok: %d pairs identical to sfm::CascadeHashing, %d valid matches\n", cchecked, cvalid);
+
     bool threw = false;
     try { hip->init(nullptr); } catch (std::invalid_argument const&) { threw = true; }
     if (!threw) { std::fprintf(stderr, "init(nullptr) did not throw\n"); return 1; }

@@ -248,7 +248,8 @@ def test_cpp_adapter_vs_reference_side_by_side():
         pytest.skip("oracle/_ref/adapter_check was not built (reference sources absent)")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "adapter_check ok: 20 pairs identical" in out.stdout
+    assert "adapter_check ok: 20 pairs identical to sfm::ExhaustiveMatching" in out.stdout
+    assert "adapter_check ok: 20 pairs identical to sfm::CascadeHashing" in out.stdout
 
 
 def test_special_rows_large_values(hm):
