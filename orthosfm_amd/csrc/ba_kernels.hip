@@ -156,7 +156,14 @@ ba_pair_pass_kernel(BaDev d, PairPassArgs a)
     for (int e = e0 + lane; e < e1; e += 64) {
         const uint64_t ent = a.entries[e];
         const int ka = (int)(ent >> 32), kb = (int)(ent & 0xffffffffu);
-        const double *ra = a.obsrec + (size_t)ka * kObsRec;
+        // whole records as 16-byte loads (26 doubles = 13 x double2): each lane reads
+        // its own records, so the request count, not the byte count, is what costs
+        double ra[kObsRec];
+        {
+            const double2 *src = reinterpret_cast<const double2 *>(a.obsrec + (size_t)ka * kObsRec);
+#pragma unroll
+            for (int i = 0; i < kObsRec / 2; ++i) { const double2 v = src[i]; ra[2 * i] = v.x; ra[2 * i + 1] = v.y; }
+        }
         double Ja[2][6];
 #pragma unroll
         for (int x = 0; x < 6; ++x) { Ja[0][x] = ra[kRecJc + x]; Ja[1][x] = ra[kRecJc + 6 + x]; }
@@ -177,8 +184,13 @@ ba_pair_pass_kernel(BaDev d, PairPassArgs a)
             }
         }
         if (d.pdim && a.mode != kPassScaleInit) {
-            // Z_a W_b^T = Jc_a^T (Q_a Jp_b^T) Jc_b
-            const double *rb = a.obsrec + (size_t)kb * kObsRec;
+            // Z_a W_b^T = Jc_a^T (Q_a Jp_b^T) Jc_b; of record b only Jc and Jp (18 doubles)
+            double rb[kRecQ];
+            {
+                const double2 *src = reinterpret_cast<const double2 *>(a.obsrec + (size_t)kb * kObsRec);
+#pragma unroll
+                for (int i = 0; i < kRecQ / 2; ++i) { const double2 v = src[i]; rb[2 * i] = v.x; rb[2 * i + 1] = v.y; }
+            }
             double M[2][2];
 #pragma unroll
             for (int r1 = 0; r1 < 2; ++r1)
@@ -205,20 +217,30 @@ ba_pair_pass_kernel(BaDev d, PairPassArgs a)
         for (int y = 0; y < 6; ++y) acc[x][y] = wave_sum(acc[x][y]);
     }
     if (lane != 0) return;
+    // fully unrolled with predicates: a loop bounded by n1 / n2 would index the
+    // accumulators dynamically and push all 36 of them into scratch memory
     if (a.mode == kPassScaleInit) {
-        if (diag_pair)
-            for (int x = 0; x < n1; ++x) a.scale_c_out[o1 + x] = 1.0 / (1.0 + sqrt(U[x]));
+        if (diag_pair) {
+#pragma unroll
+            for (int x = 0; x < 6; ++x)
+                if (x < n1) a.scale_c_out[o1 + x] = 1.0 / (1.0 + sqrt(U[x]));
+        }
         return;
     }
     if (diag_pair) {
-        for (int x = 0; x < n1; ++x) {
+#pragma unroll
+        for (int x = 0; x < 6; ++x) {
+            if (x >= n1) continue;
             if (a.update_diag) a.diag_c[o1 + x] = fmin(fmax(U[x], a.min_diag), a.max_diag);
             acc[x][x] += a.diag_c[o1 + x] / a.radius;
+            a.rhs[o1 + x] = rhs[x];
         }
-        for (int x = 0; x < n1; ++x) a.rhs[o1 + x] = rhs[x];
     }
-    for (int x = 0; x < n1; ++x)
-        for (int y = 0; y < n2; ++y) a.S[(size_t)(o1 + x) * a.ldS + (o2 + y)] = acc[x][y];
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+        for (int y = 0; y < 6; ++y)
+            if (x < n1 && y < n2) a.S[(size_t)(o1 + x) * a.ldS + (o2 + y)] = acc[x][y];
 }
 
 void launch_pair_pass(const BaDev &d, const PairPassArgs &a, hipStream_t s)
