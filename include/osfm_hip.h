@@ -318,6 +318,8 @@ typedef struct osfm_ba_summary {
     double back_pass_ms;
     int32_t linearizations;           /* number of point/pair pass executions timed */
     int32_t num_pair_entries;         /* observation pairs in the Schur complement lists */
+    double lm_loop_ms;                /* wall time of the LM iterations alone (host control included;
+                                       * problem upload, pair lists and the first linearisation are not) */
 } osfm_ba_summary;
 
 OSFM_API int osfm_ba_options_default(osfm_ba_options *opts);

@@ -282,7 +282,8 @@ def bench_global_ba(num_cameras=200, num_points=100000, max_iterations=25, devic
     return {"workload": f"{num_cameras} quaternion cameras, {num_points} tracks, "
                         f"{fp.obs_camera.size} observations, Schur + dense Cholesky",
             "iterations": int(its), "iterations_per_s": its / (s.solve_ms * 1e-3),
-            "solve_ms": s.solve_ms, "initial_cost": s.initial_cost, "final_cost": s.final_cost,
+            "lm_loop_iterations_per_s": its / max(s.lm_loop_ms * 1e-3, 1e-9),
+            "solve_ms": s.solve_ms, "lm_loop_ms": s.lm_loop_ms, "initial_cost": s.initial_cost, "final_cost": s.final_cost,
             "termination": TERMINATION.get(s.termination, "?"),
             "kernel_ms": {"point_pass": s.point_pass_ms, "pair_pass": s.pair_pass_ms,
                           "cholesky": s.cholesky_ms, "back_pass": s.back_pass_ms,

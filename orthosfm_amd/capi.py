@@ -105,7 +105,8 @@ class BaSummary(C.Structure):
                 ("solve_ms", C.c_double), ("point_pass_ms", C.c_double),
                 ("pair_pass_ms", C.c_double), ("cholesky_ms", C.c_double),
                 ("back_pass_ms", C.c_double),
-                ("linearizations", C.c_int32), ("num_pair_entries", C.c_int32)]
+                ("linearizations", C.c_int32), ("num_pair_entries", C.c_int32),
+                ("lm_loop_ms", C.c_double)]
 
 
 # every symbol include/osfm_hip.h declares (checked by tests/test_capi_symbols.py)

@@ -328,6 +328,7 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     lap("alloc + lists up");
     OSFM_RETURN_IF(linearize(true));
     lap("first linearize");
+    const auto t_loop = std::chrono::steady_clock::now();
     double x_cost = h_scal[0];
     double grad_max = std::max(h_scal[1], h_scal[3]);
     sum->initial_cost = x_cost;
@@ -424,6 +425,7 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
             fprintf(stderr, "[osfm ba] it %d cost %.9e radius %.3e\n", iteration, x_cost, radius);
     }
 
+    sum->lm_loop_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count();
     lap("LM loop");
     // ---- write back the current iterate --------------------------------------
     std::vector<double> pts0((size_t)4 * M);
