@@ -282,6 +282,10 @@ def main():
             if args.backend == "nccl":
                 torch.cuda.synchronize()
 
+    if world > 1:
+        # page-locked result buffer: the lists go device -> host -> device (gather) at full PCIe rate
+        m.use_result_buffer(D.pinned_array("local", capacity, tdev))
+
     def step():
         out = m.compute(my_pairs, capacity=capacity)
         st = m.stats()
@@ -290,8 +294,7 @@ def main():
         # the only collective of the path: the match lists travel to rank 0
         # (pair order restored there) for RANSAC / track building
         if world > 1:
-            flat = np.concatenate([tv.matches for tv in out] + [np.zeros((0, 2), np.int32)], axis=0)
-            D.gather_match_lists(counts, flat, len(all_pairs), rank, world, device=tdev)
+            D.gather_match_lists(counts, m.last_flat, len(all_pairs), rank, world, device=tdev)
         return out, st, n_corr
 
     for _ in range(args.warmup):

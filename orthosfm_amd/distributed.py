@@ -24,6 +24,23 @@ def owner_of(pair_index: int, world: int) -> int:
     return pair_index % world
 
 
+_pinned = {}
+
+
+def pinned_array(name: str, rows: int, device="cpu"):
+    """A (rows, 2) int32 numpy array backed by page-locked memory when the ranks
+    drive GPUs (torch owns the allocation; the array is reused between calls):
+    the matcher's device-to-host copy and the upload for the gather then run at
+    full PCIe rate instead of through pageable staging."""
+    import torch
+    t = _pinned.get(name)
+    if t is None or t.shape[0] < rows:
+        pin = str(device) != "cpu" and torch.cuda.is_available()
+        t = torch.empty((rows, 2), dtype=torch.int32, pin_memory=pin)
+        _pinned[name] = t
+    return t[:rows].numpy()
+
+
 def gather_match_lists(local_counts, local_corr, num_pairs: int, rank: int, world: int, device="cpu"):
     """Gathers variable-length per-pair correspondence lists on rank 0.
 
@@ -32,8 +49,10 @@ def gather_match_lists(local_counts, local_corr, num_pairs: int, rank: int, worl
     Returns on rank 0 (counts[num_pairs], offsets[num_pairs + 1], corr[total, 2])
     in GLOBAL pair order, on other ranks None.
 
-    Two collectives: an all_gather of the per-rank totals (to size the
-    buffers) and one gather of the padded int32 payload.
+    Two collectives: an all_gather of the per-rank counts (to size the buffers)
+    and one gather of the padded int32 payload.  On rank 0 the lists are put
+    into global pair order ON THE DEVICE (one index_select over the gathered
+    payload) and come to the host in one copy into a page-locked buffer.
     """
     import torch
     import torch.distributed as dist
@@ -47,38 +66,46 @@ def gather_match_lists(local_counts, local_corr, num_pairs: int, rank: int, worl
         return local_counts, offs, local_corr
 
     max_local = len(range(0, num_pairs, world))
-    # header: per-pair counts padded to the largest shard, then the total
-    head = torch.zeros(max_local + 1, dtype=torch.int64, device=device)
-    head[:n_local] = torch.from_numpy(local_counts).to(device)
-    head[max_local] = int(local_counts.sum())
+    # header: per-pair counts padded to the largest shard
+    head = torch.zeros(max_local, dtype=torch.int64)
+    head[:n_local] = torch.from_numpy(local_counts)
+    head = head.to(device)
     heads = [torch.zeros_like(head) for _ in range(world)]
     dist.all_gather(heads, head)
-    totals = [int(h[max_local].item()) for h in heads]
-    width = max(max(totals), 1)
-    payload = torch.zeros(2 * width, dtype=torch.int32, device=device)
+    heads = torch.stack(heads)                               # [world][max_local]
+    totals = heads.sum(dim=1)
+    width = max(int(totals.max().item()), 1)
+    payload = torch.zeros((width, 2), dtype=torch.int32, device=device)
     if local_corr.size:
-        payload[:local_corr.size] = torch.from_numpy(local_corr.reshape(-1)).to(device)
-    bufs = [torch.zeros_like(payload) for _ in range(world)] if rank == 0 else None
+        payload[:local_corr.shape[0]].copy_(torch.from_numpy(local_corr), non_blocking=True)
+    bufs = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
     dist.gather(payload, bufs, dst=0)
     if rank != 0:
         return None
-    counts = np.zeros(num_pairs, dtype=np.int64)
-    per_rank_counts = []
-    for r in range(world):
-        n_r = len(range(r, num_pairs, world))
-        c = heads[r][:n_r].cpu().numpy()
-        per_rank_counts.append(c)
-        counts[r::world] = c
-    offsets = np.concatenate([[0], np.cumsum(counts)])
-    corr = np.zeros((int(offsets[-1]), 2), dtype=np.int32)
-    for r in range(world):
-        data = bufs[r].cpu().numpy()[:2 * totals[r]].reshape(-1, 2)
-        pos = 0
-        for k, gi in enumerate(range(r, num_pairs, world)):
-            n = int(per_rank_counts[r][k])
-            corr[offsets[gi]:offsets[gi] + n] = data[pos:pos + n]
-            pos += n
-    return counts, offsets, corr
+    return assemble_global_order(heads, bufs, num_pairs, world, device)
+
+
+def assemble_global_order(heads, bufs, num_pairs: int, world: int, device="cpu"):
+    """Rank 0's part after the gather: heads [world][max_local] per-pair counts of
+    every rank, bufs[r] the (width, 2) payload of rank r.  Global pair
+    gi = k * world + r is local pair k of rank r (shard_pairs)."""
+    import torch
+    width = bufs[0].shape[0]
+    r_of = torch.arange(num_pairs, device=device) % world
+    k_of = torch.arange(num_pairs, device=device) // world
+    counts = heads[r_of, k_of]                               # [num_pairs], global order
+    offsets = torch.zeros(num_pairs + 1, dtype=torch.int64, device=device)
+    offsets[1:] = torch.cumsum(counts, 0)
+    local_off = torch.cumsum(heads, 1) - heads               # start of local pair k inside rank r's payload
+    src_start = r_of * width + local_off[r_of, k_of]         # into the rank-major concatenation
+    total = int(offsets[-1].item())
+    allbuf = torch.cat(bufs, 0)                              # [world * width][2]
+    pair_of = torch.repeat_interleave(torch.arange(num_pairs, device=device), counts, output_size=total)
+    src = src_start[pair_of] + (torch.arange(total, device=device) - offsets[:-1][pair_of])
+    ordered = allbuf.index_select(0, src)
+    out = pinned_array("gathered", max(total, 1), device)
+    torch.from_numpy(out)[:total].copy_(ordered)             # one device-to-host copy
+    return counts.cpu().numpy(), offsets.cpu().numpy(), out[:total]
 
 
 def max_over_ranks(value: float, world: int, device="cpu") -> float:

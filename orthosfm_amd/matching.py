@@ -137,6 +137,8 @@ class HipExhaustiveMatching:
         capi.check(capi.lib.osfm_match_all(self._h, arr, n, res, capi._ptr(corr, C.c_int32),
                                            C.c_int64(capacity), C.byref(total)))
         corr = corr[:max(int(total.value), 0)].copy() if self._copy_results else corr
+        # all lists of the call, concatenated in pair order (what the per-pair views point into)
+        self.last_flat = corr[:max(int(total.value), 0)]
         empty = np.zeros((0, 2), np.int32)
         verify = bool(self.opts.geometric_verification)
         out = []
@@ -166,6 +168,12 @@ class HipExhaustiveMatching:
             capi._ptr(corr, C.c_int32), corr.shape[0], C.byref(o), C.c_uint64(pair_id),
             capi._ptr(inl, C.c_int32), C.byref(n), capi._ptr(F, C.c_double)))
         return n.value, inl[:max(n.value, 0)].copy(), F.reshape(3, 3)
+
+    def use_result_buffer(self, buf):
+        """Lets the caller provide the (rows, 2) int32 array compute() writes the match
+        lists into, e.g. page-locked memory (orthosfm_amd.distributed.pinned_array)."""
+        assert buf.dtype == np.int32 and buf.ndim == 2 and buf.shape[1] == 2 and buf.flags.c_contiguous
+        self._corr_buf = buf
 
     def _take_buffer(self, rows):
         buf = getattr(self, "_corr_buf", None)

@@ -312,3 +312,33 @@ def test_mixed_operand_forms_in_one_batch(hm):
         exp = np.stack([idx, e12[idx]], axis=1).astype(np.int32)
         assert tv.status == capi.PAIR_MATCHED and np.array_equal(tv.matches, exp), (a, b)
     m.close()
+
+
+def test_gather_reorder_on_device():
+    """Rank 0's device-side reordering of gathered match lists (the part of the
+    multi-GPU path that runs on the GPU under NCCL), fed with fabricated shards."""
+    import torch
+    from orthosfm_amd import distributed as D
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(4)
+    world, num_pairs = 3, 47
+    counts = rng.integers(0, 900, num_pairs)
+    lists = [rng.integers(0, 20000, (c, 2)).astype(np.int32) for c in counts]
+    max_local = len(range(0, num_pairs, world))
+    heads = torch.zeros((world, max_local), dtype=torch.int64)
+    shards = []
+    for r in range(world):
+        mine = list(range(r, num_pairs, world))
+        heads[r, :len(mine)] = torch.from_numpy(counts[mine])
+        shards.append(np.concatenate([lists[g] for g in mine] + [np.zeros((0, 2), np.int32)]))
+    width = max(s.shape[0] for s in shards)
+    bufs = []
+    for s in shards:
+        b = torch.zeros((width, 2), dtype=torch.int32, device=dev)
+        b[:s.shape[0]] = torch.from_numpy(s).to(dev)
+        bufs.append(b)
+    c, off, corr = D.assemble_global_order(heads.to(dev), bufs, num_pairs, world, dev)
+    assert np.array_equal(c, counts) and off[-1] == counts.sum()
+    assert np.array_equal(corr, np.concatenate(lists))
