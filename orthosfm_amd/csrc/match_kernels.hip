@@ -226,19 +226,28 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
     // (q % CH) ^ swz(col) of column col = q / CH.
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
+    // per-lane byte offset inside a tile (loop invariant, 32 bits) and the wave id
+    // as a scalar: the DMA then addresses with a scalar base + vector offset and a
+    // scalar LDS destination, no vector arithmetic per tile
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    unsigned lane_off[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const int q = (c * 4 + wave) * 64 + lane;
+        const int col = q / CH;
+        const int ch = (q % CH) ^ ((col / RPB) % CH);
+        lane_off[c] = (unsigned)(col * D + ch * 16);
+    }
     auto stage_tile = [&](int t, int buf) {
-        const int8_t *src = Bbase + (size_t)(col_begin + t * kTileCols) * D;
+        const int8_t *src = Bbase + (size_t)(col_begin + t * kTileCols) * D;      // uniform
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-            const int q0 = (c * 4 + wave) * 64;           // first chunk of this wave-instruction
-            const int q = q0 + lane;
-            const int col = q / CH;
-            const int ch = (q % CH) ^ ((col / RPB) % CH);
+            const int q0 = (c * 4 + wave_s) * 64;         // first chunk of this wave-instruction
             __builtin_amdgcn_global_load_lds(
-                (glb_void *)(src + (size_t)col * D + ch * 16),
+                (glb_void *)(src + lane_off[c]),
                 (lds_void *)(uintptr_t)(bbuf + buf * TILE_BYTES + q0 * 16), 16, 0, 0);
         }
-        if (!RAW && wave == 0)
+        if (!RAW && wave_s == 0)
             __builtin_amdgcn_global_load_lds(
                 (glb_void *)(corrBbase + col_begin + t * kTileCols + lane),
                 (lds_void *)(uintptr_t)(corrbuf + buf * 64), 4, 0, 0);

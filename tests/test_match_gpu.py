@@ -316,29 +316,42 @@ def test_mixed_operand_forms_in_one_batch(hm):
 
 def test_gather_reorder_on_device():
     """Rank 0's device-side reordering of gathered match lists (the part of the
-    multi-GPU path that runs on the GPU under NCCL), fed with fabricated shards."""
-    import torch
-    from orthosfm_amd import distributed as D
-    if not torch.cuda.is_available():
+    multi-GPU path that runs on the GPU under NCCL), fed with fabricated shards.
+    In a fresh interpreter: torch brings its own ROCm runtime and has to be
+    imported before libosfm_hip.so is loaded, as bench.py does for N > 1."""
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+from orthosfm_amd import distributed as D
+if not torch.cuda.is_available():
+    print("NOGPU"); raise SystemExit(0)
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(4)
+world, num_pairs = 3, 47
+counts = rng.integers(0, 900, num_pairs)
+lists = [rng.integers(0, 20000, (c, 2)).astype(np.int32) for c in counts]
+max_local = len(range(0, num_pairs, world))
+heads = torch.zeros((world, max_local), dtype=torch.int64)
+shards = []
+for r in range(world):
+    mine = list(range(r, num_pairs, world))
+    heads[r, :len(mine)] = torch.from_numpy(counts[mine])
+    shards.append(np.concatenate([lists[g] for g in mine] + [np.zeros((0, 2), np.int32)]))
+width = max(s.shape[0] for s in shards)
+bufs = []
+for s in shards:
+    b = torch.zeros((width, 2), dtype=torch.int32, device=dev)
+    b[:s.shape[0]] = torch.from_numpy(s).to(dev)
+    bufs.append(b)
+c, off, corr = D.assemble_global_order(heads.to(dev), bufs, num_pairs, world, dev)
+assert np.array_equal(c, counts) and off[-1] == counts.sum()
+assert np.array_equal(corr, np.concatenate(lists))
+print("OK")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    if "NOGPU" in out.stdout:
         pytest.skip("torch sees no GPU")
-    dev = torch.device("cuda:0")
-    rng = np.random.default_rng(4)
-    world, num_pairs = 3, 47
-    counts = rng.integers(0, 900, num_pairs)
-    lists = [rng.integers(0, 20000, (c, 2)).astype(np.int32) for c in counts]
-    max_local = len(range(0, num_pairs, world))
-    heads = torch.zeros((world, max_local), dtype=torch.int64)
-    shards = []
-    for r in range(world):
-        mine = list(range(r, num_pairs, world))
-        heads[r, :len(mine)] = torch.from_numpy(counts[mine])
-        shards.append(np.concatenate([lists[g] for g in mine] + [np.zeros((0, 2), np.int32)]))
-    width = max(s.shape[0] for s in shards)
-    bufs = []
-    for s in shards:
-        b = torch.zeros((width, 2), dtype=torch.int32, device=dev)
-        b[:s.shape[0]] = torch.from_numpy(s).to(dev)
-        bufs.append(b)
-    c, off, corr = D.assemble_global_order(heads.to(dev), bufs, num_pairs, world, dev)
-    assert np.array_equal(c, counts) and off[-1] == counts.sum()
-    assert np.array_equal(corr, np.concatenate(lists))
+    assert "OK" in out.stdout
