@@ -498,6 +498,11 @@ int ensure_cashash(osfm_matcher *m)
         for (auto &v : m->views) {
             if (!v.set) continue;
             const int n = type == 0 ? v.ns : v.nu;
+            if (n >= (1 << 17)) {
+                // candidate keys hold the position inside a bucket list in 17 bits
+                set_error("cascade hashing: %d descriptors of one type in a view, at most %d supported", n, (1 << 17) - 1);
+                return OSFM_E_RANGE;
+            }
             OSFM_RETURN_IF(v.cas_hash[type].reserve((size_t)std::max(n, 1) * (dim / 64) * 8));
             OSFM_RETURN_IF(v.cas_bucket[type].reserve((size_t)std::max(n, 1) * kCasGroups));
             OSFM_RETURN_IF(v.cas_start[type].reserve((size_t)kCasGroups * (kCasBuckets + 1) * 4));
