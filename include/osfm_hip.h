@@ -408,6 +408,23 @@ OSFM_API int osfm_tracks_compute(int32_t num_views, const int32_t *view_sizes,
     int64_t track_capacity, int64_t feature_capacity, int64_t *track_offsets,
     int32_t *track_features, uint8_t *track_colors, osfm_tracks_summary *summary);
 
+/* orthosfm::buildGroups (src/data_structures/group.cpp:13-88, completeGroup
+ * :90-155): the order in which the incremental reconstruction adds views, as
+ * groups of group_size views (3 in the reference's algorithms).
+ *   view_ids [num_views]   View::getID() in the order of the `views` vector
+ *                          (views 0 and 1 seed the first group)
+ *   tracks as CSR: track_offsets [num_tracks + 1], track_views [..] = Feature::viewID
+ * out: groups [max_groups][group_size] view ids, group_tracks [max_groups]
+ * (ViewGroup::tracks), *num_groups.  A score is the number of tracks holding
+ * every view of the group (bitset popcounts on the device); candidates are taken
+ * in ascending id order on ties (the reference's OpenMP loop leaves ties to
+ * thread timing).  OSFM_E_STATE when a remaining view shares no track with any
+ * seed group (the reference never terminates there). */
+OSFM_API int osfm_build_groups(int device, int32_t num_views, const int32_t *view_ids,
+    int32_t num_tracks, const int64_t *track_offsets, const int32_t *track_views,
+    int32_t group_size, int32_t max_groups, int32_t *groups, int32_t *group_tracks,
+    int32_t *num_groups);
+
 #ifdef __cplusplus
 }
 #endif

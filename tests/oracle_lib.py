@@ -659,3 +659,23 @@ class OracleCasHash:
             m21 = oracle_cashash_oneway(t, b, h2, b2, a, h1, b1, self.lowe[t])
             parts.append(om.remove_inconsistent(m12, m21))
         return om.combine(parts[0][0], parts[0][1], parts[1][0], parts[1][1])
+
+
+# ---------------------------------------------------------------------------
+# group ordering oracle (oracle/groups_oracle.c)
+# ---------------------------------------------------------------------------
+def oracle_build_groups(view_ids, track_offsets, track_views, group_size=3):
+    lib = oracle()
+    view_ids = np.ascontiguousarray(view_ids, dtype=np.int32)
+    track_offsets = np.ascontiguousarray(track_offsets, dtype=np.int64)
+    track_views = np.ascontiguousarray(track_views, dtype=np.int32)
+    cap = max(len(view_ids), 1)
+    groups = np.zeros((cap, group_size), np.int32)
+    gtracks = np.zeros(cap, np.int32)
+    lib.oracle_build_groups.restype = C.c_int
+    n = lib.oracle_build_groups(len(view_ids), view_ids.ctypes.data_as(C.c_void_p), len(track_offsets) - 1,
+                                track_offsets.ctypes.data_as(C.c_void_p), track_views.ctypes.data_as(C.c_void_p),
+                                group_size, cap, groups.ctypes.data_as(C.c_void_p), gtracks.ctypes.data_as(C.c_void_p))
+    if n < 0:
+        return None
+    return groups[:n].copy(), gtracks[:n].copy()
