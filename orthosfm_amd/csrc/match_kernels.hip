@@ -30,12 +30,6 @@ namespace osfm {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ int med3i(int a, int b, int c)
-{
-    // lowers to v_med3_i32
-    return max(min(a, b), min(max(a, b), c));
-}
-
 // Bijective XCD-aware remap: consecutive logical blocks (which share the
 // column descriptors of one pair) land on the same XCD / L2.
 __device__ __forceinline__ int xcd_remap(int bid, int total)
@@ -76,25 +70,6 @@ __device__ __forceinline__ int med3a(int a, int b, int c)
     int r;
     asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
-}
-
-// Exact running top-2 with three-input ops.  For a state (b >= s) and two new
-// keys x, y:  b' = max3(b, x, y),  s' = max(s, med3(b, x, y))  (the second
-// largest of {b, s, x, y} is s or the median of {b, x, y}).  Four new keys
-// chain two such steps and fold both medians with one max3: 5 ops / 4 keys.
-__device__ __forceinline__ void top2_pair(int &b, int &s, int x, int y)
-{
-    const int m = med3a(b, x, y);
-    b = max3i(b, x, y);
-    s = max(s, m);
-}
-__device__ __forceinline__ void top2_quad(int &b, int &s, int x0, int x1, int x2, int x3)
-{
-    const int m01 = med3a(b, x0, x1);
-    const int b1 = max3i(b, x0, x1);
-    const int m23 = med3a(b1, x2, x3);
-    b = max3i(b1, x2, x3);
-    s = max3i(s, m01, m23);
 }
 
 // Epilogue (per 32x32 accumulator fragment, everything stays in registers).
@@ -546,36 +521,6 @@ accept_match(int ip1, int ip2, int idx1, const LoweTable &tab)
     return idx;
 }
 
-// exact inner product of two stored descriptors (SIFT bytes hold value - 128),
-// four byte products per v_dot4_i32_i8
-template <int DIM, bool SIGNED>
-__device__ __forceinline__ int exact_ip(const int8_t *q, const int8_t *c)
-{
-    const int4 *q4 = reinterpret_cast<const int4 *>(q);
-    const int4 *c4 = reinterpret_cast<const int4 *>(c);
-    int acc = 0, sq = 0, sc = 0;
-#pragma unroll
-    for (int i = 0; i < DIM / 16; ++i) {
-        const int4 a = q4[i], b = c4[i];
-        acc = __builtin_amdgcn_sdot4(a.x, b.x, acc, false);
-        acc = __builtin_amdgcn_sdot4(a.y, b.y, acc, false);
-        acc = __builtin_amdgcn_sdot4(a.z, b.z, acc, false);
-        acc = __builtin_amdgcn_sdot4(a.w, b.w, acc, false);
-        if (!SIGNED) {
-            sq = __builtin_amdgcn_sdot4(a.x, 0x01010101, sq, false);
-            sq = __builtin_amdgcn_sdot4(a.y, 0x01010101, sq, false);
-            sq = __builtin_amdgcn_sdot4(a.z, 0x01010101, sq, false);
-            sq = __builtin_amdgcn_sdot4(a.w, 0x01010101, sq, false);
-            sc = __builtin_amdgcn_sdot4(b.x, 0x01010101, sc, false);
-            sc = __builtin_amdgcn_sdot4(b.y, 0x01010101, sc, false);
-            sc = __builtin_amdgcn_sdot4(b.z, 0x01010101, sc, false);
-            sc = __builtin_amdgcn_sdot4(b.w, 0x01010101, sc, false);
-        }
-    }
-    // sum (x+128)(y+128) = sum xy + 128 (sum x + sum y) + 128*128*DIM
-    return SIGNED ? acc : acc + 128 * (sq + sc) + 128 * 128 * DIM;
-}
-
 // DPP helpers: data movement inside the wave without LDS traffic.
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ int dpp_mov(int v, int old)
@@ -705,7 +650,7 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
     const int lane = threadIdx.x & 63;
     const int nq = dir == 0 ? pd.n1 : pd.n2;
     const int nc = dir == 0 ? pd.n2 : pd.n1;
-    if (blockIdx.x * blockDim.x >= nq) return;           // whole block out of range
+    if ((int)(blockIdx.x * blockDim.x) >= nq) return;    // whole block out of range
     int32_t *out = dir == 0 ? pd.m12 : pd.m21;
     const bool active = q < nq;
 
