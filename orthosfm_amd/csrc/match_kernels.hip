@@ -127,7 +127,15 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
     constexpr int CHUNKS = kTileCols * CH;        // 16-B chunks per tile
     constexpr int CPT = CHUNKS / 256;             // chunks per thread (2 or 1)
     constexpr int BBUF_BYTES = 2 * TILE_BYTES > 16384 ? 2 * TILE_BYTES : 16384;
-    constexpr int kCurNone = RAW ? -(1 << 26) : kKeyNone;   // (-2^26 << 4) == kKeyNone
+    // RAW group keys: running best << 7 | first tile of the group inside the segment
+    // (|ip| < 2^22 for every operand form that takes this path, so the shift is safe)
+    constexpr int kRawShift = 7;
+    constexpr int kCurNone = RAW ? -(1 << 23) : kKeyNone;   // (-2^23 << 7) == kKeyNone
+    static_assert(kSegCols / kTileCols <= (1 << kRawShift), "tile index must fit the key");
+    // The correction-free kernel folds the group closes and the column merges into
+    // the MFMA-paced phases (measured: a vector op between the phases costs about
+    // twice what it costs inside one); the others keep them between phases.
+    constexpr bool PIPE = C0;
     constexpr int NCHUNK = 2 * KS;        // MFMAs (= epilogue chunks) per phase
     constexpr int RPC = 16 / NCHUNK;      // row-direction registers per chunk
     constexpr int CPC = 16 / KS;          // column-direction registers per chunk
@@ -250,8 +258,27 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
 
     // One phase: reduce the finished accumulators `cur` (row fragment PH) while
     // the MFMAs of the other fragment are issued into `nxt`, one per chunk.
-    auto phase = [&](auto ph_c, v16i (&cur)[2], v16i (&nxt)[2], int buf_next) {
+    // Extras a phase can carry (PIPE): CL >= 0 -- close the groups of slots CL, CL + 1
+    // of the OTHER row fragment (its running bests are not touched in this phase)
+    // with first tile `tile0`; MG -- merge the four waves' column partials of tile tm.
+    // Their LDS operands are fetched in front of the first chunk and used from the
+    // third on; everything is straight-line code (a branch would split the block).
+    auto phase = [&](auto ph_c, auto cl_c, auto mg_c, v16i (&cur)[2], v16i (&nxt)[2], int buf_next,
+                     int tile0, int tm) {
         constexpr int PH = decltype(ph_c)::value;
+        constexpr int CL = decltype(cl_c)::value;
+        constexpr bool MG = decltype(mg_c)::value != 0;
+        constexpr int OF = PH ^ 1;
+        int sv[2] = {0, 0};
+        ColPart cpm[4];
+        if (CL >= 0) {
+            sv[0] = rsecbuf[(OF * 16 + CL) * 256 + tid];
+            sv[1] = rsecbuf[(OF * 16 + CL + 1) * 256 + tid];
+        }
+        if (MG) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) cpm[w] = colbuf[((tm & 7) * 4 + w) * 64 + lane];
+        }
 #pragma unroll
         for (int i = 0; i < NCHUNK; ++i) {
             const int cf = i / KS, ks = i % KS;
@@ -303,6 +330,28 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
                 asm volatile("" : "+v"(gg));
                 g[cf] = gg;
             }
+            if (CL >= 0 && (i == 2 || i == 3)) {
+                const int r = CL + (i - 2);
+                const int gk = (int)(((unsigned)rcur[OF][r] << kRawShift) | (unsigned)tile0);
+                rsecbuf[(OF * 16 + r) * 256 + tid] = med3a(rbest[OF][r], sv[i - 2], gk);
+                rbest[OF][r] = max(rbest[OF][r], gk);
+                rcur[OF][r] = kCurNone;
+            }
+            if (MG && (i == 2 || i == 3)) {
+                // chunk 2: fold the four partials; chunk 3: store (no branch: every tile
+                // merged inside the loop exists, its 64 columns lie below n2stride)
+                if (i == 2) {
+                    int k1 = kKeyNone, k2 = kKeyNone;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        k2 = max(max(min(k1, cpm[w].key_best), k2), cpm[w].key_second);
+                        k1 = max(k1, cpm[w].key_best);
+                    }
+                    cpm[0].key_best = k1; cpm[0].key_second = k2;
+                } else {
+                    colout[col_begin + tm * kTileCols + lane] = cpm[0];
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -322,11 +371,11 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
     }
     __syncthreads();        // every wave holds tile 0 in registers: its LDS buffer may be refilled
 
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
+    // per-tile steps shared by the two loop forms below
+    auto tile_top = [&](int t) {
         // tile t+2 into the buffer tile t was read from (clamped: the extra
         // refills of the last tile are never consumed)
-        stage_tile(min(t + 2, ntiles - 1), buf);
+        stage_tile(min(t + 2, ntiles - 1), t & 1);
 #pragma unroll
         for (int cf = 0; cf < 2; ++cf) {
             if (!RAW) {
@@ -338,74 +387,117 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
             }
             col_valid[cf] = (col_begin + t * kTileCols + cf * 32 + lr) < n2;
         }
-
-        phase(IntC<0>(), acc0, acc1, buf ^ 1);   // reduce (rf 0, t), produce (rf 1, t), fetch B(t+1)
-        phase(IntC<1>(), acc1, acc0, buf ^ 1);   // reduce (rf 1, t), produce (rf 0, t+1)
-
-        // close a row-direction group: fold the group bests into (best, second)
-        if ((t % kGroupTiles) == kGroupTiles - 1 || t == ntiles - 1) {
-            const int gidx = t / kGroupTiles;
-            // all LDS reads first (one exposed latency instead of 32): the
-            // accumulator pair consumed by phase 1 is dead here and lends its registers
-            int sv[2][16];
+    };
+    // column direction: this lane's group best as (ip << 8 | group code); the two
+    // half-waves of a column are exchanged with one v_permlane32_swap so that
+    // lane == column within the tile, then the wave's (best, second) goes to LDS.
+    // group code = wave * 2 + half-wave (32 rows: both fragments of the half-wave)
+    auto tile_bottom = [&](int t) {
+        int kk[2];
 #pragma unroll
-            for (int rf = 0; rf < 2; ++rf)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sv[rf][r] = rsecbuf[(rf * 16 + r) * 256 + tid];
-#pragma unroll
-            for (int rf = 0; rf < 2; ++rf)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int gk = RAW ? (int)(((unsigned)rcur[rf][r] << 4) | (unsigned)gidx) : rcur[rf][r];
-                    rsecbuf[(rf * 16 + r) * 256 + tid] = med3a(rbest[rf][r], sv[rf][r], gk);
-                    rbest[rf][r] = max(rbest[rf][r], gk);
-                    rcur[rf][r] = kCurNone;
-                }
+        for (int cf = 0; cf < 2; ++cf) {
+            kk[cf] = (int)((unsigned)(g[cf] + cbj[cf]) << 8) | gcode;
+            if (MASKED) kk[cf] = g[cf] < -(1 << 27) ? kKeyNone : kk[cf];   // no valid row in this lane
         }
-
-        // column direction: this lane's group best as (ip << 8 | group code); the two
-        // half-waves of a column are exchanged with one v_permlane32_swap so that
-        // lane == column within the tile, then the wave's (best, second) goes to LDS.
-        // group code = wave * 2 + half-wave (32 rows: both fragments of the half-wave)
-        {
-            int kk[2];
-#pragma unroll
-            for (int cf = 0; cf < 2; ++cf) {
-                kk[cf] = (int)((unsigned)(g[cf] + cbj[cf]) << 8) | gcode;
-                if (MASKED) kk[cf] = g[cf] < -(1 << 27) ? kKeyNone : kk[cf];   // no valid row in this lane
-            }
-            const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)kk[0], (unsigned)kk[1], false, false);
-            const int x0 = (int)sw[0], x1 = (int)sw[1];
-            ColPart cp;
-            cp.key_best = max(x0, x1);
-            cp.key_second = min(x0, x1);
-            colbuf[((t & 7) * 4 + wave) * 64 + lane] = cp;
-        }
-
+        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)kk[0], (unsigned)kk[1], false, false);
+        const int x0 = (int)sw[0], x1 = (int)sw[1];
+        ColPart cp;
+        cp.key_best = max(x0, x1);
+        cp.key_second = min(x0, x1);
+        colbuf[((t & 7) * 4 + wave) * 64 + lane] = cp;
         __syncthreads();
+    };
+    // close the open row-direction group of every slot: fold the group bests into
+    // (best, second); first_tile(rf, r) = first tile of that slot's open group.
+    // All LDS reads first (one exposed latency instead of 32).
+    auto close_all = [&](auto first_tile) {
+        int sv[2][16];
+#pragma unroll
+        for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[rf][r] = rsecbuf[(rf * 16 + r) * 256 + tid];
+#pragma unroll
+        for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gk = RAW ? (int)(((unsigned)rcur[rf][r] << kRawShift) | (unsigned)first_tile(rf, r)) : rcur[rf][r];
+                rsecbuf[(rf * 16 + r) * 256 + tid] = med3a(rbest[rf][r], sv[rf][r], gk);
+                rbest[rf][r] = max(rbest[rf][r], gk);
+                rcur[rf][r] = kCurNone;
+            }
+    };
+    // this wave's share of a batch of four tiles: merge the four waves' partials of tile tm
+    auto merge_tile = [&](int tm) {
+        int k1 = kKeyNone, k2 = kKeyNone;
+        ColPart cp[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) cp[w] = colbuf[((tm & 7) * 4 + w) * 64 + lane];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            k2 = max(max(min(k1, cp[w].key_best), k2), cp[w].key_second);
+            k1 = max(k1, cp[w].key_best);
+        }
+        const int col = col_begin + tm * kTileCols + lane;
+        if (col < n2stride) {
+            ColPart out;
+            out.key_best = k1;
+            out.key_second = k2;
+            colout[col] = out;
+        }
+    };
 
+    int t = 0;
+    if (PIPE) {
+        // Cycles of eight tiles, fully unrolled: every phase carries a fixed share of
+        // the work that would otherwise sit between phases, so nothing has to be
+        // chosen at run time (a run-time choice between phase bodies costs a
+        // register copy of the accumulators at the join).
+        //   phase (u, 0) closes slots 2u, 2u+1 of fragment 1 -- their groups are the
+        //     eight tiles t-8 .. t-1;  phase (u, 1) closes slots 2u, 2u+1 of fragment 0
+        //     -- tiles t-7 .. t.  Group boundaries are staggered by slot; the key
+        //     carries each group's first tile, which is all the finish kernel needs.
+        //   phase (1, 0) and (5, 0) merge the column partials of the four tiles before
+        //     t-1 (for the very first cycle the result of (1, 0) is a throw-away
+        //     that (5, 0) overwrites: same wave, same addresses, program order).
+        // In the first cycle the closes of not yet started groups fold "nothing"
+        // into (best, second): a no-op.
+        static_assert(kGroupTiles == 8, "the staggered schedule assumes 8-tile groups");
+        auto cycle_tile = [&](auto u_c, int t0) {
+            constexpr int u = decltype(u_c)::value;
+            const int tt = t0 + u;
+            tile_top(tt);
+            const int bn = (tt & 1) ^ 1;
+            const int tm = max(tt - 5, 0) + wave;
+            phase(IntC<0>(), IntC<2 * u>(), IntC<(u == 1 || u == 5) ? 1 : 0>(), acc0, acc1, bn, max(tt - 8, 0), tm);
+            phase(IntC<1>(), IntC<2 * u>(), IntC<0>(), acc1, acc0, bn, max(tt - 7, 0), 0);
+            tile_bottom(tt);
+        };
+        for (; t + 8 <= ntiles; t += 8) {
+            cycle_tile(IntC<0>(), t); cycle_tile(IntC<1>(), t); cycle_tile(IntC<2>(), t); cycle_tile(IntC<3>(), t);
+            cycle_tile(IntC<4>(), t); cycle_tile(IntC<5>(), t); cycle_tile(IntC<6>(), t); cycle_tile(IntC<7>(), t);
+        }
+        if (t > 0) merge_tile(t - 4 + wave);     // the batch of the last four tiles of the last cycle
+        // the open groups of all slots (staggered starts), before the remaining tiles
+        // start one common group
+        const int tc = t;
+        close_all([&](int rf, int r) { return max(tc - (rf ? 8 : 7) + (r >> 1), 0); });
+    }
+    // tiles outside whole cycles (all tiles of the kernels without the staggered schedule)
+    const int t_tail = t;
+    for (; t < ntiles; ++t) {
+        tile_top(t);
+        phase(IntC<0>(), IntC<-1>(), IntC<0>(), acc0, acc1, (t & 1) ^ 1, 0, 0);   // reduce (rf 0, t), produce (rf 1, t), fetch B(t+1)
+        phase(IntC<1>(), IntC<-1>(), IntC<0>(), acc1, acc0, (t & 1) ^ 1, 0, 0);   // reduce (rf 1, t), produce (rf 0, t+1)
+        if (PIPE ? t == ntiles - 1 : ((t % kGroupTiles) == kGroupTiles - 1 || t == ntiles - 1)) {
+            const int first = PIPE ? t_tail : (t / kGroupTiles) * kGroupTiles;
+            close_all([&](int, int) { return first; });
+        }
+        tile_bottom(t);
         // every fourth tile all four waves merge one tile each of the last batch
         // (the same work in every wave: nobody is waited for at the next barrier)
         if ((t & 3) == 3 || t == ntiles - 1) {
             const int tm = (t & ~3) + wave;
-            if (tm <= t) {
-                int k1 = kKeyNone, k2 = kKeyNone;
-                ColPart cp[4];
-#pragma unroll
-                for (int w = 0; w < 4; ++w) cp[w] = colbuf[((tm & 7) * 4 + w) * 64 + lane];
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    k2 = max(max(min(k1, cp[w].key_best), k2), cp[w].key_second);
-                    k1 = max(k1, cp[w].key_best);
-                }
-                const int col = col_begin + tm * kTileCols + lane;
-                if (col < n2stride) {
-                    ColPart out;
-                    out.key_best = k1;
-                    out.key_second = k2;
-                    colout[col] = out;
-                }
-            }
+            if (tm <= t) merge_tile(tm);
         }
     }
 
@@ -430,17 +522,19 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
                 const int src = wave * 64 + h * 32 + l;
                 const int kbest = bb[r * 256 + src];
                 const int ksec = rsecbuf[(rf * 16 + r) * 256 + src];
-                if (ksec != kKeyNone) sec = max(sec, RAW ? (ksec >> 4) : (ksec >> 8));
+                if (ksec != kKeyNone) sec = max(sec, RAW ? (ksec >> kRawShift) : (ksec >> 8));
                 if (kbest == kKeyNone) continue;
-                const int ip = RAW ? (kbest >> 4) : (kbest >> 8);
-                const int col = RAW ? col_begin + (kbest & 15) * kGroupTiles * kTileCols + l
+                const int ip = RAW ? (kbest >> kRawShift) : (kbest >> 8);
+                const int col = RAW ? col_begin + (kbest & ((1 << kRawShift) - 1)) * kTileCols + l
                                     : col_begin + (kbest & 255) * 32 + l;
                 if (ip > bip || (ip == bip && col > bcol)) { sec = max(sec, bip); bip = ip; bcol = col; }
                 else sec = max(sec, ip);
             }
             const int row = row0 + rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             RowPart out;
-            out.ip_best = bip; out.idx_best = bcol; out.ip_second = sec; out.pad = 0;
+            // pad = 1: idx_best is the first column of the winning (lane, group) stream,
+            // the group being the eight tiles from there; 0: the exact best column
+            out.ip_best = bip; out.idx_best = bcol; out.ip_second = sec; out.pad = RAW ? 1 : 0;
             rp[row] = out;
         }
     }
@@ -560,7 +654,7 @@ __device__ __forceinline__ int wave_max(int v)
 template <int DIM, int DIR>
 __device__ __forceinline__ void
 rescan_groups(const MatchProblem &pd, const int (&q)[2], const int (&idx1)[2], const int (&code)[2],
-    int lane, int (&idx_out)[2], int (&best_out)[2], int (&second_out)[2])
+    const int (&kind)[2], int lane, int (&idx_out)[2], int (&best_out)[2], int (&second_out)[2])
 {
     constexpr int LPC = DIM / 16;       // lanes per candidate (8: SIFT, 4: SURF)
     constexpr int CPL = 64 / LPC;       // candidates per wave-wide load
@@ -583,7 +677,11 @@ rescan_groups(const MatchProblem &pd, const int (&q)[2], const int (&idx1)[2], c
             // first column of the group's first tile, lane slot inside the tiles
             const int seg = idx1[u] / kSegCols, off = idx1[u] - seg * kSegCols;
             lr = off & 31;
-            base0 = seg * kSegCols + ((off >> 6) / kGroupTiles) * kGroupTiles * kTileCols;
+            // kind 1 (raw-operand kernels): idx1 is the first column of the group's first
+            // tile (groups may start at any tile); kind 0 (keyed kernels): the exact best
+            // column, its group is the aligned run of kGroupTiles tiles around it
+            const int tile = off >> 6;
+            base0 = seg * kSegCols + (kind[u] ? tile : (tile / kGroupTiles) * kGroupTiles) * kTileCols;
         } else {
             // first row of the wave's 64-row strip, half-wave
             rbase = idx1[u] * kRowsPerBlock + (code[u] >> 1) * 64;
@@ -656,7 +754,7 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
 
     // ip1 / idx1: exact best; ip2: second largest GROUP best (lower bound of the
     // true second); code: group of the best (dir 1), idx1 = its row block there
-    int ip1 = INT_MIN, ip2 = INT_MIN, idx1 = 0, code = 0;
+    int ip1 = INT_MIN, ip2 = INT_MIN, idx1 = 0, code = 0, kind1 = 0;
     if (active && nc > 0) {
         if (dir == 0) {
             const int64_t stride = (int64_t)pd.nrb * kRowsPerBlock;
@@ -670,7 +768,7 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
                 const RowPart p = rowparts[pd.rowpart_off + sgi * stride + slot];
                 // later segment wins ties (its columns have larger indices)
                 ip2 = max(max(ip2, p.ip_second), min(ip1, p.ip_best));
-                if (p.ip_best >= ip1 && p.ip_best != INT_MIN) { ip1 = p.ip_best; idx1 = p.idx_best; }
+                if (p.ip_best >= ip1 && p.ip_best != INT_MIN) { ip1 = p.ip_best; idx1 = p.idx_best; kind1 = p.pad; }
             }
         } else {
             for (int rb = 0; rb < pd.nrb; ++rb) {
@@ -702,7 +800,7 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
     // i.e. when no real candidate reaches 0 -- then it is the value to test.
     unsigned long long todo = __ballot(refine);
     while (todo) {
-        int src[2], qs[2], is[2], cs[2], idx[2], found[2], second[2];
+        int src[2], qs[2], is[2], cs[2], ks[2], idx[2], found[2], second[2];
         src[0] = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
         src[1] = todo ? __ffsll((long long)todo) - 1 : src[0];     // odd count: the last one twice
@@ -712,9 +810,10 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
             qs[u] = __builtin_amdgcn_readlane(q, src[u]);
             is[u] = __builtin_amdgcn_readlane(idx1, src[u]);
             cs[u] = __builtin_amdgcn_readlane(code, src[u]);
+            ks[u] = __builtin_amdgcn_readlane(kind1, src[u]);
         }
-        if (dir == 0) rescan_groups<DIM, 0>(pd, qs, is, cs, lane, idx, found, second);
-        else rescan_groups<DIM, 1>(pd, qs, is, cs, lane, idx, found, second);
+        if (dir == 0) rescan_groups<DIM, 0>(pd, qs, is, cs, ks, lane, idx, found, second);
+        else rescan_groups<DIM, 1>(pd, qs, is, cs, ks, lane, idx, found, second);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
             if (lane == src[u]) res = accept_match(found[u], max(second[u], ip2), idx[u], tab);
