@@ -263,10 +263,13 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
     // with first tile `tile0`; MG -- merge the four waves' column partials of tile tm.
     // Their LDS operands are fetched in front of the first chunk and used from the
     // third on; everything is straight-line code (a branch would split the block).
-    auto phase = [&](auto ph_c, auto cl_c, auto mg_c, v16i (&cur)[2], v16i (&nxt)[2], int buf_next,
+    // RS >= 0 -- slots RS, RS + 1 of THIS fragment were closed by the phase before:
+    // their running best restarts from this tile's scores (no reset needed there).
+    auto phase = [&](auto ph_c, auto cl_c, auto mg_c, auto rs_c, v16i (&cur)[2], v16i (&nxt)[2], int buf_next,
                      int tile0, int tm) {
         constexpr int PH = decltype(ph_c)::value;
         constexpr int CL = decltype(cl_c)::value;
+        constexpr int RS = decltype(rs_c)::value;
         constexpr bool MG = decltype(mg_c)::value != 0;
         constexpr int OF = PH ^ 1;
         int sv[2] = {0, 0};
@@ -301,7 +304,8 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
 #pragma unroll
             for (int r = i * RPC; r < (i + 1) * RPC; ++r) {
                 if (RAW) {
-                    rcur[PH][r] = max(max(rcur[PH][r], cur[0][r]), cur[1][r]);
+                    if (RS >= 0 && (r == RS || r == RS + 1)) rcur[PH][r] = max(cur[0][r], cur[1][r]);
+                    else rcur[PH][r] = max(max(rcur[PH][r], cur[0][r]), cur[1][r]);
                 } else {
                     int k0 = (int)(((unsigned)cur[0][r] << 8) + (unsigned)cjt[0]);
                     int k1 = (int)(((unsigned)cur[1][r] << 8) + (unsigned)cjt[1]);
@@ -335,7 +339,7 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
                 const int gk = (int)(((unsigned)rcur[OF][r] << kRawShift) | (unsigned)tile0);
                 rsecbuf[(OF * 16 + r) * 256 + tid] = med3a(rbest[OF][r], sv[i - 2], gk);
                 rbest[OF][r] = max(rbest[OF][r], gk);
-                rcur[OF][r] = kCurNone;
+                // no reset: the next phase that touches this slot restarts it (RS)
             }
             if (MG && (i == 2 || i == 3)) {
                 // chunk 2: fold the four partials; chunk 3: store (no branch: every tile
@@ -468,15 +472,20 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
             tile_top(tt);
             const int bn = (tt & 1) ^ 1;
             const int tm = max(tt - 5, 0) + wave;
-            phase(IntC<0>(), IntC<2 * u>(), IntC<(u == 1 || u == 5) ? 1 : 0>(), acc0, acc1, bn, max(tt - 8, 0), tm);
-            phase(IntC<1>(), IntC<2 * u>(), IntC<0>(), acc1, acc0, bn, max(tt - 7, 0), 0);
+            // restarts: fragment 0 slots closed by phase (u-1, 1), fragment 1 slots by phase (u, 0)
+            phase(IntC<0>(), IntC<2 * u>(), IntC<(u == 1 || u == 5) ? 1 : 0>(), IntC<2 * ((u + 7) & 7)>(), acc0, acc1, bn,
+                max(tt - 8, 0), tm);
+            phase(IntC<1>(), IntC<2 * u>(), IntC<0>(), IntC<2 * u>(), acc1, acc0, bn, max(tt - 7, 0), 0);
             tile_bottom(tt);
         };
         for (; t + 8 <= ntiles; t += 8) {
             cycle_tile(IntC<0>(), t); cycle_tile(IntC<1>(), t); cycle_tile(IntC<2>(), t); cycle_tile(IntC<3>(), t);
             cycle_tile(IntC<4>(), t); cycle_tile(IntC<5>(), t); cycle_tile(IntC<6>(), t); cycle_tile(IntC<7>(), t);
         }
-        if (t > 0) merge_tile(t - 4 + wave);     // the batch of the last four tiles of the last cycle
+        if (t > 0) {
+            merge_tile(t - 4 + wave);            // the batch of the last four tiles of the last cycle
+            rcur[0][14] = kCurNone; rcur[0][15] = kCurNone;   // closed by the last phase, never restarted
+        }
         // the open groups of all slots (staggered starts), before the remaining tiles
         // start one common group
         const int tc = t;
@@ -486,8 +495,8 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
     const int t_tail = t;
     for (; t < ntiles; ++t) {
         tile_top(t);
-        phase(IntC<0>(), IntC<-1>(), IntC<0>(), acc0, acc1, (t & 1) ^ 1, 0, 0);   // reduce (rf 0, t), produce (rf 1, t), fetch B(t+1)
-        phase(IntC<1>(), IntC<-1>(), IntC<0>(), acc1, acc0, (t & 1) ^ 1, 0, 0);   // reduce (rf 1, t), produce (rf 0, t+1)
+        phase(IntC<0>(), IntC<-1>(), IntC<0>(), IntC<-1>(), acc0, acc1, (t & 1) ^ 1, 0, 0);   // reduce (rf 0, t), produce (rf 1, t), fetch B(t+1)
+        phase(IntC<1>(), IntC<-1>(), IntC<0>(), IntC<-1>(), acc1, acc0, (t & 1) ^ 1, 0, 0);   // reduce (rf 1, t), produce (rf 0, t+1)
         if (PIPE ? t == ntiles - 1 : ((t % kGroupTiles) == kGroupTiles - 1 || t == ntiles - 1)) {
             const int first = PIPE ? t_tail : (t / kGroupTiles) * kGroupTiles;
             close_all([&](int, int) { return first; });
