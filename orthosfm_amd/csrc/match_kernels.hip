@@ -720,7 +720,11 @@ rescan_groups(const MatchProblem &pd, const int (&q)[2], const int (&idx1)[2], c
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        int vbest = INT_MIN, vidx = -1, vsec = INT_MIN;     // over this lane group's candidates
+        // key = score * 32 + position in the group: one maximum yields value and index.
+        // Keys are distinct, so (best, second) of a lane is a max / med3 pair.  Equal
+        // SCORES are told apart by position only; the caller defers every accepted
+        // tie for best to the sequential-scan kernel, so that order never shows.
+        int kbest = INT_MIN, ksec = INT_MIN;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             int acc = __builtin_amdgcn_sdot4(qv[u].x, cv[u][j].x, 0, false);
@@ -730,18 +734,21 @@ rescan_groups(const MatchProblem &pd, const int (&q)[2], const int (&idx1)[2], c
             acc += dpp_mov<kDppXor1>(acc, 0);
             acc += dpp_mov<kDppXor2>(acc, 0);
             if (LPC == 8) acc += dpp_mov<kDppHalfMirror>(acc, 0);
-            const int v = cand[u][j] >= 0 ? acc + corr_q[u] + corr_c[u][j] : INT_MIN;
-            // larger index wins ties (later column / later ORIGINAL row: the gathered
-            // order of special rows need not be monotone)
-            if (v > vbest || (v == vbest && cand[u][j] > vidx)) { vsec = vbest; vbest = v; vidx = cand[u][j]; }
-            else if (v > vsec) vsec = v;
+            const int key = cand[u][j] >= 0 ? (acc + corr_q[u] + corr_c[u][j]) * 32 + (j * CPL + k) : INT_MIN;
+            ksec = med3a(kbest, ksec, key);                // kbest >= ksec: the middle one
+            kbest = max(kbest, key);
         }
-        const int best = wave_max(vbest);
-        const int widx = wave_max(vbest == best ? vidx : -1);
-        const bool winner = vbest == best && vidx == widx;
-        second_out[u] = wave_max(winner ? vsec : vbest);
+        const int wbest = wave_max(kbest);
+        const int wsec = wave_max(kbest == wbest ? ksec : kbest);
+        // position -> candidate index: the lane group that holds it broadcasts
+        const int pos = wbest & 31;
+        int widx = 0;
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            if ((pos / CPL) == j) widx = __builtin_amdgcn_readlane(cand[u][j], (pos % CPL) * LPC);
         idx_out[u] = max(widx, 0);
-        best_out[u] = best;
+        best_out[u] = wbest >> 5;
+        second_out[u] = wsec == INT_MIN ? INT_MIN : wsec >> 5;
     }
 }
 
@@ -749,15 +756,21 @@ template <int DIM, bool SIGNED>
 __global__ __launch_bounds__(128) void
 match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__restrict__ rowparts,
     const ColPart *__restrict__ colparts, LoweTable tab, int force_exact,
-    ExactItem *__restrict__ exact_items, int32_t *__restrict__ exact_count, int exact_cap)
+    ExactItem *__restrict__ exact_items, int32_t *__restrict__ exact_count, int exact_cap,
+    int blocks_per_dir, int total_blocks)
 {
-    const MatchProblem &pd = problems[blockIdx.y];
-    const int dir = blockIdx.z;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    // every XCD works through a contiguous run of problems, so the descriptors the
+    // rescans gather from are fetched into one L2 instead of all eight
+    const int lin = xcd_remap(blockIdx.x, total_blocks);
+    const int problem = lin / (2 * blocks_per_dir), within = lin - problem * 2 * blocks_per_dir;
+    const MatchProblem &pd = problems[problem];
+    const int dir = within / blocks_per_dir;
+    const int block_x = within - dir * blocks_per_dir;
+    const int q = block_x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int nq = dir == 0 ? pd.n1 : pd.n2;
     const int nc = dir == 0 ? pd.n2 : pd.n1;
-    if ((int)(blockIdx.x * blockDim.x) >= nq) return;    // whole block out of range
+    if ((int)(block_x * blockDim.x) >= nq) return;    // whole block out of range
     int32_t *out = dir == 0 ? pd.m12 : pd.m21;
     const bool active = q < nq;
 
@@ -808,6 +821,7 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
     // differs from ip1 only when ip1 = 0 came from a padding column (raw path),
     // i.e. when no real candidate reaches 0 -- then it is the value to test.
     unsigned long long todo = __ballot(refine);
+    int rbest = 0, rsecond = 0, ridx = 0;
     while (todo) {
         int src[2], qs[2], is[2], cs[2], ks[2], idx[2], found[2], second[2];
         src[0] = __ffsll((long long)todo) - 1;
@@ -825,13 +839,21 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
         else rescan_groups<DIM, 1>(pd, qs, is, cs, ks, lane, idx, found, second);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
-            if (lane == src[u]) res = accept_match(found[u], max(second[u], ip2), idx[u], tab);
+            if (lane == src[u]) { rbest = found[u]; rsecond = second[u]; ridx = idx[u]; }
+    }
+    if (refine) {
+        // the table lookups of all rescanned queries of the wave at once
+        rsecond = max(rsecond, ip2);
+        res = accept_match(rbest, rsecond, ridx, tab);
+        // accepted although two candidates tie for best (0/0 distances): the index the
+        // reference keeps depends on scan order -- leave it to the sequential scan
+        if (res >= 0 && rsecond == rbest) exact = true;
     }
     if (exact) {
         const int slot = atomicAdd(exact_count, 1);
         if (slot < exact_cap) {
             ExactItem it;
-            it.problem = blockIdx.y; it.dir = dir; it.query = q;
+            it.problem = problem; it.dir = dir; it.query = q;
             exact_items[slot] = it;
         }
     }
@@ -843,13 +865,16 @@ void launch_match_finish(const MatchProblem *d_problems, int num_problems, int m
     ExactItem *exact_items, int32_t *exact_count, int exact_cap, hipStream_t s)
 {
     if (num_problems <= 0 || max_n <= 0) return;
-    dim3 grid((max_n + 127) / 128, num_problems, 2);
+    const int blocks_per_dir = (max_n + 127) / 128;
+    const int64_t total = (int64_t)blocks_per_dir * 2 * num_problems;
+    if (total > INT_MAX) return;    // cannot happen: launches are sized by pairs_per_batch
+    const dim3 grid((unsigned)total);
     if (tab.is_signed)
         hipLaunchKernelGGL((match_finish_kernel<64, true>), grid, dim3(128), 0, s, d_problems, rowparts,
-            colparts, tab, force_exact, exact_items, exact_count, exact_cap);
+            colparts, tab, force_exact, exact_items, exact_count, exact_cap, blocks_per_dir, (int)total);
     else
         hipLaunchKernelGGL((match_finish_kernel<128, false>), grid, dim3(128), 0, s, d_problems, rowparts,
-            colparts, tab, force_exact, exact_items, exact_count, exact_cap);
+            colparts, tab, force_exact, exact_items, exact_count, exact_cap, blocks_per_dir, (int)total);
 }
 
 // ---------------------------------------------------------------------------
