@@ -29,18 +29,31 @@ __device__ __forceinline__ double readlane_d(double x, int l)
     return __hiloint2double(hi, lo);
 }
 
+// 1 / sqrt(d) to double precision: v_rsq_f64 seed and two Newton steps.  The
+// pivot chain of the factorisation is serial, so its length in dependent
+// instructions (a sqrt and a divide are ~70) is what the panel kernel waits for.
+__device__ __forceinline__ double rsqrt_newton(double d)
+{
+    const double h = 0.5 * d;
+    double y = __builtin_amdgcn_rsq(d);
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    return y;
+}
+
 // One wave per workgroup.  Every workgroup factors the 32x32 diagonal block
 // with its rows held in registers (lane r = row r; the pivot column is
-// broadcast with v_readlane), workgroup 0 publishes the factor, the others solve
-// X L_kk^T = A_ik for 64 rows of the panel (lane = row, X in registers, L
-// broadcast from LDS).
+// broadcast with v_readlane; pivots enter as reciprocal square roots),
+// workgroup 0 publishes the factor, the others solve X L_kk^T = A_ik for 64 rows
+// of the panel (lane = row, X in registers, L broadcast from LDS, stored
+// transposed so that two multipliers arrive per ds_read_b128).
 __global__ __launch_bounds__(64, 1) void
 chol_panel_kernel(double *A, int ld, int nblk, int k, double *Ldiag, int *info)
 {
-    __shared__ double Ls[NB][NB + 1];
+    __shared__ __attribute__((aligned(16))) double LsT[NB][NB];     // LsT[c][m] = L[m][c]
     const int lane = threadIdx.x, r = lane & 31;
     const double *Akk = A + (size_t)(k * NB + r) * ld + k * NB;
-    double L[NB];
+    double L[NB], dinv[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) L[c] = Akk[c];
     int bad = 0;
@@ -48,8 +61,9 @@ chol_panel_kernel(double *A, int ld, int nblk, int k, double *Ldiag, int *info)
     for (int j = 0; j < NB; ++j) {
         double d = readlane_d(L[j], j);
         if (!(d > 0.0)) { d = 1.0; bad = j + 1; }
-        const double piv = sqrt(d);
-        const double lj = (r == j && bad == j + 1) ? 1.0 : L[j] / piv;   // lane j: d / sqrt(d) = sqrt(d)
+        const double rinv = rsqrt_newton(d);
+        dinv[j] = rinv;
+        const double lj = (r == j && bad == j + 1) ? 1.0 : L[j] * rinv;   // lane j: d / sqrt(d) = sqrt(d)
         L[j] = lj;
 #pragma unroll
         for (int c = j + 1; c < NB; ++c) L[c] -= lj * readlane_d(lj, c);   // meaningful for r >= c
@@ -65,7 +79,7 @@ chol_panel_kernel(double *A, int ld, int nblk, int k, double *Ldiag, int *info)
     }
     if (lane < NB) {
 #pragma unroll
-        for (int c = 0; c < NB; ++c) Ls[r][c] = c <= r ? L[c] : 0.0;
+        for (int c = 0; c < NB; ++c) LsT[c][r] = c <= r ? L[c] : 0.0;
     }
     __syncthreads();
     const int row = (k + 1) * NB + (blockIdx.x - 1) * 64 + lane;
@@ -79,10 +93,10 @@ chol_panel_kernel(double *A, int ld, int nblk, int k, double *Ldiag, int *info)
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
         asm volatile("" ::: "memory");    // keep the LDS reads of step c behind step c-1
-        const double xc = X[c] / Ls[c][c];
+        const double xc = X[c] * dinv[c];
         X[c] = xc;
 #pragma unroll
-        for (int m = c + 1; m < NB; ++m) X[m] -= xc * Ls[m][c];
+        for (int m = c + 1; m < NB; ++m) X[m] -= xc * LsT[c][m];
     }
 #pragma unroll
     for (int c = 0; c < NB; ++c) Ar[c] = X[c];
