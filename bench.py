@@ -10,8 +10,11 @@ One "step" = one pass of the hot path over one synthetic image set:
     of configs[3] (200 quaternion cameras, 100k tracks) -- see `ba` in the
     JSON line.
 `value` = image pairs matched per second over all ranks (pairs are sharded
-across ranks with no data-path collective; the match lists are gathered to
-rank 0 over RCCL at the end of every step, inside the timed region).
+across ranks with no data-path collective; the match lists reach rank 0 at the
+end of every step, inside the timed region: on one node every rank's lists go
+straight into its slice of a shared page-locked host segment and only the
+per-pair counts are all-gathered over RCCL -- `--exchange rccl` gathers the
+lists themselves over xGMI instead, as a multi-node run would).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -68,7 +71,30 @@ def parse():
     ap.add_argument("--no-lowres-gate", action="store_true",
                     help="kernel experiments only: match every pair in full whatever the results are")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsal)")
+    ap.add_argument("--exchange", default="shm", choices=["shm", "rccl"],
+                    help="how the match lists reach rank 0 for N > 1: shared host segment (one node) or RCCL gather")
     return ap.parse_args()
+
+
+def exchanged_tracks(gathered, all_pairs, V, F, how):
+    """Rank 0 after an N > 1 pass: track building over the lists of ALL ranks, read
+    in place from the shared segment (shm) or from the gathered buffer (rccl)."""
+    from orthosfm_amd import capi, tracks as T
+    pairs = (capi.Pair * len(all_pairs))()
+    for i, (a, b) in enumerate(all_pairs):
+        pairs[i].view_1, pairs[i].view_2 = a, b
+    sizes = np.full(V, F, dtype=np.int32)
+    t0 = time.perf_counter()
+    if how == "shm":
+        counts, starts, corr = gathered
+        res = T.compute_flat_ranges(sizes, None, pairs, starts, counts, corr)
+    else:
+        counts, offs, corr = gathered
+        res = T.compute_flat(sizes, None, pairs, offs, np.ascontiguousarray(corr))
+    ms = (time.perf_counter() - t0) * 1e3
+    return {"how": "shared host segment, lists consumed in place" if how == "shm" else "RCCL gather to rank 0",
+            "correspondences_all_ranks": int(np.sum(counts)), "tracks": int(res[4].num_tracks),
+            "invalid_tracks": int(res[4].num_invalid_tracks), "track_building_ms": ms}
 
 
 def cpu_baseline(iset, pairs, n_sample):
@@ -282,9 +308,18 @@ def main():
             if args.backend == "nccl":
                 torch.cuda.synchronize()
 
-    if world > 1:
+    store = None
+    if world > 1 and args.exchange == "shm":
+        # the matcher writes its lists into this rank's slice of the shared segment
+        try:
+            store = D.SharedMatchStore(F * len(range(0, len(all_pairs), world)), rank, world, tdev)   # same on every rank
+            m.use_result_buffer(store.slice)
+        except D.SharedSegmentUnavailable:
+            args.exchange = "rccl"
+    if world > 1 and store is None:
         # page-locked result buffer: the lists go device -> host -> device (gather) at full PCIe rate
         m.use_result_buffer(D.pinned_array("local", capacity, tdev))
+    gathered = [None]
 
     def step():
         out = m.compute(my_pairs, capacity=capacity)
@@ -293,8 +328,10 @@ def main():
         n_corr = int(counts.sum())
         # the only collective of the path: the match lists travel to rank 0
         # (pair order restored there) for RANSAC / track building
-        if world > 1:
-            D.gather_match_lists(counts, m.last_flat, len(all_pairs), rank, world, device=tdev)
+        if store is not None:
+            gathered[0] = store.collect(counts, len(all_pairs))
+        elif world > 1:
+            gathered[0] = D.gather_match_lists(counts, m.last_flat, len(all_pairs), rank, world, device=tdev)
         return out, st, n_corr
 
     for _ in range(args.warmup):
@@ -341,6 +378,11 @@ def main():
             cascade = cascade_bench(iset, V, my_pairs, capacity, device_index, not args.no_cpu_baseline)
         except Exception as e:
             cascade = {"error": str(e)}
+
+    # N > 1: rank 0 consumes the lists of all ranks where the exchange left them
+    exchanged = None
+    if rank == 0 and world > 1 and gathered[0] is not None:
+        exchanged = exchanged_tracks(gathered[0], all_pairs, V, F, args.exchange)
 
     tracks = None
     if rank == 0 and world == 1 and not args.no_ba:
@@ -396,6 +438,8 @@ def main():
         }
         if tracks is not None:
             line["tracks"] = tracks
+        if exchanged is not None:
+            line["exchange"] = exchanged
         if cascade is not None:
             line["cascade_hashing"] = cascade
         if verified is not None:

@@ -408,6 +408,18 @@ OSFM_API int osfm_tracks_compute(int32_t num_views, const int32_t *view_sizes,
     int64_t track_capacity, int64_t feature_capacity, int64_t *track_offsets,
     int32_t *track_features, uint8_t *track_colors, osfm_tracks_summary *summary);
 
+/* The same with one explicit match range per pair: pair p owns
+ * corr[pair_starts[p] .. pair_starts[p] + pair_counts[p]).  For match lists that
+ * are not packed back to back -- the per-rank slices of a multi-GPU run lie in
+ * one shared host segment (orthosfm_amd/distributed.py) and are consumed where
+ * they are. */
+OSFM_API int osfm_tracks_compute_ranges(int32_t num_views, const int32_t *view_sizes,
+    const uint8_t *colors, int32_t num_pairs, const osfm_pair *pairs,
+    const int64_t *pair_starts, const int64_t *pair_counts, const int32_t *corr,
+    int32_t *track_ids, int64_t track_capacity, int64_t feature_capacity,
+    int64_t *track_offsets, int32_t *track_features, uint8_t *track_colors,
+    osfm_tracks_summary *summary);
+
 /* orthosfm::buildGroups (src/data_structures/group.cpp:13-88, completeGroup
  * :90-155): the order in which the incremental reconstruction adds views, as
  * groups of group_size views (3 in the reference's algorithms).

@@ -121,7 +121,7 @@ EXPORTS = [
     "osfm_ba_options_default", "osfm_ba_solve", "osfm_ba_reprojection_errors",
     "osfm_ba_triangulate",
     "osfm_nn_distances", "osfm_filter_outlier_tracks", "osfm_filter_reprojection",
-    "osfm_tracks_compute", "osfm_build_groups",
+    "osfm_tracks_compute", "osfm_tracks_compute_ranges", "osfm_build_groups",
 ]
 
 lib.osfm_last_error.restype = C.c_char_p

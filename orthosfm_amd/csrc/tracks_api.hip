@@ -7,6 +7,7 @@
 // (head / tail / size), unify_tracks (:23-45) splices the smaller list behind
 // the larger one in O(1) after relabelling its nodes, and nothing is
 // reallocated.  The output order is the reference's, element for element.
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -17,14 +18,16 @@ using namespace osfm;
 
 extern "C" {
 
-int osfm_tracks_compute(int32_t num_views, const int32_t *view_sizes, const uint8_t *colors,
-    int32_t num_pairs, const osfm_pair *pairs, const int64_t *pair_offsets, const int32_t *corr,
+// pair p owns corr[pair_begin[p] .. pair_end[p])
+static int tracks_compute_impl(int32_t num_views, const int32_t *view_sizes, const uint8_t *colors,
+    int32_t num_pairs, const osfm_pair *pairs, const int64_t *pair_begin, const int64_t *pair_end,
+    const int32_t *corr,
     int32_t *track_ids, int64_t track_capacity, int64_t feature_capacity,
     int64_t *track_offsets, int32_t *track_features, uint8_t *track_colors,
     osfm_tracks_summary *summary)
 {
     if (num_views < 0 || num_pairs < 0 || (num_views > 0 && !view_sizes) ||
-        (num_pairs > 0 && (!pairs || !pair_offsets)) || !track_offsets ||
+        (num_pairs > 0 && (!pairs || !pair_begin || !pair_end)) || !track_offsets ||
         (track_capacity > 0 && !track_colors) || (feature_capacity > 0 && !track_features)) {
         set_error("tracks_compute: null array / negative count");
         return OSFM_E_ARG;
@@ -36,7 +39,15 @@ int osfm_tracks_compute(int32_t num_views, const int32_t *view_sizes, const uint
     }
     const int64_t G = voff[num_views];
     if (G > 0 && !track_ids) { set_error("tracks_compute: track_ids is null"); return OSFM_E_ARG; }
-    const int64_t total_matches = num_pairs > 0 ? pair_offsets[num_pairs] : 0;
+    int64_t total_matches = 0;
+    for (int p = 0; p < num_pairs; ++p) {
+        if (pair_begin[p] < 0 || pair_end[p] < pair_begin[p]) {
+            set_error("tracks_compute: pair %d has the match range [%lld, %lld)", p,
+                (long long)pair_begin[p], (long long)pair_end[p]);
+            return OSFM_E_ARG;
+        }
+        total_matches += pair_end[p] - pair_begin[p];
+    }
     if (total_matches > 0 && !corr) { set_error("tracks_compute: corr is null"); return OSFM_E_ARG; }
 
     // node g = voff[view] + feature; nxt[g] = next feature of the same track
@@ -51,7 +62,7 @@ int osfm_tracks_compute(int32_t num_views, const int32_t *view_sizes, const uint
             set_error("tracks_compute: pair %d names view %d / %d of %d", p, v1, v2, num_views);
             return OSFM_E_ARG;
         }
-        for (int64_t k = pair_offsets[p]; k < pair_offsets[p + 1]; ++k) {
+        for (int64_t k = pair_begin[p]; k < pair_end[p]; ++k) {
             const int f1 = corr[2 * k], f2 = corr[2 * k + 1];
             if (f1 < 0 || f1 >= view_sizes[v1] || f2 < 0 || f2 >= view_sizes[v2]) {
                 set_error("tracks_compute: match %lld of pair %d out of range", (long long)k, p);
@@ -129,6 +140,35 @@ int osfm_tracks_compute(int32_t num_views, const int32_t *view_sizes, const uint
     }
     track_offsets[valid] = nf;
     return OSFM_OK;
+}
+
+int osfm_tracks_compute(int32_t num_views, const int32_t *view_sizes, const uint8_t *colors,
+    int32_t num_pairs, const osfm_pair *pairs, const int64_t *pair_offsets, const int32_t *corr,
+    int32_t *track_ids, int64_t track_capacity, int64_t feature_capacity,
+    int64_t *track_offsets, int32_t *track_features, uint8_t *track_colors,
+    osfm_tracks_summary *summary)
+{
+    return tracks_compute_impl(num_views, view_sizes, colors, num_pairs, pairs, pair_offsets,
+        pair_offsets ? pair_offsets + 1 : nullptr, corr, track_ids, track_capacity, feature_capacity,
+        track_offsets, track_features, track_colors, summary);
+}
+
+int osfm_tracks_compute_ranges(int32_t num_views, const int32_t *view_sizes, const uint8_t *colors,
+    int32_t num_pairs, const osfm_pair *pairs, const int64_t *pair_starts, const int64_t *pair_counts,
+    const int32_t *corr,
+    int32_t *track_ids, int64_t track_capacity, int64_t feature_capacity,
+    int64_t *track_offsets, int32_t *track_features, uint8_t *track_colors,
+    osfm_tracks_summary *summary)
+{
+    if (num_pairs > 0 && (!pair_starts || !pair_counts)) {
+        set_error("tracks_compute_ranges: null range arrays");
+        return OSFM_E_ARG;
+    }
+    std::vector<int64_t> ends((size_t)std::max(num_pairs, 0));
+    for (int p = 0; p < num_pairs; ++p) ends[p] = pair_starts[p] + pair_counts[p];
+    return tracks_compute_impl(num_views, view_sizes, colors, num_pairs, pairs, pair_starts, ends.data(),
+        corr, track_ids, track_capacity, feature_capacity, track_offsets, track_features, track_colors,
+        summary);
 }
 
 }  // extern "C"

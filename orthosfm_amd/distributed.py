@@ -1,7 +1,9 @@
 """Multi-GPU form of the matching path: view pairs are independent units, so
 they are dealt to the ranks up front (no data-path collective) and only the
-per-pair match lists are gathered on rank 0 for track building -- the one
-exchange step of the path.  One process per GPU, torch.distributed
+per-pair match lists are brought to rank 0 for track building -- the one
+exchange step of the path: in place through a shared host segment
+on one node (SharedMatchStore), as an RCCL gather across nodes
+(gather_match_lists).  One process per GPU, torch.distributed
 ("nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for the tests).
 
 The reference has no distributed runtime at all (its pair loop is an OpenMP
@@ -106,6 +108,99 @@ def assemble_global_order(heads, bufs, num_pairs: int, world: int, device="cpu")
     out = pinned_array("gathered", max(total, 1), device)
     torch.from_numpy(out)[:total].copy_(ordered)             # one device-to-host copy
     return counts.cpu().numpy(), offsets.cpu().numpy(), out[:total]
+
+
+class SharedSegmentUnavailable(RuntimeError):
+    """Raised on EVERY rank when rank 0 cannot create the segment; callers fall
+    back to gather_match_lists."""
+
+
+class SharedMatchStore:
+    """The exchange step on ONE node without moving the lists twice.
+
+    The consumer of the match lists is host code on rank 0 (RANSAC bookkeeping,
+    track building), and every GPU of a node has its own PCIe link to the host.
+    So each rank lets the matcher write its lists straight into its slice of
+    one POSIX shared-memory segment (page-locked in the owning process), and
+    rank 0 reads them where they lie: 8 device-to-host copies in parallel
+    instead of a gather over xGMI followed by one 8x larger copy through rank
+    0's link.  The only collective left is the all_gather of the per-pair
+    counts (RCCL), which also orders the slices' contents before rank 0 reads.
+
+    Across nodes use gather_match_lists (payload over RCCL) instead.
+    """
+
+    def __init__(self, rows_per_rank: int, rank: int, world: int, device="cpu"):
+        import os
+        import torch
+        import torch.distributed as dist
+        # whole pages per slice (512 rows of 8 bytes), so every rank page-locks only its own
+        self.rank, self.world, self.rows = rank, world, (int(max(rows_per_rank, 1)) + 511) // 512 * 512
+        self.device = device
+        self._registered = None
+        name = [None, self.rows]
+        if rank == 0:
+            need = self.world * self.rows * 8
+            st = os.statvfs("/dev/shm")
+            if st.f_bavail * st.f_frsize >= need + (64 << 20):     # a tmpfs write past its size is a SIGBUS
+                name[0] = f"/dev/shm/osfm_matches_{os.getpid()}_{id(self) & 0xffffff:x}"
+                with open(name[0], "wb") as f:
+                    f.truncate(need)
+        if world > 1:
+            dist.broadcast_object_list(name, src=0)
+        if name[0] is None:
+            raise SharedSegmentUnavailable(f"/dev/shm cannot hold {self.world * self.rows * 8} bytes")
+        if name[1] != self.rows:
+            raise ValueError(f"SharedMatchStore: rank {rank} asks for {self.rows} rows per rank, rank 0 for {name[1]}")
+        self.path = name[0]
+        self.array = np.memmap(self.path, dtype=np.int32, mode="r+", shape=(self.world * self.rows, 2))
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            os.unlink(self.path)          # the mappings keep the segment alive; nothing is left behind
+        self.slice = self.array[rank * self.rows:(rank + 1) * self.rows]
+        if str(device) != "cpu" and torch.cuda.is_available():
+            # page-lock the own slice so that the matcher's copy runs at PCIe rate
+            rc = torch.cuda.cudart().cudaHostRegister(self.slice.ctypes.data, self.slice.nbytes, 0)
+            if int(rc) != 0:
+                raise RuntimeError(f"hipHostRegister of the result slice failed ({rc})")
+            self._registered = self.slice.ctypes.data
+
+    def collect(self, local_counts, num_pairs: int):
+        """After the rank's lists are in its slice (packed in shard order): returns on
+        rank 0 (counts[num_pairs], starts[num_pairs], corr) with pair gi's list at
+        corr[starts[gi] : starts[gi] + counts[gi]], global pair order; None elsewhere."""
+        import torch
+        import torch.distributed as dist
+        local_counts = np.ascontiguousarray(local_counts, dtype=np.int64)
+        n_local = len(range(self.rank, num_pairs, self.world))
+        assert local_counts.shape[0] == n_local and int(local_counts.sum()) <= self.rows
+        max_local = len(range(0, num_pairs, self.world))
+        head = torch.zeros(max_local, dtype=torch.int64)
+        head[:n_local] = torch.from_numpy(local_counts)
+        if self.world > 1:
+            head = head.to(self.device)
+            heads = [torch.zeros_like(head) for _ in range(self.world)]
+            dist.all_gather(heads, head)           # every rank's lists are complete once this returns
+            heads = torch.stack(heads).cpu().numpy()
+        else:
+            heads = head.numpy()[None]
+        if self.rank != 0:
+            return None
+        gi = np.arange(num_pairs)
+        r_of, k_of = gi % self.world, gi // self.world
+        local_off = np.cumsum(heads, axis=1) - heads
+        counts = heads[r_of, k_of]
+        starts = r_of.astype(np.int64) * self.rows + local_off[r_of, k_of]
+        return counts, starts, self.array
+
+    def close(self):
+        if self._registered is not None:
+            import torch
+            torch.cuda.cudart().cudaHostUnregister(self._registered)
+            self._registered = None
+        self.slice = None
+        self.array = None
 
 
 def max_over_ranks(value: float, world: int, device="cpu") -> float:

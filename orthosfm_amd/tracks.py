@@ -73,6 +73,39 @@ def compute_flat(view_sizes, colors, pairs, pair_offsets, corr):
             track_colors[:nt], summary)
 
 
+def compute_flat_ranges(view_sizes, colors, pairs, pair_starts, pair_counts, corr):
+    """osfm_tracks_compute_ranges: like compute_flat, but pair p owns
+    corr[pair_starts[p] : pair_starts[p] + pair_counts[p]] -- the lists need not
+    be packed (distributed.SharedMatchStore hands them over in place)."""
+    view_sizes = np.ascontiguousarray(view_sizes, dtype=np.int32)
+    total = int(view_sizes.sum())
+    pair_starts = np.ascontiguousarray(pair_starts, dtype=np.int64)
+    pair_counts = np.ascontiguousarray(pair_counts, dtype=np.int64)
+    assert pair_starts.shape == pair_counts.shape
+    n_matches = int(pair_counts.sum())
+    track_ids = np.full(max(total, 1), -1, dtype=np.int32)
+    tcap, fcap = max(n_matches, 1), max(2 * n_matches, 1)
+    track_offsets = np.zeros(tcap + 1, dtype=np.int64)
+    track_features = np.zeros((fcap, 2), dtype=np.int32)
+    track_colors = np.zeros((tcap, 3), dtype=np.uint8)
+    summary = capi.TracksSummary()
+    col_ptr = None
+    if colors is not None:
+        colors = np.ascontiguousarray(colors, dtype=np.uint8).reshape(-1, 3)
+        assert colors.shape[0] == total
+        col_ptr = capi._ptr(colors, C.c_uint8)
+    assert corr.dtype == np.int32 and corr.flags.c_contiguous
+    capi.check(capi.lib.osfm_tracks_compute_ranges(
+        len(view_sizes), capi._ptr(view_sizes, C.c_int32), col_ptr, len(pair_starts), pairs,
+        capi._ptr(pair_starts, C.c_int64), capi._ptr(pair_counts, C.c_int64), capi._ptr(corr, C.c_int32),
+        capi._ptr(track_ids, C.c_int32), C.c_int64(tcap), C.c_int64(fcap),
+        capi._ptr(track_offsets, C.c_int64), capi._ptr(track_features, C.c_int32),
+        capi._ptr(track_colors, C.c_uint8), C.byref(summary)))
+    nt = summary.num_tracks
+    return (track_ids[:total], track_offsets[:nt + 1], track_features[:summary.num_features],
+            track_colors[:nt], summary)
+
+
 class Tracks:
     """sfm::bundler::Tracks."""
 

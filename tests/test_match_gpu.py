@@ -355,3 +355,47 @@ print("OK")
     if "NOGPU" in out.stdout:
         pytest.skip("torch sees no GPU")
     assert "OK" in out.stdout
+
+
+def test_lists_written_into_the_shared_segment():
+    """The single-node exchange on the GPU side: the matcher's device-to-host copy
+    lands in this rank's page-locked slice of the shared segment (world 1 here;
+    the cross-rank part is covered by the gloo tests) and rank 0's view of it
+    equals the lists compute() returns.  Fresh interpreter: torch first."""
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+from orthosfm_amd import capi, synth, distributed as D
+from orthosfm_amd.matching import HipExhaustiveMatching
+if not torch.cuda.is_available():
+    print("NOGPU"); raise SystemExit(0)
+dev = torch.device("cuda:0")
+V, F = 5, 1500
+iset = synth.make_image_set(V, F, seed=3)
+pairs = [capi.pair_from_index(i) for i in range(V * (V - 1) // 2)]
+m = HipExhaustiveMatching(V, device=0)
+for v in range(V):
+    m.set_view(v, iset.sift[v])
+ref = m.compute(pairs, capacity=F * len(pairs))
+ref_lists = [np.array(tv.matches) if tv.status == capi.PAIR_MATCHED else np.zeros((0, 2), np.int32) for tv in ref]
+store = D.SharedMatchStore(F * len(pairs), 0, 1, dev)
+assert store._registered is not None
+store.slice[:] = -5
+m.use_result_buffer(store.slice)
+out = m.compute(pairs, capacity=F * len(pairs))
+counts = np.array([tv.num_matches if tv.status == capi.PAIR_MATCHED else 0 for tv in out], dtype=np.int64)
+c, starts, corr = store.collect(counts, len(pairs))
+assert counts.sum() > 0 and np.array_equal(c, counts)
+for i in range(len(pairs)):
+    assert np.array_equal(corr[starts[i]:starts[i] + c[i]], ref_lists[i]), i
+assert np.all(np.asarray(corr[int(counts.sum()):]) == -5)
+m.close(); store.close()
+print("OK")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    if "NOGPU" in out.stdout:
+        pytest.skip("torch sees no GPU")
+    assert "OK" in out.stdout

@@ -103,3 +103,34 @@ def test_mirror_class_and_scale():
     np.testing.assert_array_equal(np.concatenate([vp.track_ids for vp in viewports]), orc["track_ids"])
     np.testing.assert_array_equal(np.concatenate([t.features for t in tracks]), orc["track_features"])
     np.testing.assert_array_equal(np.stack([t.color for t in tracks]), orc["track_colors"])
+
+
+def test_ranges_entry_matches_packed_entry():
+    """osfm_tracks_compute_ranges on lists scattered through a larger buffer gives
+    the result of osfm_tracks_compute on the packed lists."""
+    from orthosfm_amd import capi, tracks
+    m = track_cases.random_matching(7, 60, 150, seed=11)
+    pairs = (capi.Pair * len(m["pairs"]))()
+    for i, (a, b) in enumerate(m["pairs"]):
+        pairs[i].view_1, pairs[i].view_2 = int(a), int(b)
+    m["corr"] = np.ascontiguousarray(m["corr"], dtype=np.int32)
+    ref = tracks.compute_flat(m["view_sizes"], m["colors"], pairs, m["pair_offsets"], m["corr"])
+    offs = np.asarray(m["pair_offsets"], dtype=np.int64)
+    counts = np.diff(offs)
+    # lay the lists out in reverse pair order with gaps of garbage between them
+    big = np.full((int(counts.sum()) + 5 * len(counts) + 3, 2), -77, dtype=np.int32)
+    starts = np.zeros(len(counts), dtype=np.int64)
+    pos = 3
+    for p in range(len(counts) - 1, -1, -1):
+        starts[p] = pos
+        big[pos:pos + counts[p]] = m["corr"][offs[p]:offs[p + 1]]
+        pos += counts[p] + 5
+    got = tracks.compute_flat_ranges(m["view_sizes"], m["colors"], pairs, starts, counts, big)
+    for a, b in zip(ref[:4], got[:4]):
+        assert np.array_equal(a, b)
+    assert (ref[4].num_tracks, ref[4].num_features) == (got[4].num_tracks, got[4].num_features)
+    # a negative count is an argument error
+    bad = counts.copy()
+    bad[0] = -1
+    with pytest.raises(capi.OsfmError):
+        tracks.compute_flat_ranges(m["view_sizes"], m["colors"], pairs, starts, bad, big)
