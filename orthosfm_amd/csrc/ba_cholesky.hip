@@ -69,11 +69,29 @@ chol_panel_kernel(double *A, int ld, int nblk, int k, double *Ldiag, int *info)
         for (int c = j + 1; c < NB; ++c) L[c] -= lj * readlane_d(lj, c);   // meaningful for r >= c
     }
     if (blockIdx.x == 0) {
+        // Publishes inv(L_kk) for the backward substitution (a 32x32 product there
+        // instead of a 32-step chain).  Lane j solves L x = e_j for column j of the
+        // inverse: x stays in its own registers, the multipliers L[i][c] arrive as
+        // LDS broadcasts -- no cross-lane traffic in the chain.  This workgroup has
+        // no panel rows to solve, so the extra work hides behind the others.
         if (bad && lane == 0) atomicMax(info, k * NB + bad);
         if (lane < NB) {
-            double *Lk = Ldiag + (size_t)k * NB * NB + r * NB;
 #pragma unroll
-            for (int c = 0; c < NB; ++c) Lk[c] = c <= r ? L[c] : 0.0;
+            for (int c = 0; c < NB; ++c) LsT[r][c] = c <= r ? L[c] : 0.0;      // row-major here: LsT[i][c] = L[i][c]
+        }
+        __syncthreads();
+        double x[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            double acc = (i == r) ? 1.0 : 0.0;
+#pragma unroll
+            for (int c = 0; c < i; ++c) acc -= LsT[i][c] * x[c];
+            x[i] = acc * dinv[i];
+        }
+        if (lane < NB) {
+            double *Lk = Ldiag + (size_t)k * NB * NB;                          // [i][j] = inv(L)[i][j]
+#pragma unroll
+            for (int i = 0; i < NB; ++i) Lk[i * NB + r] = x[i];
         }
         return;
     }
@@ -129,49 +147,70 @@ chol_update_kernel(double *A, int ld, int nblk, int k)
     for (int c = 0; c < 4; ++c) Aij[(size_t)r * ld + c0 + c] -= acc[c];
 }
 
-// x = L^-T y with y in row N (= nblk * NB) of A; result written to x[0..n)
+// x = L^-T y with y in row N (= nblk * NB) of A; result written to x[0..n).
+// Ldiag holds inv(L_kk) of every diagonal block (chol_panel_kernel), so block k
+// is x_k = inv(L_kk)^T y_k: 32 independent dot products.  One workgroup: the
+// work is a chain of nblk small steps.
+// Workgroup barrier that only orders LDS traffic.  __syncthreads() also drains the
+// vector-memory counter, which here would expose the latency of every prefetch and
+// of every result store once per step of the chain.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __global__ __launch_bounds__(1024) void
 chol_backsolve_kernel(const double *A, int ld, int nblk, int n, const double *Ldiag, double *x)
 {
-    extern __shared__ double y[];            // [nblk * NB]
+    extern __shared__ double ys[];           // y [N], then x [N]
     __shared__ double xk[NB];
-    __shared__ double Lk[NB][NB + 1];
+    __shared__ double Li[NB][NB];            // inv(L_kk), row-major
     const int N = nblk * NB;
+    double *y = ys, *xs = ys + N;
     const int tid = threadIdx.x;
     for (int c = tid; c < N; c += blockDim.x) y[c] = A[(size_t)N * ld + c];
+    double li_next = Ldiag[(size_t)(nblk - 1) * NB * NB + tid];       // 1024 threads = 32 x 32
     __syncthreads();
     for (int k = nblk - 1; k >= 0; --k) {
-        Lk[tid >> 5][tid & 31] = Ldiag[(size_t)k * NB * NB + tid];     // 1024 threads = 32 x 32
-        __syncthreads();
-        // L_kk^T x_k = y_k: wave 0, lane m keeps y_m; unknowns resolved last to first
-        if (tid < 64) {
-            const int m = tid & 31;
-            double ym = y[k * NB + m];
-            for (int c = NB - 1; c >= 0; --c) {
-                const double xc = __shfl(ym, c) / Lk[c][c];
-                if (m < c) ym -= Lk[c][m] * xc;
-                if (m == c) ym = xc;
-            }
-            if (tid < NB) xk[tid] = ym;
+        Li[tid >> 5][tid & 31] = li_next;
+        if (k > 0) li_next = Ldiag[(size_t)(k - 1) * NB * NB + tid];  // in flight during this step
+        lds_barrier();
+        if (tid < NB) {
+            // x_k[m] = sum_{c >= m} inv(L)[c][m] * y_k[c]
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) acc += (c >= tid) ? Li[c][tid] * y[k * NB + c] : 0.0;
+            xk[tid] = acc;
+            xs[k * NB + tid] = acc;
         }
-        __syncthreads();
+        lds_barrier();
         // y_j -= L[k-block rows][j]^T x_k for every column j left of the block
         const double *Lrow = A + (size_t)(k * NB) * ld;
-        for (int c = tid; c < k * NB; c += blockDim.x) {
+        for (unsigned c = tid; c < (unsigned)(k * NB); c += blockDim.x) {
+            // all 32 loads in flight at once: scalar row base + one shared vector offset
+            // (left to itself the compiler issues load, wait, fma, load, ... -- 32 memory
+            // latencies in a row per step of the chain)
+            double l[NB];
+#pragma unroll
+            for (int m = 0; m < NB; ++m) {
+                const double *rowp = Lrow + (size_t)m * ld;       // uniform
+                l[m] = rowp[c];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             double v = y[c];
-#pragma unroll 8
-            for (int m = 0; m < NB; ++m) v -= Lrow[(size_t)m * ld + c] * xk[m];
+#pragma unroll
+            for (int m = 0; m < NB; ++m) v -= l[m] * xk[m];
             y[c] = v;
         }
-        if (tid < NB && k * NB + tid < n) x[k * NB + tid] = xk[tid];
-        __syncthreads();
+        lds_barrier();
     }
+    for (int c = tid; c < n; c += blockDim.x) x[c] = xs[c];
 }
 
 int cholesky_padded_dim(int n) { return (n + NB - 1) / NB * NB; }
 
 // A: (N + 32) x N row-major, rows/cols >= n padded with identity, rhs in row N.
-// Ldiag: N * 32 doubles of scratch for the factored diagonal blocks.
+// Ldiag: N * 32 doubles of scratch for the inverses of the factored diagonal blocks.
 void launch_cholesky_solve(double *A, int n, double *Ldiag, double *x, int *info, hipStream_t s)
 {
     const int N = cholesky_padded_dim(n);
@@ -183,7 +222,7 @@ void launch_cholesky_solve(double *A, int n, double *Ldiag, double *x, int *info
         if (t > 0)
             hipLaunchKernelGGL(chol_update_kernel, dim3(t, t + 1), dim3(256), 0, s, A, N, nblk, k);
     }
-    hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(1024), (size_t)N * sizeof(double), s, A, N,
+    hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(1024), (size_t)2 * N * sizeof(double), s, A, N,
         nblk, n, Ldiag, x);
 }
 

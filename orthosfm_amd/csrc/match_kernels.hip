@@ -786,19 +786,47 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
                 const int sidx = pd.special_slot[q];
                 if (sidx >= 0) slot = pd.nrb_main * kRowsPerBlock + sidx;
             }
-            for (int sgi = 0; sgi < pd.nseg; ++sgi) {
-                const RowPart p = rowparts[pd.rowpart_off + sgi * stride + slot];
-                // later segment wins ties (its columns have larger indices)
-                ip2 = max(max(ip2, p.ip_second), min(ip1, p.ip_best));
-                if (p.ip_best >= ip1 && p.ip_best != INT_MIN) { ip1 = p.ip_best; idx1 = p.idx_best; kind1 = p.pad; }
+            // four segments per round, loads issued together (see the column side below)
+            constexpr int kBatch = 4;
+            const RowPart *rp0 = rowparts + pd.rowpart_off + slot;
+            const int nseg = pd.nseg;
+            for (int s0 = 0; s0 < nseg; s0 += kBatch) {
+                RowPart p[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) p[u] = rp0[(int64_t)min(s0 + u, nseg - 1) * stride];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const bool live = s0 + u < nseg;
+                    const int pb = live ? p[u].ip_best : INT_MIN, ps = live ? p[u].ip_second : INT_MIN;
+                    // later segment wins ties (its columns have larger indices)
+                    ip2 = max(max(ip2, ps), min(ip1, pb));
+                    if (pb >= ip1 && pb != INT_MIN) { ip1 = pb; idx1 = p[u].idx_best; kind1 = p[u].pad; }
+                }
             }
         } else {
-            for (int rb = 0; rb < pd.nrb; ++rb) {
-                const ColPart p = colparts[pd.colpart_off + (int64_t)rb * pd.n2stride + q];
-                const int pb = p.key_best == kKeyNone ? INT_MIN : (p.key_best >> 8);
-                const int ps = p.key_second == kKeyNone ? INT_MIN : (p.key_second >> 8);
-                ip2 = max(max(ip2, ps), min(ip1, pb));
-                if (pb >= ip1 && pb != INT_MIN) { ip1 = pb; idx1 = rb; code = p.key_best & 255; }
+            // eight row blocks per round, their loads issued together (left as a plain
+            // loop the compiler emits load, wait, fold per row block: one memory latency
+            // per partial with a single request in flight per lane)
+            constexpr int kBatch = 8;
+            const ColPart *cp0 = colparts + pd.colpart_off + q;
+            const int nrb = pd.nrb;
+            const int64_t stride = pd.n2stride;
+            for (int rb0 = 0; rb0 < nrb; rb0 += kBatch) {
+                ColPart p[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u)
+                    p[u] = cp0[(int64_t)min(rb0 + u, nrb - 1) * stride];     // clamped repeats are not folded
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    // no branch (a branch would let the optimiser sink each load to its use)
+                    const bool live = rb0 + u < nrb;
+                    const int pb = (!live || p[u].key_best == kKeyNone) ? INT_MIN : (p[u].key_best >> 8);
+                    const int ps = (!live || p[u].key_second == kKeyNone) ? INT_MIN : (p[u].key_second >> 8);
+                    ip2 = max(max(ip2, ps), min(ip1, pb));
+                    if (pb >= ip1 && pb != INT_MIN) { ip1 = pb; idx1 = rb0 + u; code = p[u].key_best & 255; }
+                }
             }
         }
     }
