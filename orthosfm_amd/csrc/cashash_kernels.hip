@@ -252,94 +252,186 @@ cashash_scan_kernel(const MatchProblem *__restrict__ problems, int32_t *__restri
     }
 }
 
+// DPP moves inside a lane group (no LDS traffic)
+template <int CTRL>
+__device__ __forceinline__ int cas_dpp(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+template <int LPC>
+__device__ __forceinline__ int group_sum(int v)      // sum over the LPC lanes of a group, in every lane
+{
+    v += cas_dpp<0xB1>(v);                 // quad_perm [1,0,3,2]
+    v += cas_dpp<0x4E>(v);                 // quad_perm [2,3,0,1]
+    if (LPC == 8) v += cas_dpp<0x141>(v);  // row_half_mirror
+    return v;
+}
+
+// The final stage of CascadeHashing::oneway_match for one query per thread:
+// candidate ids from the ranked keys, the 6..10 rule, then NearestNeighbor<T>::find
+// over the chosen candidates.  The nearest-neighbour part runs with DIM/16 lanes per
+// query (8 queries of a wave at a time for SIFT): a candidate row is one coalesced
+// 128-byte read per lane group instead of eight 16-byte reads scattered over 64
+// rows per wave instruction, and the inner product is four v_dot4 per lane plus
+// three DPP adds.
+//   Exactness: the reference sums eight 16-bit lanes that wrap (nearest_neighbor.cc:
+//   60-129).  SIFT products are non-negative, so no lane can wrap unless the whole
+//   inner product exceeds 65535: below that the dot-product value IS the wrapped
+//   sum.  Otherwise -- and always for SURF, whose signed lanes can wrap at any
+//   total -- the eight lane sums are formed as such (mod 2^16 is a ring
+//   homomorphism, so they may be reduced across lanes before they are truncated).
 template <int DIM, bool SIGNED>
 __global__ __launch_bounds__(128) void
 cashash_finish_kernel(const MatchProblem *__restrict__ problems, const int32_t *__restrict__ state,
-    LoweTable tab)
+    LoweTable tab, int blocks_per_dir, int total_blocks)
 {
-    const MatchProblem &pd = problems[blockIdx.y];
-    const int dir = blockIdx.z;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int LPC = DIM / 16, NG = 64 / LPC;
+    // every XCD works through a contiguous run of problems (candidate rows stay in one L2)
+    const int lin = xcd_remap(blockIdx.x, total_blocks);
+    const int problem = lin / (2 * blocks_per_dir), within = lin - problem * 2 * blocks_per_dir;
+    const MatchProblem &pd = problems[problem];
+    const int dir = within / blocks_per_dir;
+    const int q = (within - dir * blocks_per_dir) * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int nq = dir == 0 ? pd.n1 : pd.n2;
     const int nc = dir == 0 ? pd.n2 : pd.n1;
-    if (q >= nq) return;
+    if ((within - dir * blocks_per_dir) * (int)blockDim.x >= nq) return;     // whole block out of range
     int32_t *out = dir == 0 ? pd.m12 : pd.m21;
-    if (nc == 0) { out[q] = -1; return; }
+    if (nc == 0) {                          // uniform: the other view has nothing of this type
+        if (q < nq) out[q] = -1;
+        return;
+    }
+    const bool active = q < nq;
     const int s1 = dir, s2 = dir ^ 1;
     const int8_t *Q = dir == 0 ? pd.A : pd.B;
     const int8_t *Cm = dir == 0 ? pd.B : pd.A;
-    const CasRecord me = static_cast<const CasRecord *>(pd.cas_rec[s1])[q];
-    const int32_t *st = state + (pd.cas_state_off[dir] + q) * kCasMaxCand;
+    const int32_t *corrQ = dir == 0 ? pd.corrA : pd.corrB;
+    const int32_t *corrC = dir == 0 ? pd.corrB : pd.corrA;
+
     int key[kCasMaxCand], cid[kCasMaxCand];
-#pragma unroll
-    for (int j = 0; j < kCasMaxCand; ++j) {
-        key[j] = st[j];
-        cid[j] = -1;
-        if (key[j] != kCasKeyNone) {
-            const int g = (key[j] >> kCasGroupShift) & 7, pos = key[j] & ((1 << kCasPosBits) - 1);
-            const int myb = (int)((me.buckets >> (8 * g)) & 0xffu);
-            cid[j] = pd.cas_items[s2][(size_t)g * nc + pd.cas_start[s2][(size_t)g * (kCasBuckets + 1) + myb] + pos];
-        }
-    }
-    // collect_top_ranked_candidates (h:446-468): whole distance levels until at
-    // least 6 are in, never more than 10
     int nt = 0;
+    {
+        const int qs = active ? q : 0;
+        const uint64_t my_buckets = active ? static_cast<const CasRecord *>(pd.cas_rec[s1])[qs].buckets : 0;
+        const int32_t *st = state + (pd.cas_state_off[dir] + qs) * kCasMaxCand;
+        // all loads of a stage issued together: keys, then bucket starts, then ids
+        // (invalid entries read index 0 and are discarded)
 #pragma unroll
-    for (int j = 0; j < kCasMaxCand; ++j) {
-        if (cid[j] < 0) break;
-        if (nt >= kCasMinCand && (key[j] >> kCasDistShift) > (key[nt - 1] >> kCasDistShift)) break;
-        nt = j + 1;
-    }
-    // NearestNeighbor<T>::find over the candidates in that order
-    // (nearest_neighbor.cc:60-129,214-268): 8 lanes of 16-bit wrap-around sums,
-    // state held in T; query descriptor once into registers, 16 bytes at a time
-    const int4 *qrow = reinterpret_cast<const int4 *>(Q + (size_t)q * DIM);
-    int4 qv[DIM / 16];
+        for (int j = 0; j < kCasMaxCand; ++j) key[j] = active ? st[j] : kCasKeyNone;
+        int base[kCasMaxCand];
 #pragma unroll
-    for (int e = 0; e < DIM / 16; ++e) qv[e] = qrow[e];
-    int best = 0, second = 0, i1 = 0;
-    for (int j = 0; j < nt; ++j) {
-        const int4 *crow = reinterpret_cast<const int4 *>(Cm + (size_t)cid[j] * DIM);
-        unsigned lanes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int e = 0; e < DIM / 16; ++e) {
-            const int4 cv = crow[e];
-            const int qa[4] = {qv[e].x, qv[e].y, qv[e].z, qv[e].w};
-            const int ca[4] = {cv.x, cv.y, cv.z, cv.w};
-            // element 16 e + 4 w + b sits in byte b of word w; its SSE lane is (4 w + b) % 8
-#pragma unroll
-            for (int w = 0; w < 4; ++w)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int qb = (int)(int8_t)(qa[w] >> (8 * b)), cb = (int)(int8_t)(ca[w] >> (8 * b));
-                    lanes[(4 * w + b) & 7] += (unsigned)((SIGNED ? qb : qb + 128) * (SIGNED ? cb : cb + 128));
-                }
+        for (int j = 0; j < kCasMaxCand; ++j) {
+            const bool ok = key[j] != kCasKeyNone;
+            const int g = ok ? (key[j] >> kCasGroupShift) & 7 : 0;
+            const int myb = (int)((my_buckets >> (8 * g)) & 0xffu);
+            base[j] = pd.cas_start[s2][(size_t)g * (kCasBuckets + 1) + myb];
         }
-        int ip = 0;
 #pragma unroll
-        for (int l = 0; l < 8; ++l) ip += SIGNED ? (int)(short)(lanes[l] & 0xffffu) : (int)(lanes[l] & 0xffffu);
-        if (ip >= second) {
-            if (ip >= best) {
-                second = best;
-                best = SIGNED ? (int)(short)ip : (int)(unsigned short)ip;
-                i1 = j;
-            } else {
-                second = SIGNED ? (int)(short)ip : (int)(unsigned short)ip;
+        for (int j = 0; j < kCasMaxCand; ++j) {
+            const bool ok = key[j] != kCasKeyNone;
+            const int g = ok ? (key[j] >> kCasGroupShift) & 7 : 0;
+            const int pos = ok ? key[j] & ((1 << kCasPosBits) - 1) : 0;
+            const int v = pd.cas_items[s2][(size_t)g * nc + (ok ? base[j] + pos : 0)];
+            cid[j] = ok ? v : -1;
+        }
+        // collect_top_ranked_candidates (h:446-468): whole distance levels until at
+        // least 6 are in, never more than 10
+        bool open = true;
+#pragma unroll
+        for (int j = 0; j < kCasMaxCand; ++j) {
+            if (cid[j] < 0) open = false;
+            if (j >= kCasMinCand && (key[j] >> kCasDistShift) > (key[j - 1] >> kCasDistShift)) open = false;
+            if (open) nt = j + 1;
+        }
+    }
+
+    // NearestNeighbor<T>::find over the candidates in that order, one lane group per query
+    const int g = lane / LPC, c = lane % LPC;
+    int my_best = 0, my_second = 0, my_i1 = 0;
+    for (int round = 0; round < LPC; ++round) {
+        const int src = (round * NG + g) * 4;                    // byte address of the owner lane
+        const int gq = __builtin_amdgcn_ds_bpermute(src, active ? q : 0);
+        const int gnt = __builtin_amdgcn_ds_bpermute(src, nt);
+        int gcid[kCasMaxCand];
+#pragma unroll
+        for (int j = 0; j < kCasMaxCand; ++j) gcid[j] = max(__builtin_amdgcn_ds_bpermute(src, cid[j]), 0);
+        // candidates behind the cut re-read the first row (same cache line, no extra traffic)
+#pragma unroll
+        for (int j = 1; j < kCasMaxCand; ++j) gcid[j] = j < gnt ? gcid[j] : gcid[0];
+        if (__ballot(gnt > 0) == 0) continue;                    // uniform: nothing to do in this round
+        const int4 qv = *reinterpret_cast<const int4 *>(Q + (size_t)gq * DIM + c * 16);
+        const int cq = corrQ[gq];
+        int4 cv[kCasMaxCand];
+        int cc[kCasMaxCand];
+#pragma unroll
+        for (int j = 0; j < kCasMaxCand; ++j) {
+            cv[j] = *reinterpret_cast<const int4 *>(Cm + (size_t)gcid[j] * DIM + c * 16);
+            cc[j] = corrC[gcid[j]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int best = 0, second = 0, i1 = 0;
+#pragma unroll
+        for (int j = 0; j < kCasMaxCand; ++j) {
+            int ip;
+            bool wrapped = SIGNED;
+            if (!SIGNED) {
+                int acc = __builtin_amdgcn_sdot4(qv.x, cv[j].x, 0, false);
+                acc = __builtin_amdgcn_sdot4(qv.y, cv[j].y, acc, false);
+                acc = __builtin_amdgcn_sdot4(qv.z, cv[j].z, acc, false);
+                acc = __builtin_amdgcn_sdot4(qv.w, cv[j].w, acc, false);
+                ip = group_sum<LPC>(acc) + cq + cc[j];
+                wrapped = ip > 65535 && j < gnt;
+            }
+            if (__ballot(wrapped)) {
+                // the eight 16-bit lanes as such: element 16 c + 4 w + b is SSE lane (4 w + b) % 8
+                const int qa[4] = {qv.x, qv.y, qv.z, qv.w};
+                const int ca[4] = {cv[j].x, cv[j].y, cv[j].z, cv[j].w};
+                int part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int qb = (int)(int8_t)(qa[w] >> (8 * b)), cb = (int)(int8_t)(ca[w] >> (8 * b));
+                        part[(4 * w + b) & 7] += (SIGNED ? qb : qb + 128) * (SIGNED ? cb : cb + 128);
+                    }
+                int ipw = 0;
+#pragma unroll
+                for (int l = 0; l < 8; ++l) {
+                    const int t = group_sum<LPC>(part[l]);
+                    ipw += SIGNED ? (int)(short)(t & 0xffff) : (t & 0xffff);
+                }
+                if (SIGNED) ip = ipw; else ip = wrapped ? ipw : ip;
+            }
+            if (j < gnt && ip >= second) {
+                if (ip >= best) {
+                    second = best;
+                    best = SIGNED ? (int)(short)ip : (int)(unsigned short)ip;
+                    i1 = j;
+                } else {
+                    second = SIGNED ? (int)(short)ip : (int)(unsigned short)ip;
+                }
             }
         }
+        // back to the owner lane: lane L was served in round L / NG by group L % NG
+        const int from = ((lane % NG) * LPC) * 4;
+        const int rb = __builtin_amdgcn_ds_bpermute(from, best);
+        const int rs = __builtin_amdgcn_ds_bpermute(from, second);
+        const int ri = __builtin_amdgcn_ds_bpermute(from, i1);
+        if (lane / NG == round) { my_best = rb; my_second = rs; my_i1 = ri; }
     }
+    if (q >= nq) return;
     int d1, d2;
     if (SIGNED) {
-        const int b = min(16129, max(0, best)), s = min(16129, max(0, second));
+        const int b = min(16129, max(0, my_best)), s = min(16129, max(0, my_second));
         d1 = (int)(short)(32258 - 2 * b); d2 = (int)(short)(32258 - 2 * s);
     } else {
-        const int b = min(65025, best), s = min(65025, second);
+        const int b = min(65025, my_best), s = min(65025, my_second);
         d1 = min(32767, 65025 - b) * 2; d2 = min(32767, 65025 - s) * 2;
     }
-    // i1 indexes the candidate list; the cid[] array is indexed dynamically only here
+    // my_i1 indexes the candidate list; the cid[] array is indexed dynamically only here
     int res = -1;
 #pragma unroll
-    for (int j = 0; j < kCasMaxCand; ++j) if (j == i1 && j < nt) res = cid[j];
+    for (int j = 0; j < kCasMaxCand; ++j) if (j == my_i1 && j < nt) res = cid[j];
     if (d1 > tab.max_d1) res = -1;
     else if (d1 >= tab.reject_from[d2 >> 1]) res = -1;
     out[q] = res;
@@ -391,11 +483,16 @@ void launch_cashash_match(int dim, const MatchProblem *d_problems, int num_probl
     static_assert(kCasGroups == 6, "one instantiation per bucket group");
     OSFM_CAS_SCAN(0); OSFM_CAS_SCAN(1); OSFM_CAS_SCAN(2); OSFM_CAS_SCAN(3); OSFM_CAS_SCAN(4); OSFM_CAS_SCAN(5);
 #undef OSFM_CAS_SCAN
-    const dim3 grid((max_n + 127) / 128, num_problems, 2);
+    const int blocks_per_dir = (max_n + 127) / 128;
+    const int64_t total = (int64_t)blocks_per_dir * 2 * num_problems;
+    if (total <= 0 || total > INT_MAX) return;
+    const dim3 grid((unsigned)total);
     if (dim == 128)
-        hipLaunchKernelGGL((cashash_finish_kernel<128, false>), grid, dim3(128), 0, s, d_problems, state, tab);
+        hipLaunchKernelGGL((cashash_finish_kernel<128, false>), grid, dim3(128), 0, s, d_problems, state, tab,
+            blocks_per_dir, (int)total);
     else
-        hipLaunchKernelGGL((cashash_finish_kernel<64, true>), grid, dim3(128), 0, s, d_problems, state, tab);
+        hipLaunchKernelGGL((cashash_finish_kernel<64, true>), grid, dim3(128), 0, s, d_problems, state, tab,
+            blocks_per_dir, (int)total);
 }
 
 }  // namespace osfm

@@ -57,6 +57,16 @@ struct MatchProblem {
 struct RowPart { int32_t ip_best, idx_best, ip_second, pad; };
 struct ColPart { int32_t key_best, key_second; };
 
+// Bijective XCD-aware remap (device code only): consecutive logical blocks (which share the
+// column descriptors of one pair) land on the same XCD / L2.
+__device__ __forceinline__ int xcd_remap(int bid, int total)
+{
+    const int q = total >> 3, r = total & 7;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
 // Accept / reject tables and clamps of one descriptor type.
 struct LoweTable {
     const int32_t *reject_from;  // [32768]: reject iff d1 >= reject_from[d2/2]

@@ -30,15 +30,6 @@ namespace osfm {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-// Bijective XCD-aware remap: consecutive logical blocks (which share the
-// column descriptors of one pair) land on the same XCD / L2.
-__device__ __forceinline__ int xcd_remap(int bid, int total)
-{
-    const int q = total >> 3, r = total & 7;
-    const int xcd = bid & 7, slot = bid >> 3;
-    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + slot;
-}
 
 // ---------------------------------------------------------------------------
 // Score-tile kernel.  CH = 16-byte chunks per descriptor (8: SIFT, 4: SURF).
