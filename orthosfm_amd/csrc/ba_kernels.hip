@@ -50,12 +50,69 @@ __device__ __forceinline__ void block_partial(double v, double *partials, int sl
 }
 
 // ---------------------------------------------------------------------------
+// Camera tables in LDS.  The per-point kernels walk a track's observations one
+// after the other, and every observation gathers its camera's parameters,
+// image size, tangent layout and column scales through its camera index --
+// chains of dependent global loads, several per observation.  A few hundred
+// cameras are a few tens of KB: each workgroup copies the tables into LDS once
+// (loads issued in batches) and the gathers never leave the CU.  Problems whose
+// tables do not fit keep reading global memory (same code: generic pointers).
+// ---------------------------------------------------------------------------
+constexpr size_t kCamStageLimit = 64 * 1024;
+
+static size_t cam_stage_bytes(const BaDev &d, bool with_y)
+{
+    auto r8 = [](size_t bytes) { return (bytes + 7) / 8 * 8; };      // stage_array rounds every table up
+    const size_t b = 8 * ((size_t)7 * d.C + (size_t)d.nc * (with_y ? 2 : 1)) + 4 * r8((size_t)4 * d.C) + r8((size_t)6 * d.C);
+    return b <= kCamStageLimit ? b : 0;
+}
+
+template <typename T>
+__device__ __forceinline__ const T *stage_array(const T *src, int n, char *&lds)
+{
+    T *dst = reinterpret_cast<T *>(lds);
+    constexpr int kB = 8;
+    for (int i0 = 0; i0 < n; i0 += kB * 256) {
+        T v[kB];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) v[u] = src[min(i0 + u * 256 + (int)threadIdx.x, n - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kB; ++u) { const int i = i0 + u * 256 + (int)threadIdx.x; if (i < n) dst[i] = v[u]; }
+    }
+    lds += ((size_t)n * sizeof(T) + 7) / 8 * 8;
+    return dst;
+}
+
+// d with its per-camera arrays (and cams / y_c, if given) replaced by LDS copies
+__device__ __forceinline__ BaDev stage_cameras(const BaDev &d, char *lds, bool staged, const double *&cams,
+    const double **y_c)
+{
+    BaDev o = d;
+    if (!staged || d.C <= 0) return o;
+    cams = stage_array(cams, 7 * d.C, lds);
+    o.cams = cams;
+    if (d.nc > 0) o.scale_c = stage_array(d.scale_c, d.nc, lds);
+    if (y_c && d.nc > 0) *y_c = stage_array(*y_c, d.nc, lds);
+    o.img_w = stage_array(d.img_w, d.C, lds);
+    o.img_h = stage_array(d.img_h, d.C, lds);
+    o.cam_ldim = stage_array(d.cam_ldim, d.C, lds);
+    o.cam_off = stage_array(d.cam_off, d.C, lds);
+    o.cam_colmap = stage_array(d.cam_colmap, 6 * d.C, lds);
+    __syncthreads();
+    return o;
+}
+
+// ---------------------------------------------------------------------------
 // point pass
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void
-ba_point_pass_kernel(BaDev d, PointPassArgs a)
+ba_point_pass_kernel(BaDev dg, PointPassArgs a, int staged)
 {
+    extern __shared__ __attribute__((aligned(16))) char cam_lds[];
     __shared__ double sh[4];
+    const double *cams = dg.cams;
+    const BaDev d = stage_cameras(dg, cam_lds, staged != 0, cams, nullptr);
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     double cost = 0.0, gmax = 0.0;
     int bad = 0;
@@ -125,7 +182,8 @@ ba_point_pass_kernel(BaDev d, PointPassArgs a)
 
 void launch_point_pass(const BaDev &d, const PointPassArgs &a, int blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL(ba_point_pass_kernel, dim3(blocks), dim3(256), 0, s, d, a);
+    const size_t lds = cam_stage_bytes(d, false);
+    hipLaunchKernelGGL(ba_point_pass_kernel, dim3(blocks), dim3(256), lds, s, d, a, lds ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -346,9 +404,12 @@ void launch_cam_update(const BaDev &d, const double *y_c, double *cams_out, doub
 // back substitution + model cost change + candidate points
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void
-ba_back_pass_kernel(BaDev d, BackPassArgs a)
+ba_back_pass_kernel(BaDev dg, BackPassArgs a, int staged)
 {
+    extern __shared__ __attribute__((aligned(16))) char cam_lds[];
     __shared__ double sh[4];
+    const double *cams = dg.cams;
+    const BaDev d = stage_cameras(dg, cam_lds, staged != 0, cams, &a.y_c);
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     double mcc = 0.0, sn = 0.0, xn = 0.0;
     if (j < d.M) {
@@ -394,16 +455,19 @@ ba_back_pass_kernel(BaDev d, BackPassArgs a)
 
 void launch_back_pass(const BaDev &d, const BackPassArgs &a, int blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL(ba_back_pass_kernel, dim3(blocks), dim3(256), 0, s, d, a);
+    const size_t lds = cam_stage_bytes(d, true);
+    hipLaunchKernelGGL(ba_back_pass_kernel, dim3(blocks), dim3(256), lds, s, d, a, lds ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------
 // cost at (cams, points) given explicitly
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void
-ba_cost_pass_kernel(BaDev d, const double *cams, const double *points, double *partials)
+ba_cost_pass_kernel(BaDev dg, const double *cams, const double *points, double *partials, int staged)
 {
+    extern __shared__ __attribute__((aligned(16))) char cam_lds[];
     __shared__ double sh[4];
+    const BaDev d = stage_cameras(dg, cam_lds, staged != 0, cams, nullptr);
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     double cost = 0.0;
     if (j < d.M) {
@@ -419,7 +483,8 @@ ba_cost_pass_kernel(BaDev d, const double *cams, const double *points, double *p
 void launch_cost_pass(const BaDev &d, const double *cams, const double *points, double *partials,
     int blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL(ba_cost_pass_kernel, dim3(blocks), dim3(256), 0, s, d, cams, points, partials);
+    const size_t lds = cam_stage_bytes(d, false);
+    hipLaunchKernelGGL(ba_cost_pass_kernel, dim3(blocks), dim3(256), lds, s, d, cams, points, partials, lds ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------
