@@ -991,48 +991,83 @@ void launch_exact_scan(int dim, const MatchProblem *d_problems, const ExactItem 
 // both directions must be judged from the UNMODIFIED lists: phase 0 marks,
 // phase 1 applies (+ adds the combine_results offsets, matching.cc:74-86).
 // ---------------------------------------------------------------------------
-__global__ void
+// kCheckPerThread queries per thread: a workgroup per 256 queries is mostly launch
+// overhead for a kernel this small (0.73 ms for 49 M queries that way).
+constexpr int kCheckPerThread = 8;
+
+__global__ __launch_bounds__(256) void
 cross_check_mark_kernel(const MatchProblem *__restrict__ problems, uint8_t *__restrict__ keep12,
     uint8_t *__restrict__ keep21, const int64_t *__restrict__ mark_off, int32_t *__restrict__ counts)
 {
     const MatchProblem &pd = problems[blockIdx.y];
     const int dir = blockIdx.z;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const int nq = dir == 0 ? pd.n1 : pd.n2;
-    int ok = 0;
-    if (q < nq) {
-        const int32_t *mine = dir == 0 ? pd.m12 : pd.m21;
-        const int32_t *other = dir == 0 ? pd.m21 : pd.m12;
-        const int j = mine[q];
-        ok = (j >= 0 && other[j] == q) ? 1 : 0;
-        (dir == 0 ? keep12 : keep21)[mark_off[blockIdx.y * 2 + dir] + q] = (uint8_t)ok;
+    const int n_other = dir == 0 ? pd.n2 : pd.n1;
+    const int q0 = blockIdx.x * (256 * kCheckPerThread) + threadIdx.x;
+    if ((int)(blockIdx.x * (256 * kCheckPerThread)) >= nq) return;       // whole block out of range
+    const int32_t *mine = dir == 0 ? pd.m12 : pd.m21;
+    const int32_t *other = dir == 0 ? pd.m21 : pd.m12;
+    uint8_t *keep = (dir == 0 ? keep12 : keep21) + mark_off[blockIdx.y * 2 + dir];
+    int j[kCheckPerThread], back[kCheckPerThread];
+#pragma unroll
+    for (int u = 0; u < kCheckPerThread; ++u) {
+        const int q = q0 + u * 256;
+        j[u] = q < nq ? mine[q] : -1;
     }
-    if (dir == 0 && counts) {
-        const unsigned long long bal = __ballot(ok);
-        if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counts[blockIdx.y], __popcll(bal));
+#pragma unroll
+    for (int u = 0; u < kCheckPerThread; ++u)       // entry 0 for "no match": discarded (uniform guard: empty side)
+        back[u] = n_other > 0 ? other[max(j[u], 0)] : -1;
+    int n_ok = 0;
+#pragma unroll
+    for (int u = 0; u < kCheckPerThread; ++u) {
+        const int q = q0 + u * 256;
+        const int ok = (j[u] >= 0 && back[u] == q) ? 1 : 0;
+        if (q < nq) keep[q] = (uint8_t)ok;
+        n_ok += ok;
+    }
+    if (dir == 0 && counts) {           // uniform per block
+        __shared__ int wave_ok[4];
+        for (int off = 32; off >= 1; off >>= 1) n_ok += __shfl_down(n_ok, off);
+        if ((threadIdx.x & 63) == 0) wave_ok[threadIdx.x >> 6] = n_ok;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int t = wave_ok[0] + wave_ok[1] + wave_ok[2] + wave_ok[3];
+            if (t) atomicAdd(&counts[blockIdx.y], t);
+        }
     }
 }
 
-__global__ void
+__global__ __launch_bounds__(256) void
 cross_check_apply_kernel(const MatchProblem *__restrict__ problems, const uint8_t *__restrict__ keep12,
     const uint8_t *__restrict__ keep21, const int64_t *__restrict__ mark_off)
 {
     const MatchProblem &pd = problems[blockIdx.y];
     const int dir = blockIdx.z;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
     const int nq = dir == 0 ? pd.n1 : pd.n2;
-    if (q >= nq) return;
+    const int q0 = blockIdx.x * (256 * kCheckPerThread) + threadIdx.x;
+    if ((int)(blockIdx.x * (256 * kCheckPerThread)) >= nq) return;
     int32_t *mine = dir == 0 ? pd.m12 : pd.m21;
-    const uint8_t k = (dir == 0 ? keep12 : keep21)[mark_off[blockIdx.y * 2 + dir] + q];
+    const uint8_t *keep = (dir == 0 ? keep12 : keep21) + mark_off[blockIdx.y * 2 + dir];
     const int off = dir == 0 ? pd.out_off12 : pd.out_off21;
-    mine[q] = k ? mine[q] + off : -1;
+    int v[kCheckPerThread];
+    uint8_t k[kCheckPerThread];
+#pragma unroll
+    for (int u = 0; u < kCheckPerThread; ++u) {
+        const int q = min(q0 + u * 256, nq - 1);
+        v[u] = mine[q]; k[u] = keep[q];
+    }
+#pragma unroll
+    for (int u = 0; u < kCheckPerThread; ++u) {
+        const int q = q0 + u * 256;
+        if (q < nq) mine[q] = k[u] ? v[u] + off : -1;
+    }
 }
 
 void launch_cross_check_mark(const MatchProblem *d_problems, int num_problems, int max_n,
     uint8_t *keep12, uint8_t *keep21, const int64_t *mark_off, int32_t *counts, hipStream_t s)
 {
     if (num_problems <= 0 || max_n <= 0) return;
-    dim3 grid((max_n + 255) / 256, num_problems, 2);
+    dim3 grid((max_n + 256 * kCheckPerThread - 1) / (256 * kCheckPerThread), num_problems, 2);
     hipLaunchKernelGGL(cross_check_mark_kernel, grid, dim3(256), 0, s, d_problems, keep12, keep21,
         mark_off, counts);
 }
@@ -1041,7 +1076,7 @@ void launch_cross_check_apply(const MatchProblem *d_problems, int num_problems, 
     const uint8_t *keep12, const uint8_t *keep21, const int64_t *mark_off, hipStream_t s)
 {
     if (num_problems <= 0 || max_n <= 0) return;
-    dim3 grid((max_n + 255) / 256, num_problems, 2);
+    dim3 grid((max_n + 256 * kCheckPerThread - 1) / (256 * kCheckPerThread), num_problems, 2);
     hipLaunchKernelGGL(cross_check_apply_kernel, grid, dim3(256), 0, s, d_problems, keep12, keep21,
         mark_off);
 }
