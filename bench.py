@@ -450,6 +450,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(iset, all_pairs, args.cpu_sample_pairs)
         print(json.dumps(line))
     m.close()
+    if store is not None:
+        store.close()
     if world > 1:
         dist.destroy_process_group()
 
