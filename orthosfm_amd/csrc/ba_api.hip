@@ -119,16 +119,19 @@ int upload_problem(const osfm_ba_problem *p, const Layout &L, double huber, int 
     OSFM_RETURN_IF(D->points[1].alloc((size_t)4 * M * 8));
     OSFM_RETURN_IF(upload(D->obs_xy, p->obs_xy, (size_t)2 * O, s));
     OSFM_RETURN_IF(upload(D->obs_cam, p->obs_camera, (size_t)O, s));
-    OSFM_RETURN_IF(upload(D->obs_pt, p->obs_point, (size_t)O, s));
     OSFM_RETURN_IF(upload(D->pt_start, L.pt_start.data(), (size_t)M + 1, s));
+    // obs_point is validated non-decreasing, i.e. it is the expansion of pt_start
+    OSFM_RETURN_IF(D->obs_pt.alloc((size_t)O * sizeof(int32_t)));
+    launch_expand_points(D->pt_start.as<int32_t>(), M, D->obs_pt.as<int32_t>(), s);
     OSFM_RETURN_IF(upload(D->img_w, p->img_width, (size_t)C, s));
     OSFM_RETURN_IF(upload(D->img_h, p->img_height, (size_t)C, s));
     OSFM_RETURN_IF(upload(D->cam_ldim, L.cam_ldim.data(), (size_t)C, s));
     OSFM_RETURN_IF(upload(D->cam_off, L.cam_off.data(), (size_t)C, s));
     OSFM_RETURN_IF(upload(D->colmap, L.colmap.data(), (size_t)6 * C, s));
-    std::vector<double> ones((size_t)std::max(L.nc, 3 * M) + 1, 1.0);
-    OSFM_RETURN_IF(upload(D->scale_c, ones.data(), (size_t)L.nc, s));
-    OSFM_RETURN_IF(upload(D->scale_p, ones.data(), (size_t)3 * M, s));
+    OSFM_RETURN_IF(D->scale_c.alloc((size_t)L.nc * 8));
+    OSFM_RETURN_IF(D->scale_p.alloc((size_t)3 * M * 8));
+    launch_fill(D->scale_c.as<double>(), (size_t)L.nc, 1.0, s);
+    launch_fill(D->scale_p.as<double>(), (size_t)3 * M, 1.0, s);
     BaDev &d = D->dev;
     d.model = p->model; d.C = C; d.M = M; d.O = O; d.nc = L.nc; d.pdim = pdim;
     d.cams = D->cams[0].as<double>(); d.points = D->points[0].as<double>();

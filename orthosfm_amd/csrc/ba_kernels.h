@@ -62,6 +62,8 @@ void launch_reduce(const double *partials, int n, int num_slots, unsigned max_ma
     const double *extra, int extra_n, int extra_stride, int extra_slots, hipStream_t s);
 void launch_max_reduce(const double *v, int n, double *out, hipStream_t s);
 void launch_pad_diag(double *S, int ld, int n, int N, hipStream_t s);
+void launch_fill(double *v, size_t n, double value, hipStream_t s);
+void launch_expand_points(const int32_t *pt_start, int M, int32_t *obs_pt, hipStream_t s);
 void launch_reproj(const BaDev &d, double *err, double *residuals, hipStream_t s);
 void launch_triangulate(const BaDev &d, double *points_out, uint8_t *valid, hipStream_t s);
 

@@ -556,6 +556,35 @@ void launch_pad_diag(double *S, int ld, int n, int N, hipStream_t s)
     if (N > n) hipLaunchKernelGGL(ba_pad_diag_kernel, dim3(1), dim3(64), 0, s, S, ld, n, N);
 }
 
+// v[i] = value (the unit Jacobi scales before their first estimate)
+__global__ void
+ba_fill_kernel(double *v, size_t n, double value)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = value;
+}
+
+void launch_fill(double *v, size_t n, double value, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(ba_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, n, value);
+}
+
+// obs_pt[k] = j for pt_start[j] <= k < pt_start[j + 1] (observations are grouped by
+// point: the per-observation point index is redundant with the CSR and is expanded
+// here instead of crossing PCIe)
+__global__ void
+ba_expand_points_kernel(const int32_t *__restrict__ pt_start, int M, int32_t *__restrict__ obs_pt)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    for (int k = pt_start[j]; k < pt_start[j + 1]; ++k) obs_pt[k] = j;
+}
+
+void launch_expand_points(const int32_t *pt_start, int M, int32_t *obs_pt, hipStream_t s)
+{
+    if (M > 0) hipLaunchKernelGGL(ba_expand_points_kernel, dim3((M + 255) / 256), dim3(256), 0, s, pt_start, M, obs_pt);
+}
+
 void launch_max_reduce(const double *v, int n, double *out, hipStream_t s)
 {
     hipLaunchKernelGGL(ba_max_reduce_kernel, dim3(1), dim3(256), 0, s, v, n, out);
