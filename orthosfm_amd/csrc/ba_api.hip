@@ -146,14 +146,7 @@ int upload_problem(const osfm_ba_problem *p, const Layout &L, double huber, int 
     return OSFM_OK;
 }
 
-struct StreamGuard {
-    hipStream_t s = nullptr;
-    ~StreamGuard() { if (s) (void)hipStreamDestroy(s); }
-};
-struct EventPair {
-    hipEvent_t a = nullptr, b = nullptr;
-    ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
-};
+using StreamGuard = StreamLease;
 
 int select_device(int device)
 {
@@ -216,10 +209,9 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     lap("layout");
 
     StreamGuard sg;
-    OSFM_HIP_CHECK(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
+    OSFM_RETURN_IF(sg.acquire());
     hipStream_t s = sg.s;
-    EventPair ev[4];
-    for (auto &e : ev) { OSFM_HIP_CHECK(hipEventCreate(&e.a)); OSFM_HIP_CHECK(hipEventCreate(&e.b)); }
+    EventPair *ev = sg.ev;
 
     DeviceProblem D;
     OSFM_RETURN_IF(upload_problem(p, L, o.huber_delta, pdim, s, &D));
@@ -459,7 +451,7 @@ int osfm_ba_reprojection_errors(const osfm_ba_problem *p, int device, double *er
     if (!err && !residuals) { set_error("ba_reprojection_errors: no output"); return OSFM_E_ARG; }
     OSFM_RETURN_IF(select_device(device));
     StreamGuard sg;
-    OSFM_HIP_CHECK(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
+    OSFM_RETURN_IF(sg.acquire());
     Layout L;
     build_layout(p, &L);
     DeviceProblem D;
@@ -481,7 +473,7 @@ int osfm_ba_triangulate(const osfm_ba_problem *p, int device, uint8_t *point_val
     OSFM_RETURN_IF(validate_problem(p, "ba_triangulate"));
     OSFM_RETURN_IF(select_device(device));
     StreamGuard sg;
-    OSFM_HIP_CHECK(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
+    OSFM_RETURN_IF(sg.acquire());
     Layout L;
     build_layout(p, &L);
     DeviceProblem D;
@@ -506,7 +498,7 @@ int osfm_filter_reprojection(const osfm_ba_problem *p, int device, double max_er
     if (!obs_keep && p->num_observations > 0) { set_error("filter_reprojection: obs_keep is null"); return OSFM_E_ARG; }
     OSFM_RETURN_IF(select_device(device));
     StreamGuard sg;
-    OSFM_HIP_CHECK(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
+    OSFM_RETURN_IF(sg.acquire());
     Layout L;
     build_layout(p, &L);
     DeviceProblem D;

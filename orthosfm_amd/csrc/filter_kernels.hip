@@ -46,8 +46,9 @@ int nn_distances_device(int device, const double *points, int n, double *nn_out)
 {
     if (n <= 0) return OSFM_OK;
     OSFM_HIP_CHECK(hipSetDevice(device));
-    hipStream_t s;
-    OSFM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    StreamLease lease;                       // pooled: creating a stream costs ~1 ms
+    OSFM_RETURN_IF(lease.acquire());
+    hipStream_t s = lease.s;
     DeviceBuffer d_pts, d_nn;
     int rc = d_pts.reserve((size_t)n * 32);
     if (rc == OSFM_OK) rc = d_nn.reserve((size_t)n * 8);
@@ -63,7 +64,6 @@ int nn_distances_device(int device, const double *points, int n, double *nn_out)
         if (e != hipSuccess) { set_error("nn_distances: %s", hipGetErrorString(e)); rc = OSFM_E_DEVICE; }
     }
     d_pts.release(); d_nn.release();
-    (void)hipStreamDestroy(s);
     return rc;
 }
 

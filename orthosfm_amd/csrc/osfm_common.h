@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/osfm_hip.h"
 
@@ -47,5 +49,65 @@ struct DeviceBuffer {
     }
     template <typename T> T *as() const { return static_cast<T *>(ptr); }
 };
+
+// A stream and its timing events, leased for the duration of one call.  Creating a
+// stream costs about a millisecond -- a real share of a 15 ms solve that the
+// incremental reconstruction repeats for every camera group -- so the sets live in
+// a per-process free list: a call takes one for its device (concurrent callers get
+// different ones) and hands it back, drained, on every exit path.
+struct EventPair { hipEvent_t a = nullptr, b = nullptr; };
+struct StreamSet {
+    int device = -1;
+    hipStream_t s = nullptr;
+    EventPair ev[4];
+};
+inline std::mutex g_stream_pool_mutex;
+inline std::vector<StreamSet *> g_stream_pool;
+
+struct StreamLease {
+    hipStream_t s = nullptr;
+    EventPair *ev = nullptr;
+    StreamSet *set = nullptr;
+    int acquire()
+    {
+        int device = 0;
+        OSFM_HIP_CHECK(hipGetDevice(&device));
+        {
+            std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
+            for (size_t i = 0; i < g_stream_pool.size(); ++i)
+                if (g_stream_pool[i]->device == device) {
+                    set = g_stream_pool[i];
+                    g_stream_pool.erase(g_stream_pool.begin() + (long)i);
+                    break;
+                }
+        }
+        if (!set) {
+            StreamSet *n = new StreamSet;
+            n->device = device;
+            hipError_t e = hipStreamCreateWithFlags(&n->s, hipStreamNonBlocking);
+            for (auto &p : n->ev) {
+                if (e == hipSuccess) e = hipEventCreate(&p.a);
+                if (e == hipSuccess) e = hipEventCreate(&p.b);
+            }
+            if (e != hipSuccess) {
+                for (auto &p : n->ev) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
+                if (n->s) (void)hipStreamDestroy(n->s);
+                delete n;
+                OSFM_HIP_CHECK(e);
+            }
+            set = n;
+        }
+        s = set->s; ev = set->ev;
+        return OSFM_OK;
+    }
+    ~StreamLease()
+    {
+        if (!set) return;
+        (void)hipStreamSynchronize(set->s);       // nothing of this call may still run when the next one reuses it
+        std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
+        g_stream_pool.push_back(set);
+    }
+};
+
 
 }  // namespace osfm
