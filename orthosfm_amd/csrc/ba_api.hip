@@ -141,8 +141,8 @@ int upload_problem(const osfm_ba_problem *p, const Layout &L, double huber, int 
     d.cam_colmap = D->colmap.as<int8_t>();
     d.scale_c = D->scale_c.as<double>(); d.scale_p = D->scale_p.as<double>();
     d.huber = huber;
-    // the staging vectors above are locals: make sure the copies have landed
-    OSFM_HIP_CHECK(hipStreamSynchronize(s));
+    // No synchronisation here: every source array (the caller's and the Layout's) outlives
+    // the call, and what follows is ordered behind the copies on the same stream.
     return OSFM_OK;
 }
 
@@ -450,10 +450,10 @@ int osfm_ba_reprojection_errors(const osfm_ba_problem *p, int device, double *er
     OSFM_RETURN_IF(validate_problem(p, "ba_reprojection_errors"));
     if (!err && !residuals) { set_error("ba_reprojection_errors: no output"); return OSFM_E_ARG; }
     OSFM_RETURN_IF(select_device(device));
+    Layout L;                 // declared before the stream lease: it must outlive the copies that read it
+    build_layout(p, &L);
     StreamGuard sg;
     OSFM_RETURN_IF(sg.acquire());
-    Layout L;
-    build_layout(p, &L);
     DeviceProblem D;
     OSFM_RETURN_IF(upload_problem(p, L, 1.0, 3, sg.s, &D));
     const int O = p->num_observations;
@@ -472,10 +472,10 @@ int osfm_ba_triangulate(const osfm_ba_problem *p, int device, uint8_t *point_val
 {
     OSFM_RETURN_IF(validate_problem(p, "ba_triangulate"));
     OSFM_RETURN_IF(select_device(device));
+    Layout L;                 // declared before the stream lease: it must outlive the copies that read it
+    build_layout(p, &L);
     StreamGuard sg;
     OSFM_RETURN_IF(sg.acquire());
-    Layout L;
-    build_layout(p, &L);
     DeviceProblem D;
     OSFM_RETURN_IF(upload_problem(p, L, 1.0, 3, sg.s, &D));
     const int M = p->num_points;
@@ -497,10 +497,10 @@ int osfm_filter_reprojection(const osfm_ba_problem *p, int device, double max_er
     OSFM_RETURN_IF(validate_problem(p, "filter_reprojection"));
     if (!obs_keep && p->num_observations > 0) { set_error("filter_reprojection: obs_keep is null"); return OSFM_E_ARG; }
     OSFM_RETURN_IF(select_device(device));
+    Layout L;                 // declared before the stream lease: it must outlive the copies that read it
+    build_layout(p, &L);
     StreamGuard sg;
     OSFM_RETURN_IF(sg.acquire());
-    Layout L;
-    build_layout(p, &L);
     DeviceProblem D;
     OSFM_RETURN_IF(upload_problem(p, L, 1.0, 3, sg.s, &D));
     const int M = p->num_points, O = p->num_observations;
