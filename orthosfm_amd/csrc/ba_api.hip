@@ -232,7 +232,7 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     sum->num_pair_entries = PL.num_entries;
     lap("pair lists (device)");
 
-    const int blocksM = std::max(1, (M + 255) / 256);
+    const int blocksM = std::max(1, (int)(((int64_t)M * kPointLanes + 255) / 256));
     const int N = cholesky_padded_dim(std::max(nc, 1));
     DevArray obsrec, diag_c, diag_p, vinv, ge, S, Ldiag, y_c, partA, partB, partC, part_cam, gmax_cam, scalars, info;
     OSFM_RETURN_IF(obsrec.alloc((size_t)std::max(p->num_observations, 1) * kObsRec * 8));

@@ -322,12 +322,18 @@ linearize_obs(const BaDev &d, int k, const double *cams, const double *points, b
     o.n = d.cam_ldim[c];
     o.off = d.cam_off[c];
     if (!want_j) return;
+#pragma unroll
     for (int t = 0; t < 6; ++t) {
         if (t < o.n) {
             const int f = d.cam_colmap[6 * c + t];
             const double sc = sq * d.scale_c[o.off + t];
-            o.Jc[0][t] = sc * e.Jc[0][f];
-            o.Jc[1][t] = sc * e.Jc[1][f];
+            // column f of the full Jacobian by a select chain: indexing the register
+            // array with f would put it (and this kernel's hot loop) into scratch memory
+            double j0 = e.Jc[0][0], j1 = e.Jc[1][0];
+#pragma unroll
+            for (int ff = 1; ff < 6; ++ff) { j0 = f == ff ? e.Jc[0][ff] : j0; j1 = f == ff ? e.Jc[1][ff] : j1; }
+            o.Jc[0][t] = sc * j0;
+            o.Jc[1][t] = sc * j1;
         } else {
             o.Jc[0][t] = 0.0;
             o.Jc[1][t] = 0.0;

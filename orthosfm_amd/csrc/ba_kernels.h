@@ -14,6 +14,10 @@ enum { kPassNormal = 0, kPassScaleInit = 1 };
 constexpr int kObsRec = 26;
 constexpr int kRecJc = 0, kRecJp = 12, kRecQ = 18, kRecR = 24;
 
+// lanes per track in the per-point kernels (point / back / cost pass): their grids are
+// ceil(M * kPointLanes / 256) workgroups of 256 threads, and so are their partials
+constexpr int kPointLanes = 4;
+
 struct PointPassArgs {
     int mode;                 // kPassScaleInit: only derive the Jacobi scaling
     int update_diag;          // recompute the LM diagonal (reuse_diagonal == false)

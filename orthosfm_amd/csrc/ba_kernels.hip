@@ -33,6 +33,19 @@ __device__ __forceinline__ double wave_max(double v)
     return v;
 }
 
+// The per-point kernels give every track kPointLanes neighbouring lanes (observation
+// k0 + lane, k0 + lane + 4, ...): one thread per track left 1.5 waves per SIMD to
+// hide a chain of dependent loads per observation.  Sums over a track are folded
+// with two xor-shuffles in a fixed order -- ((l0 + l1) + (l2 + l3)) in every lane --
+// so results stay bit-reproducible.
+static_assert(kPointLanes == 4, "quad_sum folds four lanes");
+__device__ __forceinline__ double quad_sum(double v)
+{
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    return v;
+}
+
 // per-block partial -> partials[slot * gridDim.x + blockIdx.x]
 template <bool IS_MAX>
 __device__ __forceinline__ void block_partial(double v, double *partials, int slot, double *sh)
@@ -113,13 +126,14 @@ ba_point_pass_kernel(BaDev dg, PointPassArgs a, int staged)
     __shared__ double sh[4];
     const double *cams = dg.cams;
     const BaDev d = stage_cameras(dg, cam_lds, staged != 0, cams, nullptr);
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = gt / kPointLanes, sub = gt % kPointLanes;       // a quad never straddles j < M
     double cost = 0.0, gmax = 0.0;
     int bad = 0;
     if (j < d.M) {
         const int k0 = d.pt_start[j], k1 = d.pt_start[j + 1];
         double V[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } }, g[3] = { 0, 0, 0 };
-        for (int k = k0; k < k1; ++k) {
+        for (int k = k0 + sub; k < k1; k += kPointLanes) {
             ObsLin o;
             linearize_obs(d, k, d.cams, d.points, true, o);
             cost += 0.5 * o.rho0;
@@ -135,16 +149,24 @@ ba_point_pass_kernel(BaDev dg, PointPassArgs a, int staged)
             }
         }
         if (d.pdim) {
+            // the track's sums, identical in its four lanes from here on
+            for (int x = 0; x < 3; ++x) {
+                g[x] = quad_sum(g[x]);
+                for (int y = 0; y <= x; ++y) V[x][y] = quad_sum(V[x][y]);
+            }
             V[0][1] = V[1][0]; V[0][2] = V[2][0]; V[1][2] = V[2][1];
             if (a.mode == kPassScaleInit) {
                 // Jacobi scaling, computed once from the unscaled column norms
                 // (TrustRegionMinimizer::EvaluateGradientAndJacobian, iteration 0)
-                for (int x = 0; x < 3; ++x) a.scale_p_out[3 * j + x] = 1.0 / (1.0 + sqrt(V[x][x]));
+                if (sub == 0)
+                    for (int x = 0; x < 3; ++x) a.scale_p_out[3 * j + x] = 1.0 / (1.0 + sqrt(V[x][x]));
             } else {
-                if (a.update_diag)
-                    for (int x = 0; x < 3; ++x)
-                        a.diag_p[3 * j + x] = fmin(fmax(V[x][x], a.min_diag), a.max_diag);
-                for (int x = 0; x < 3; ++x) V[x][x] += a.diag_p[3 * j + x] / a.radius;
+                for (int x = 0; x < 3; ++x) {
+                    // every lane derives the diagonal itself (lane 0's store is not read back)
+                    const double dp = a.update_diag ? fmin(fmax(V[x][x], a.min_diag), a.max_diag) : a.diag_p[3 * j + x];
+                    if (a.update_diag && sub == 0) a.diag_p[3 * j + x] = dp;
+                    V[x][x] += dp / a.radius;
+                }
                 double Vi[3][3];
                 if (k1 > k0) {
                     if (!inv3_spd(V, Vi)) bad = 1;
@@ -152,12 +174,13 @@ ba_point_pass_kernel(BaDev dg, PointPassArgs a, int staged)
                     for (int x = 0; x < 3; ++x)
                         for (int y = 0; y < 3; ++y) Vi[x][y] = x == y ? 1.0 / V[x][x] : 0.0;
                 }
-                for (int x = 0; x < 3; ++x) {
-                    a.ge[3 * j + x] = g[x];
-                    for (int y = 0; y < 3; ++y) a.vinv[9 * j + 3 * x + y] = bad ? 0.0 : Vi[x][y];
-                }
-                // Q = Jp V^-1 for every observation of the track
-                for (int k = k0; k < k1; ++k) {
+                if (sub == 0)
+                    for (int x = 0; x < 3; ++x) {
+                        a.ge[3 * j + x] = g[x];
+                        for (int y = 0; y < 3; ++y) a.vinv[9 * j + 3 * x + y] = bad ? 0.0 : Vi[x][y];
+                    }
+                // Q = Jp V^-1 for every observation of the track (each lane its own records)
+                for (int k = k0 + sub; k < k1; k += kPointLanes) {
                     double *rec = a.obsrec + (size_t)k * kObsRec;
                     for (int rr = 0; rr < 2; ++rr) {
                         const double j0 = rec[kRecJp + 3 * rr], j1 = rec[kRecJp + 3 * rr + 1], j2 = rec[kRecJp + 3 * rr + 2];
@@ -165,7 +188,7 @@ ba_point_pass_kernel(BaDev dg, PointPassArgs a, int staged)
                             rec[kRecQ + 3 * rr + t] = bad ? 0.0 : j0 * Vi[0][t] + j1 * Vi[1][t] + j2 * Vi[2][t];
                     }
                 }
-                if (a.want_gradient) {
+                if (a.want_gradient && sub == 0) {
                     // |Plus(x, -g) - x|_inf with the UNSCALED gradient g / scale
                     double dl[3], out[4];
                     for (int x = 0; x < 3; ++x) dl[x] = -g[x] / d.scale_p[3 * j + x];
@@ -410,14 +433,15 @@ ba_back_pass_kernel(BaDev dg, BackPassArgs a, int staged)
     __shared__ double sh[4];
     const double *cams = dg.cams;
     const BaDev d = stage_cameras(dg, cam_lds, staged != 0, cams, &a.y_c);
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = gt / kPointLanes, sub = gt % kPointLanes;
     double mcc = 0.0, sn = 0.0, xn = 0.0;
     if (j < d.M) {
         const int k0 = d.pt_start[j], k1 = d.pt_start[j + 1];
         double step_p[3] = { 0, 0, 0 };
         if (d.pdim) {
-            double t3[3] = { a.ge[3 * j], a.ge[3 * j + 1], a.ge[3 * j + 2] };
-            for (int k = k0; k < k1; ++k) {
+            double t3[3] = { 0, 0, 0 };
+            for (int k = k0 + sub; k < k1; k += kPointLanes) {
                 const double *rec = a.obsrec + (size_t)k * kObsRec;
                 const int c = d.obs_cam[k], n = d.cam_ldim[c], off = d.cam_off[c];
                 double u0 = 0.0, u1 = 0.0;
@@ -425,11 +449,12 @@ ba_back_pass_kernel(BaDev dg, BackPassArgs a, int staged)
                     if (x < n) { u0 += rec[kRecJc + x] * a.y_c[off + x]; u1 += rec[kRecJc + 6 + x] * a.y_c[off + x]; }
                 for (int t = 0; t < 3; ++t) t3[t] -= rec[kRecJp + t] * u0 + rec[kRecJp + 3 + t] * u1;
             }
+            for (int t = 0; t < 3; ++t) t3[t] = a.ge[3 * j + t] + quad_sum(t3[t]);
             const double *Vi = a.vinv + 9 * j;
             for (int x = 0; x < 3; ++x) step_p[x] = -(Vi[3 * x] * t3[0] + Vi[3 * x + 1] * t3[1] + Vi[3 * x + 2] * t3[2]);
         }
         // model_cost_change = -(J step)^T (r + J step / 2)  (scaled J, scaled step)
-        for (int k = k0; k < k1; ++k) {
+        for (int k = k0 + sub; k < k1; k += kPointLanes) {
             const double *rec = a.obsrec + (size_t)k * kObsRec;
             const int c = d.obs_cam[k], n = d.cam_ldim[c], off = d.cam_off[c];
             double m0 = 0.0, m1 = 0.0;
@@ -444,9 +469,11 @@ ba_back_pass_kernel(BaDev dg, BackPassArgs a, int staged)
             double dl[3];
             for (int x = 0; x < 3; ++x) dl[x] = step_p[x] * d.scale_p[3 * j + x];
             homog_plus(P, dl, out);
-            for (int x = 0; x < 4; ++x) { sn += (P[x] - out[x]) * (P[x] - out[x]); xn += P[x] * P[x]; }
+            if (sub == 0)
+                for (int x = 0; x < 4; ++x) { sn += (P[x] - out[x]) * (P[x] - out[x]); xn += P[x] * P[x]; }
         }
-        for (int x = 0; x < 4; ++x) a.points_out[4 * j + x] = out[x];
+        if (sub == 0)
+            for (int x = 0; x < 4; ++x) a.points_out[4 * j + x] = out[x];
     }
     block_partial<false>(mcc, a.partials, 0, sh);
     block_partial<false>(sn, a.partials, 1, sh);
@@ -468,10 +495,11 @@ ba_cost_pass_kernel(BaDev dg, const double *cams, const double *points, double *
     extern __shared__ __attribute__((aligned(16))) char cam_lds[];
     __shared__ double sh[4];
     const BaDev d = stage_cameras(dg, cam_lds, staged != 0, cams, nullptr);
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = gt / kPointLanes, sub = gt % kPointLanes;
     double cost = 0.0;
     if (j < d.M) {
-        for (int k = d.pt_start[j]; k < d.pt_start[j + 1]; ++k) {
+        for (int k = d.pt_start[j] + sub; k < d.pt_start[j + 1]; k += kPointLanes) {
             ObsLin o;
             linearize_obs(d, k, cams, points, false, o);
             cost += 0.5 * o.rho0;
