@@ -697,14 +697,27 @@ rescan_groups(const MatchProblem &pd, const int (&q)[2], const int (&idx1)[2], c
             } else {
                 const int r = n & 15;
                 cd = rbase + (n >> 4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (idx1[u] >= pd.nrb_main) {
-                    // a block of gathered special rows: back to the original row
-                    const int sidx = cd - pd.nrb_main * kRowsPerBlock;
-                    cd = sidx < pd.n_special ? pd.special_map[sidx] : -1;
-                } else if (cd >= pd.n1) cd = -1;
+                if (idx1[u] < pd.nrb_main && cd >= pd.n1) cd = -1;
             }
             cand[u][j] = cd;
-            const int cs = max(cd, 0);          // padding candidates read row 0, masked below
+        }
+        if (DIR == 1 && idx1[u] >= pd.nrb_main) {
+            // a block of gathered special rows (uniform, rare): back to the original rows,
+            // all look-ups of the query together and BEFORE any descriptor load -- a
+            // look-up between the loads makes the compiler drain the load counter at
+            // every candidate (one memory latency each instead of one for all)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int sidx = cand[u][j] - pd.nrb_main * kRowsPerBlock;
+                cand[u][j] = sidx < pd.n_special ? pd.special_map[sidx] : -1;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int cs = max(cand[u][j], 0);     // padding candidates read row 0, masked below
             cv[u][j] = *reinterpret_cast<const int4 *>(Cm + (size_t)cs * DIM + c * 16);
             corr_c[u][j] = corrC[cs];
         }
