@@ -442,12 +442,21 @@ ba_back_pass_kernel(BaDev dg, BackPassArgs a, int staged)
         if (d.pdim) {
             double t3[3] = { 0, 0, 0 };
             for (int k = k0 + sub; k < k1; k += kPointLanes) {
-                const double *rec = a.obsrec + (size_t)k * kObsRec;
+                // Jc and Jp of the record as nine 16-byte loads issued together (loads under
+                // the x < n tests came out as load, wait, use one by one)
+                double r[kRecQ];
+                {
+                    const double2 *src = reinterpret_cast<const double2 *>(a.obsrec + (size_t)k * kObsRec);
+#pragma unroll
+                    for (int i = 0; i < kRecQ / 2; ++i) { const double2 v = src[i]; r[2 * i] = v.x; r[2 * i + 1] = v.y; }
+                }
                 const int c = d.obs_cam[k], n = d.cam_ldim[c], off = d.cam_off[c];
                 double u0 = 0.0, u1 = 0.0;
+#pragma unroll
                 for (int x = 0; x < 6; ++x)
-                    if (x < n) { u0 += rec[kRecJc + x] * a.y_c[off + x]; u1 += rec[kRecJc + 6 + x] * a.y_c[off + x]; }
-                for (int t = 0; t < 3; ++t) t3[t] -= rec[kRecJp + t] * u0 + rec[kRecJp + 3 + t] * u1;
+                    if (x < n) { const double yx = a.y_c[off + x]; u0 += r[kRecJc + x] * yx; u1 += r[kRecJc + 6 + x] * yx; }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) t3[t] -= r[kRecJp + t] * u0 + r[kRecJp + 3 + t] * u1;
             }
             for (int t = 0; t < 3; ++t) t3[t] = a.ge[3 * j + t] + quad_sum(t3[t]);
             const double *Vi = a.vinv + 9 * j;
@@ -455,13 +464,21 @@ ba_back_pass_kernel(BaDev dg, BackPassArgs a, int staged)
         }
         // model_cost_change = -(J step)^T (r + J step / 2)  (scaled J, scaled step)
         for (int k = k0 + sub; k < k1; k += kPointLanes) {
-            const double *rec = a.obsrec + (size_t)k * kObsRec;
+            double r[kObsRec];
+            {
+                const double2 *src = reinterpret_cast<const double2 *>(a.obsrec + (size_t)k * kObsRec);
+#pragma unroll
+                for (int i = 0; i < kRecQ / 2; ++i) { const double2 v = src[i]; r[2 * i] = v.x; r[2 * i + 1] = v.y; }
+                const double2 v = src[kRecR / 2]; r[kRecR] = v.x; r[kRecR + 1] = v.y;
+            }
             const int c = d.obs_cam[k], n = d.cam_ldim[c], off = d.cam_off[c];
             double m0 = 0.0, m1 = 0.0;
+#pragma unroll
             for (int x = 0; x < 6; ++x)
-                if (x < n) { m0 -= rec[kRecJc + x] * a.y_c[off + x]; m1 -= rec[kRecJc + 6 + x] * a.y_c[off + x]; }
-            for (int t = 0; t < 3; ++t) { m0 += rec[kRecJp + t] * step_p[t]; m1 += rec[kRecJp + 3 + t] * step_p[t]; }
-            mcc -= m0 * (rec[kRecR] + m0 / 2.0) + m1 * (rec[kRecR + 1] + m1 / 2.0);
+                if (x < n) { const double yx = a.y_c[off + x]; m0 -= r[kRecJc + x] * yx; m1 -= r[kRecJc + 6 + x] * yx; }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { m0 += r[kRecJp + t] * step_p[t]; m1 += r[kRecJp + 3 + t] * step_p[t]; }
+            mcc -= m0 * (r[kRecR] + m0 / 2.0) + m1 * (r[kRecR + 1] + m1 / 2.0);
         }
         const double *P = d.points + 4 * j;
         double out[4] = { P[0], P[1], P[2], P[3] };
