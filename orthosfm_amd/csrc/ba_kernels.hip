@@ -137,10 +137,18 @@ ba_point_pass_kernel(BaDev dg, PointPassArgs a, int staged)
             ObsLin o;
             linearize_obs(d, k, d.cams, d.points, true, o);
             cost += 0.5 * o.rho0;
-            double *rec = a.obsrec + (size_t)k * kObsRec;
-            for (int x = 0; x < 6; ++x) { rec[kRecJc + x] = o.Jc[0][x]; rec[kRecJc + 6 + x] = o.Jc[1][x]; }
-            for (int x = 0; x < 3; ++x) { rec[kRecJp + x] = o.Jp[0][x]; rec[kRecJp + 3 + x] = o.Jp[1][x]; }
-            rec[kRecR] = o.r[0]; rec[kRecR + 1] = o.r[1];
+            // the record (16-byte aligned: 26 doubles) in 16-byte stores
+            {
+                double w[kRecQ];
+#pragma unroll
+                for (int x = 0; x < 6; ++x) { w[kRecJc + x] = o.Jc[0][x]; w[kRecJc + 6 + x] = o.Jc[1][x]; }
+#pragma unroll
+                for (int x = 0; x < 3; ++x) { w[kRecJp + x] = o.Jp[0][x]; w[kRecJp + 3 + x] = o.Jp[1][x]; }
+                double2 *dst = reinterpret_cast<double2 *>(a.obsrec + (size_t)k * kObsRec);
+#pragma unroll
+                for (int i = 0; i < kRecQ / 2; ++i) dst[i] = make_double2(w[2 * i], w[2 * i + 1]);
+                dst[kRecR / 2] = make_double2(o.r[0], o.r[1]);
+            }
             if (d.pdim) {
                 for (int x = 0; x < 3; ++x) {
                     g[x] += o.Jp[0][x] * o.r[0] + o.Jp[1][x] * o.r[1];
@@ -181,12 +189,17 @@ ba_point_pass_kernel(BaDev dg, PointPassArgs a, int staged)
                     }
                 // Q = Jp V^-1 for every observation of the track (each lane its own records)
                 for (int k = k0 + sub; k < k1; k += kPointLanes) {
-                    double *rec = a.obsrec + (size_t)k * kObsRec;
-                    for (int rr = 0; rr < 2; ++rr) {
-                        const double j0 = rec[kRecJp + 3 * rr], j1 = rec[kRecJp + 3 * rr + 1], j2 = rec[kRecJp + 3 * rr + 2];
+                    double2 *rec2 = reinterpret_cast<double2 *>(a.obsrec + (size_t)k * kObsRec);
+                    double jp[6], qv[6];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { const double2 v = rec2[kRecJp / 2 + i]; jp[2 * i] = v.x; jp[2 * i + 1] = v.y; }
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
                         for (int t = 0; t < 3; ++t)
-                            rec[kRecQ + 3 * rr + t] = bad ? 0.0 : j0 * Vi[0][t] + j1 * Vi[1][t] + j2 * Vi[2][t];
-                    }
+                            qv[3 * rr + t] = bad ? 0.0 : jp[3 * rr] * Vi[0][t] + jp[3 * rr + 1] * Vi[1][t] + jp[3 * rr + 2] * Vi[2][t];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) rec2[kRecQ / 2 + i] = make_double2(qv[2 * i], qv[2 * i + 1]);
                 }
                 if (a.want_gradient && sub == 0) {
                     // |Plus(x, -g) - x|_inf with the UNSCALED gradient g / scale
