@@ -109,6 +109,16 @@ def test_euler_solver_dof_masks(ba):
         assert np.array_equal(fp.cam_params[const], sc.cam_params[const])
 
 
+def test_many_cameras_take_the_unstaged_path(ba):
+    """The per-point kernels keep the camera tables in LDS when they fit (64 KB); a
+    problem with more cameras reads them from global memory through the same code.
+    900 Euler cameras with one free angle each: 71 KB of tables, a 900-unknown system."""
+    sc = synth.make_ba_scene(1, 900, 3000, config_id=47, euler_free=1, min_len=3, max_len=6)
+    tables = 8 * (7 * 900 + 900) + 4 * 4 * 900 + 6 * 900
+    assert tables > 64 * 1024
+    _compare_solve(ba, sc, max_num_iterations=4)
+
+
 def test_run_bundle_adjustment_semantics(ba):
     """The adapter reproduces runBundleAdjustment's quirks: viewID lookup,
     tracks without a point are skipped, in-place point update only without
