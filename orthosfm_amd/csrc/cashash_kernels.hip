@@ -24,25 +24,70 @@ namespace osfm {
 // memory latency is paid once per chunk instead of once per descriptor.
 constexpr int kAccChunk = 64;
 
-__global__ __launch_bounds__(128) void
+constexpr int kAccStage = 4 * kAccChunk;       // rows fetched per round (32 KB of LDS for SIFT)
+
+__global__ __launch_bounds__(128, 1) void      // one workgroup: all registers are its own
 cashash_accumulate_kernel(const int8_t *__restrict__ desc, int n, int dim, int bias, float div,
     float *__restrict__ sum)
 {
-    __shared__ int8_t rows[kAccChunk * 128];
+    __shared__ __attribute__((aligned(16))) int8_t rows[kAccStage * 128];
+    __shared__ float quot[256];          // (float)(byte + bias) / div for every stored byte value
     const int k = threadIdx.x;
+    // A stored byte has 256 values, so the reference's division (IEEE, not a multiply by
+    // a reciprocal) is done 256 times here instead of once per element: 14 instructions
+    // per element were what this one-workgroup kernel spent its time on.
+    for (int v = k; v < 256; v += 128) quot[v] = (float)((int)(int8_t)v + bias) / div;
     float s = k < dim ? sum[k] : 0.0f;
-    for (int base = 0; base < n; base += kAccChunk) {
-        const int cnt = min(kAccChunk, n - base);
-        const int bytes = cnt * dim;
-        const int4 *src = reinterpret_cast<const int4 *>(desc + (size_t)base * dim);
-        for (int e = threadIdx.x; e * 16 < bytes; e += blockDim.x)
-            reinterpret_cast<int4 *>(rows)[e] = src[e];
-        __syncthreads();
-        if (k < dim)
-            for (int j = 0; j < cnt; ++j)
-                s += (float)((int)rows[j * dim + k] + bias) / div;      // sift_descr[j][k] / 255.0f
+    constexpr int kPer = kAccStage * 128 / 16 / 128;        // 16-byte pieces per thread and round (16)
+    // One workgroup walks the whole view, so what it waits for is memory latency: a round
+    // of 256 rows is fetched (16 loads per thread in flight) while the round before is summed.
+    // (written out rather than as lambdas taking the array: a reference to it puts it in
+    // scratch memory and every load is then waited for at once)
+#define OSFM_ACC_FETCH(BASE)                                                                       \
+    {                                                                                              \
+        const int vecs_ = min(kAccStage, n - (BASE)) * dim / 16;                                   \
+        const int4 *src_ = reinterpret_cast<const int4 *>(desc + (size_t)(BASE) * dim);            \
+        _Pragma("unroll") for (int u = 0; u < kPer; ++u) v[u] = src_[min(u * 128 + k, max(vecs_ - 1, 0))]; \
+    }
+    // every piece is stored, also the clamped repeats behind the round's end (rows that are
+    // never read): a store under a per-piece condition becomes a branch per piece with v[]
+    // parked in scratch memory
+#define OSFM_ACC_DEPOSIT(BASE)                                                                     \
+    {                                                                                              \
+        _Pragma("unroll") for (int u = 0; u < kPer; ++u) reinterpret_cast<int4 *>(rows)[u * 128 + k] = v[u]; \
+    }
+    int4 v[kPer];                        // the only copy in registers: no ping-pong arrays
+    if (n <= 0) return;
+    OSFM_ACC_FETCH(0);
+    OSFM_ACC_DEPOSIT(0);
+    __syncthreads();
+    for (int base = 0; base < n; base += kAccStage) {
+        const int cnt = min(kAccStage, n - base);
+        const bool more = base + kAccStage < n;
+        const int nb = more ? base + kAccStage : base;       // unconditional (a conditional definition of v[] sends it to scratch)
+        OSFM_ACC_FETCH(nb);                                  // in flight while this round is summed
+        if (k < dim) {
+            for (int j0 = 0; j0 < cnt; j0 += kAccChunk) {
+                if (cnt - j0 >= kAccChunk) {
+                    // quotients looked up first (independent), then the additions in the
+                    // reference's order: only the additions form a chain
+                    float q[kAccChunk];
+#pragma unroll
+                    for (int j = 0; j < kAccChunk; ++j) q[j] = quot[(uint8_t)rows[(j0 + j) * dim + k]];   // sift_descr[j][k] / 255.0f
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < kAccChunk; ++j) s += q[j];
+                } else {
+                    for (int j = j0; j < cnt; ++j) s += quot[(uint8_t)rows[j * dim + k]];
+                }
+            }
+        }
+        __syncthreads();                                     // this round has been consumed
+        OSFM_ACC_DEPOSIT(nb);                                // the last round re-deposits itself: harmless
         __syncthreads();
     }
+#undef OSFM_ACC_FETCH
+#undef OSFM_ACC_DEPOSIT
     if (k < dim) sum[k] = s;
 }
 
@@ -108,42 +153,53 @@ cashash_hash_kernel(const int8_t *__restrict__ desc, int n, int bias, float div,
 // ascending order (two passes over the ids: count, then fill).  The ids pass
 // through LDS in chunks fetched by all threads, so that the per-thread scans
 // read LDS broadcasts instead of waiting on one global load per id.
-constexpr int kBucketChunk = 4096;
-
-__global__ __launch_bounds__(kCasBuckets) void
+// build_buckets (cascade_hashing.cc:187-209): per group the CSR of feature ids by
+// bucket, ascending inside a bucket -- a stable counting sort.  One wave per group:
+// histogram with LDS atomics, then the ids go through 64 at a time; lanes holding
+// the same bucket find each other with eight ballots (one per id bit), their rank
+// among equals orders them, the last of them advances the bucket's cursor.
+__global__ __launch_bounds__(64) void
 cashash_buckets_kernel(const uint8_t *__restrict__ bucket_ids, int n, int32_t *__restrict__ start,
     int32_t *__restrict__ items)
 {
     __shared__ int32_t cnt[kCasBuckets + 1];
-    __shared__ uint8_t chunk[kBucketChunk];
-    const int g = blockIdx.x, b = threadIdx.x;
+    __shared__ int32_t cur[kCasBuckets];
+    const int g = blockIdx.x, lane = threadIdx.x;
     const uint8_t *ids = bucket_ids + (size_t)g * n;
     int32_t *out = items + (size_t)g * n;
-    int pos = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        int c = 0;
-        for (int base = 0; base < n; base += kBucketChunk) {
-            const int len = min(kBucketChunk, n - base);
-            __syncthreads();
-            for (int e = b; e < len; e += kCasBuckets) chunk[e] = ids[base + e];
-            __syncthreads();
-            if (pass == 0) {
-                for (int i = 0; i < len; ++i) c += chunk[i] == b;
-            } else {
-                for (int i = 0; i < len; ++i)
-                    if (chunk[i] == b) out[pos++] = base + i;
-            }
+    for (int b = lane; b <= kCasBuckets; b += 64) cnt[b] = 0;
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) atomicAdd(&cnt[ids[i] + 1], 1);
+    __syncthreads();
+    if (lane == 0) for (int k = 0; k < kCasBuckets; ++k) cnt[k + 1] += cnt[k];
+    __syncthreads();
+    for (int b = lane; b <= kCasBuckets; b += 64) {
+        start[(size_t)g * (kCasBuckets + 1) + b] = cnt[b];
+        if (b < kCasBuckets) cur[b] = cnt[b];
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1;
+    int id_next = lane < n ? ids[lane] : 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool act = i < n;
+        const int id = id_next;
+        if (base + 64 + lane < n) id_next = ids[base + 64 + lane];
+        // lanes with the same id
+        unsigned long long same = __ballot(act);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const unsigned long long m = __ballot((id >> bit) & 1);
+            same &= ((id >> bit) & 1) ? m : ~m;
         }
-        if (pass == 0) {
-            cnt[b + 1] = c;
-            if (b == 0) cnt[0] = 0;
-            __syncthreads();
-            if (b == 0) for (int k = 0; k < kCasBuckets; ++k) cnt[k + 1] += cnt[k];
-            __syncthreads();
-            start[(size_t)g * (kCasBuckets + 1) + b] = cnt[b];
-            if (b == kCasBuckets - 1) start[(size_t)g * (kCasBuckets + 1) + kCasBuckets] = cnt[kCasBuckets];
-            pos = cnt[b];
+        if (act) {
+            const int rank = __popcll(same & below);
+            out[cur[id] + rank] = i;
         }
+        __syncthreads();
+        // the highest lane of every set moves the cursor past the set
+        if (act && (same >> lane) == 1ull) cur[id] += __popcll(same);
+        __syncthreads();
     }
 }
 
@@ -474,7 +530,7 @@ void launch_cashash_pack(const uint64_t *hashes, const uint8_t *bucket_ids, int 
 
 void launch_cashash_buckets(const uint8_t *bucket_ids, int n, int32_t *start, int32_t *items, hipStream_t s)
 {
-    hipLaunchKernelGGL(cashash_buckets_kernel, dim3(kCasGroups), dim3(kCasBuckets), 0, s, bucket_ids, n, start, items);
+    hipLaunchKernelGGL(cashash_buckets_kernel, dim3(kCasGroups), dim3(64), 0, s, bucket_ids, n, start, items);
 }
 
 void launch_cashash_match(int dim, const MatchProblem *d_problems, int num_problems, int max_n,
