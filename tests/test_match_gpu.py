@@ -90,7 +90,8 @@ def test_golden_exhaustive_views(hm):
     m.close()
 
 
-@pytest.mark.parametrize("n1,n2,seed", [(300, 257, 1), (1000, 777, 2), (2500, 9000, 3), (8300, 700, 4)])
+@pytest.mark.parametrize("n1,n2,seed", [(300, 257, 1), (1000, 777, 2), (2500, 9000, 3), (8300, 700, 4), (2049, 4097, 5),
+                                          (2048, 4096, 6)])
 def test_sift_vs_oracle_multi_block(hm, n1, n2, seed):
     """Several row blocks / column segments / partial tiles, vs the oracle."""
     s1, s2 = match_cases.sift_pair(n1, n2, min(n1, n2) // 2, 500 + seed)
