@@ -242,6 +242,13 @@ cashash_pack_kernel(const uint64_t *__restrict__ hashes, const uint8_t *__restri
 constexpr int kCasPosBits = 17, kCasGroupShift = kCasPosBits, kCasDistShift = 20;
 constexpr int kCasKeyNone = 0x7fffffff;
 
+__device__ __forceinline__ int cas_med3(int a, int b, int c)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int DIM, int G>
 __global__ __launch_bounds__(128) void
 cashash_scan_kernel(const MatchProblem *__restrict__ problems, int32_t *__restrict__ state, int buckets_per_block)
@@ -283,26 +290,39 @@ cashash_scan_kernel(const MatchProblem *__restrict__ problems, int32_t *__restri
             __syncthreads();
             const int cnt = min(128, ce - c0);
             if (!act) continue;
-            for (int j = 0; j < cnt; ++j) {
-                const CasRecord r = crec[j];
-                // seen in an earlier group iff one of the first G bucket ids equals the
-                // query's: a zero byte in the xor (bytes >= G forced non-zero)
+            // Branch-free and two candidates per round: a duplicate or a candidate that
+            // does not make the list goes through the insertion network as "infinity" and
+            // leaves the keys as they are.  (With 64 queries per wave some lane inserts at
+            // almost every candidate, so the network ran anyway -- behind two `continue`s
+            // whose exec-mask handling was half of the loop's instructions.)
+            auto cand_key = [&](uint64_t h0, uint64_t h1, uint64_t bk, int pos) {
                 bool dup = false;
                 if (G > 0) {
-                    const uint32_t x = ((uint32_t)r.buckets ^ (uint32_t)me.buckets) | (G < 4 ? ~0u << (8 * (G & 3)) : 0u);
+                    // seen in an earlier group iff one of the first G bucket ids equals the
+                    // query's: a zero byte in the xor (bytes >= G forced non-zero)
+                    const uint32_t x = ((uint32_t)bk ^ (uint32_t)me.buckets) | (G < 4 ? ~0u << (8 * (G & 3)) : 0u);
                     dup = ((x - 0x01010101u) & ~x & 0x80808080u) != 0;
                 }
-                if (G == 5) dup |= (((uint32_t)(r.buckets >> 32) ^ (uint32_t)(me.buckets >> 32)) & 0xffu) == 0;
-                if (dup) continue;
-                const int hd = __popcll(me.h[0] ^ r.h[0]) + (DIM > 64 ? __popcll(me.h[1] ^ r.h[1]) : 0);
-                int k = (hd << kCasDistShift) | (g << kCasGroupShift) | (c0 - cb + j);
-                if (k >= key[kCasMaxCand - 1]) continue;
+                if (G == 5) dup |= (((uint32_t)(bk >> 32) ^ (uint32_t)(me.buckets >> 32)) & 0xffu) == 0;
+                const int hd = __popcll(me.h[0] ^ h0) + (DIM > 64 ? __popcll(me.h[1] ^ h1) : 0);
+                const int k = (hd << kCasDistShift) | (g << kCasGroupShift) | pos;
+                return dup ? kCasKeyNone : k;
+            };
+            for (int j = 0; j < cnt; j += 2) {
+                const int j1 = min(j + 1, cnt - 1);
+                const uint64_t a0 = crec[j].h[0], a1 = crec[j].h[1], ab = crec[j].buckets;
+                const uint64_t b0 = crec[j1].h[0], b1 = crec[j1].h[1], bb = crec[j1].buckets;
+                int k0 = cand_key(a0, a1, ab, c0 - cb + j);
+                int k1 = j + 1 < cnt ? cand_key(b0, b1, bb, c0 - cb + j + 1) : kCasKeyNone;
+                // sorted insertion, one op per slot: slot e of the new list is the median of
+                // (old slot e-1, old slot e, x) -- the old neighbour if x lies below it, x if
+                // it falls between the two, the old value otherwise
 #pragma unroll
-                for (int e = 0; e < kCasMaxCand; ++e) {             // sorted insertion
-                    const int lo = min(k, key[e]);
-                    k = max(k, key[e]);
-                    key[e] = lo;
-                }
+                for (int e = kCasMaxCand - 1; e >= 1; --e) key[e] = cas_med3(key[e - 1], key[e], k0);
+                key[0] = min(key[0], k0);
+#pragma unroll
+                for (int e = kCasMaxCand - 1; e >= 1; --e) key[e] = cas_med3(key[e - 1], key[e], k1);
+                key[0] = min(key[0], k1);
             }
         }
         if (act) {
