@@ -730,7 +730,8 @@ int osfm_ransac_fundamental(int device, const float *pos1, int n1, const float *
     struct Rel { DeviceBuffer *b[7]; ~Rel() { for (auto *x : b) x->release(); } } rel{{&d1, &d2, &dc, &di, &dn, &df, &dj}};
     OSFM_RETURN_IF(d1.reserve((size_t)n1 * 8)); OSFM_RETURN_IF(d2.reserve((size_t)n2 * 8));
     OSFM_RETURN_IF(dc.reserve((size_t)k * 8)); OSFM_RETURN_IF(di.reserve((size_t)k * 4));
-    OSFM_RETURN_IF(dn.reserve(16)); OSFM_RETURN_IF(df.reserve(72)); OSFM_RETURN_IF(dj.reserve(sizeof(RansacJob)));
+    OSFM_RETURN_IF(dn.reserve(16)); OSFM_RETURN_IF(df.reserve(72));
+    OSFM_RETURN_IF(dj.reserve(256 + ransac_scratch_bytes(1)));       // the job, then the kernel's scratch
     OSFM_HIP_CHECK(hipMemcpy(d1.ptr, pos1, (size_t)n1 * 8, hipMemcpyHostToDevice));
     OSFM_HIP_CHECK(hipMemcpy(d2.ptr, pos2, (size_t)n2 * 8, hipMemcpyHostToDevice));
     OSFM_HIP_CHECK(hipMemcpy(dc.ptr, corr, (size_t)k * 8, hipMemcpyHostToDevice));
@@ -740,7 +741,7 @@ int osfm_ransac_fundamental(int device, const float *pos1, int n1, const float *
     job.pair_id = pair_id; job.inliers_out = di.as<int32_t>(); job.count_out = dn.as<int32_t>();
     job.F_out = df.as<double>();
     OSFM_HIP_CHECK(hipMemcpy(dj.ptr, &job, sizeof(job), hipMemcpyHostToDevice));
-    launch_ransac(dj.as<RansacJob>(), 1, o.max_iterations, o.threshold, o.seed, nullptr);
+    launch_ransac(dj.as<RansacJob>(), 1, o.max_iterations, o.threshold, o.seed, static_cast<char *>(dj.ptr) + 256, nullptr);
     OSFM_HIP_CHECK(hipGetLastError());
     OSFM_HIP_CHECK(hipDeviceSynchronize());
     int32_t cnt = 0;
@@ -973,10 +974,11 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
                     j.F_out = nullptr;
                     jobs.push_back(j); job_pair.push_back(k);
                 }
-                OSFM_RETURN_IF(m->d_jobs.reserve(jobs.size() * sizeof(RansacJob)));
+                const size_t jobs_bytes = (jobs.size() * sizeof(RansacJob) + 255) / 256 * 256;
+                OSFM_RETURN_IF(m->d_jobs.reserve(jobs_bytes + ransac_scratch_bytes((int)jobs.size())));
                 OSFM_HIP_CHECK(hipMemcpyAsync(m->d_jobs.ptr, jobs.data(), jobs.size() * sizeof(RansacJob), hipMemcpyHostToDevice, s));
                 launch_ransac(m->d_jobs.as<RansacJob>(), (int)jobs.size(), o.ransac_max_iterations, o.ransac_threshold,
-                    o.ransac_seed, s);
+                    o.ransac_seed, static_cast<char *>(m->d_jobs.ptr) + jobs_bytes, s);
                 OSFM_HIP_CHECK(hipGetLastError());
                 std::vector<int32_t> h_cnt(jobs.size());
                 OSFM_HIP_CHECK(hipMemcpyAsync(h_cnt.data(), m->d_inl_count.ptr, jobs.size() * 4, hipMemcpyDeviceToHost, s));

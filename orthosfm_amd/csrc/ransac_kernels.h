@@ -1,6 +1,7 @@
 // Batched RANSAC-F (geometric verification of matched view pairs).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace osfm {
@@ -17,7 +18,12 @@ struct RansacJob {
     double *F_out;            // [9] or null
 };
 
+constexpr int kRansacSplit = 2;     // workgroups per pair (each takes a share of the hypotheses)
+
+// scratch: ransac_scratch_bytes(num_jobs) of device memory (best-of-part slots and the
+// per-pair completion counters), 16-byte aligned
+size_t ransac_scratch_bytes(int num_jobs);
 void launch_ransac(const RansacJob *d_jobs, int num_jobs, int max_iterations, double threshold,
-    uint64_t seed, hipStream_t s);
+    uint64_t seed, void *scratch, hipStream_t s);
 
 }  // namespace osfm

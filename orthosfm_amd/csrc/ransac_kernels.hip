@@ -12,6 +12,8 @@
 // the operation order of the CPU oracle, so both agree bit for bit.
 #include "ransac_kernels.h"
 
+#include <algorithm>
+
 namespace osfm {
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
@@ -158,30 +160,45 @@ eight_point(const double p1[8][2], const double p2[8][2], double F[9])
     return true;
 }
 
-constexpr int kHyp = 4;            // hypotheses per thread and pass
+constexpr int kHyp = 2;            // hypotheses per thread and pass
 constexpr int kChunk = 1024;       // matches staged in LDS at a time
+// The hypotheses of a pair are split over kRansacSplit workgroups: one workgroup per pair
+// of the bench (1225 workgroups, two resident per CU) ran as 2.4 waves of workgroups, the
+// last one 40 % full.  Every part keeps its best (count, iteration, F) in a slot; the part
+// that finishes last (a counter per pair) picks the overall best and lists its inliers.
+struct RansacSlot { int32_t count, iter; double F[9]; };
+
+size_t ransac_scratch_bytes(int num_jobs)
+{
+    return (size_t)std::max(num_jobs, 1) * (kRansacSplit * sizeof(RansacSlot) + 16);
+}
 
 __global__ __launch_bounds__(256) void
-ransac_kernel(const RansacJob *__restrict__ jobs, int max_iterations, double thr2, uint64_t seed)
+ransac_kernel(const RansacJob *__restrict__ jobs, int num_jobs, int max_iterations, double thr2, uint64_t seed,
+    RansacSlot *__restrict__ slots, int32_t *__restrict__ done)
 {
     __shared__ double4 mpt[kChunk];           // (x1, y1, x2, y2) of the staged matches, widened once
     __shared__ int s_count[256], s_iter[256];
     __shared__ double s_F[9];
-    __shared__ int s_wave[4], s_run;
+    __shared__ int s_wave[4], s_run, s_last;
 
-    const RansacJob job = jobs[blockIdx.x];
+    const int jid = blockIdx.x / kRansacSplit, part = blockIdx.x % kRansacSplit;
+    const RansacJob job = jobs[jid];
     const int k = job.k, tid = threadIdx.x;
     if (k < 8) {                      // the reference throws (ransac_fundamental.cc:66-67)
-        if (tid == 0) *job.count_out = -1;
+        if (tid == 0 && part == 0) *job.count_out = -1;
         return;
     }
+    // this part's iterations: whole passes of 256 * kHyp
+    const int per_part = ((max_iterations + kRansacSplit - 1) / kRansacSplit + 256 * kHyp - 1) / (256 * kHyp) * (256 * kHyp);
+    const int it_begin = part * per_part, it_end = min(max_iterations, it_begin + per_part);
     const double thr_lo = thr2 * (1.0 - 1.7763568394002505e-15);     // 2^-49
     const double thr_hi = thr2 * (1.0 + 1.7763568394002505e-15);
     int best_count = 0, best_iter = 0x7fffffff;
     double bestF[9];
     for (int i = 0; i < 9; ++i) bestF[i] = 0.0;
 
-    for (int base = 0; base < max_iterations; base += 256 * kHyp) {
+    for (int base = it_begin; base < it_end; base += 256 * kHyp) {
         double F[kHyp][9];
         bool valid[kHyp];
         int cnt[kHyp];
@@ -190,7 +207,7 @@ ransac_kernel(const RansacJob *__restrict__ jobs, int max_iterations, double thr
             const int it = base + h * 256 + tid;
             valid[h] = false; cnt[h] = 0;
             for (int i = 0; i < 9; ++i) F[h][i] = 0.0;
-            if (it >= max_iterations) continue;
+            if (it >= it_end) continue;
             // 8 distinct match ids, ascending (std::set order, :69-76)
             int idx[8], n = 0;
             for (uint64_t d = 0; n < 8; ++d) {
@@ -251,11 +268,35 @@ ransac_kernel(const RansacJob *__restrict__ jobs, int max_iterations, double thr
         }
         __syncthreads();
     }
-    const int win_count = s_count[0], win_iter = s_iter[0];
+    int win_count = s_count[0], win_iter = s_iter[0];
     if (best_count == win_count && best_iter == win_iter && win_count > 0)
         for (int i = 0; i < 9; ++i) s_F[i] = bestF[i];
-    if (tid == 0) s_run = 0;
     __syncthreads();
+    // this part's best into its slot; the last part to get here goes on with all of them
+    if (tid == 0) {
+        RansacSlot &mine = slots[(size_t)jid * kRansacSplit + part];
+        mine.count = win_count; mine.iter = win_iter;
+        for (int i = 0; i < 9; ++i) mine.F[i] = win_count > 0 ? s_F[i] : 0.0;
+        __threadfence();
+        s_last = atomicAdd(&done[jid], 1) == kRansacSplit - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) {
+        __threadfence();
+        int bc = 0, bi = 0x7fffffff, bp = -1;
+        for (int p = 0; p < kRansacSplit; ++p) {
+            const RansacSlot &sl = slots[(size_t)jid * kRansacSplit + p];
+            // strictly more inliers wins; equal counts keep the earlier iteration (:47)
+            if (sl.count > bc || (sl.count == bc && sl.count > 0 && sl.iter < bi)) { bc = sl.count; bi = sl.iter; bp = p; }
+        }
+        s_count[0] = bc; s_iter[0] = bi;
+        if (bp >= 0) for (int i = 0; i < 9; ++i) s_F[i] = slots[(size_t)jid * kRansacSplit + bp].F[i];
+        done[jid] = 0;                 // ready for the next launch
+        s_run = 0;
+    }
+    __syncthreads();
+    win_count = s_count[0]; win_iter = s_iter[0];
     if (win_count == 0) {
         if (tid == 0) { *job.count_out = 0; if (job.F_out) for (int i = 0; i < 9; ++i) job.F_out[i] = 0.0; }
         return;
@@ -286,11 +327,14 @@ ransac_kernel(const RansacJob *__restrict__ jobs, int max_iterations, double thr
 }
 
 void launch_ransac(const RansacJob *d_jobs, int num_jobs, int max_iterations, double threshold,
-    uint64_t seed, hipStream_t s)
+    uint64_t seed, void *scratch, hipStream_t s)
 {
     if (num_jobs <= 0) return;
-    hipLaunchKernelGGL(ransac_kernel, dim3(num_jobs), dim3(256), 0, s, d_jobs, max_iterations,
-        threshold * threshold, seed);
+    RansacSlot *slots = static_cast<RansacSlot *>(scratch);
+    int32_t *done = reinterpret_cast<int32_t *>(static_cast<char *>(scratch) + (size_t)num_jobs * kRansacSplit * sizeof(RansacSlot));
+    (void)hipMemsetAsync(done, 0, (size_t)num_jobs * sizeof(int32_t), s);
+    hipLaunchKernelGGL(ransac_kernel, dim3(num_jobs * kRansacSplit), dim3(256), 0, s, d_jobs, num_jobs, max_iterations,
+        threshold * threshold, seed, slots, done);
 }
 
 }  // namespace osfm
