@@ -29,13 +29,25 @@ nn_distance_kernel(const double4 *__restrict__ points, int n, double *__restrict
         tile[threadIdx.x] = points[min(j0, n - 1)];
         __syncthreads();
         const int cnt = min(kNnThreads, n - base);
+        if (base != (int)(blockIdx.x * kNnThreads)) {
+            // a tile that cannot hold the thread's own point (uniform per workgroup: the
+            // threads of a workgroup are the points of ONE tile): no index test
 #pragma unroll 8
-        for (int t = 0; t < cnt; ++t) {
-            const double4 q = tile[t];
-            const double d0 = p.x - q.x, d1 = p.y - q.y, d2 = p.z - q.z, d3 = p.w - q.w;
-            const double s = (d0 * d0 + d2 * d2) + (d1 * d1 + d3 * d3);
-            // strict '<' (:29); the point itself is skipped by index, duplicates are not
-            if (base + t != i && s < best) best = s;
+            for (int t = 0; t < cnt; ++t) {
+                const double4 q = tile[t];
+                const double d0 = p.x - q.x, d1 = p.y - q.y, d2 = p.z - q.z, d3 = p.w - q.w;
+                const double s = (d0 * d0 + d2 * d2) + (d1 * d1 + d3 * d3);
+                best = s < best ? s : best;                  // strict '<' (:29)
+            }
+        } else {
+#pragma unroll 8
+            for (int t = 0; t < cnt; ++t) {
+                const double4 q = tile[t];
+                const double d0 = p.x - q.x, d1 = p.y - q.y, d2 = p.z - q.z, d3 = p.w - q.w;
+                const double s = (d0 * d0 + d2 * d2) + (d1 * d1 + d3 * d3);
+                // the point itself is skipped by index, duplicates are not
+                if (base + t != i && s < best) best = s;
+            }
         }
         __syncthreads();
     }
