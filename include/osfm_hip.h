@@ -37,6 +37,9 @@ OSFM_API const char *osfm_last_error(void);
 OSFM_API int osfm_version(void);
 /* Number of visible HIP devices (0 when there is none). */
 OSFM_API int osfm_device_count(void);
+/* Free / total bytes of a device's HBM (hipMemGetInfo): lets a caller size its
+ * batches and check that handles give their memory back. */
+OSFM_API int osfm_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 
 /* ====================================================================== */
 /* (A) Matching                                                            */
@@ -75,6 +78,14 @@ typedef struct osfm_match_options {
     int32_t matcher_type;      /* OSFM_MATCHER_EXHAUSTIVE (default) or OSFM_MATCHER_CASCADE_HASHING:
                                 * bundler::Matching::MatcherType, bundler_matching.h:52-56 */
     uint64_t ransac_seed;           /* stream seed of the counter-based sampler */
+    /* Cascade hashing only.  0 (default): the Result layout of sfm::CascadeHashing --
+     * a descriptor type that EITHER view lacks contributes no entries at all
+     * (CascadeHashing::oneway_match returns before sizing its list,
+     * cascade_hashing.h:341-342, so combine_results sees empty lists and applies no
+     * offset, matching.cc:74-86).  1: the exhaustive matcher's layout (the block of a
+     * type view_1 has is always present, -1 filled): consistent combined indices. */
+    int32_t cascade_keep_empty_blocks;
+    int32_t reserved;
 } osfm_match_options;
 
 OSFM_API int osfm_match_options_default(osfm_match_options *opts);

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <exception>
 #include <memory>
 #include <random>
 #include <vector>
@@ -74,24 +75,9 @@ int main()
             for (int m : r1.matches_1_2) valid += m >= 0;
             checked++;
         }
-    /* cascade hashing: when the OTHER view has no descriptors of a type the
-     * reference leaves that type's block out of its vectors altogether
-     * (oneway_match returns before resizing, cascade_hashing.h:341-342), which
-     * shifts the SURF entries to the front; the adapter keeps the exhaustive
-     * matcher's layout (block present, all -1).  Re-insert the blocks before
-     * comparing. */
-    const int counts[5][2] = { { 700, 300 }, { 650, 0 }, { 0, 280 }, { 810, 333 }, { 3, 2 } };
-    auto expand = [&](std::vector<int> const& ref_v, int a, int b) {
-        std::vector<int> out;
-        std::size_t pos = 0;
-        for (int t = 0; t < 2; ++t) {
-            const int na = counts[a][t], nb = counts[b][t];
-            if (na == 0) continue;                         /* type skipped by both (cc:82,95) */
-            for (int i = 0; i < na; ++i) out.push_back(nb > 0 ? ref_v[pos + i] : -1);
-            if (nb > 0) pos += na;
-        }
-        return out;
-    };
+    /* cascade hashing: the adapter's default layout is sfm::CascadeHashing's own (a type
+     * that either view lacks contributes no entries, cascade_hashing.h:341-342), so the
+     * Result vectors are compared as they are */
     sfm::bundler::ViewportList vc, vd;
     fill_views(&vc, 7);
     fill_views(&vd, 7);
@@ -106,26 +92,7 @@ int main()
             sfm::Matching::Result r1, r2;
             cref->pairwise_match(a, b, &r1);
             chip->pairwise_match(a, b, &r2);
-            /* matches_2_1 follows view b's blocks; a type takes part iff view a has it */
-            std::vector<int> e21;
-            {
-                std::size_t pos = 0;
-                for (int t = 0; t < 2; ++t) {
-                    if (counts[a][t] == 0) continue;
-                    const int nb = counts[b][t];
-                    /* with view b SIFT-less the reference's SIFT lists are EMPTY, so its
-                     * combine_results (matching.cc:74-86) does not shift the SURF indices of
-                     * the 2->1 list behind view a's SIFT block; the adapter does (consistent
-                     * combined indices, as with the exhaustive matcher) */
-                    const int shift = (t == 1 && counts[a][0] > 0 && counts[b][0] == 0) ? counts[a][0] : 0;
-                    for (int i = 0; i < nb; ++i) {
-                        const int v = r1.matches_2_1[pos + i];
-                        e21.push_back(v >= 0 ? v + shift : v);
-                    }
-                    pos += nb;
-                }
-            }
-            if (expand(r1.matches_1_2, a, b) != r2.matches_1_2 || e21 != r2.matches_2_1) {
+            if (r1.matches_1_2 != r2.matches_1_2 || r1.matches_2_1 != r2.matches_2_1) {
                 std::fprintf(stderr, "MISMATCH cascade pairwise_match(%d,%d)\n", a, b);
                 return 1;
             }
@@ -135,6 +102,39 @@ int main()
             cchecked++;
         }
     std::printf("adapter_check ok: %d pairs identical to sfm::CascadeHashing, %d valid matches\n", cchecked, cvalid);
+
+    /* The caller's loop (bundler::Matching::compute, bundler_matching.cc:74-79,149,162):
+     * pairwise_match / pairwise_match_lowres invoked concurrently from an OpenMP team on
+     * one const matcher.  Every thread's results must equal the serial ones. */
+    {
+        const int num_pairs = 5 * 4 / 2;
+        std::vector<sfm::Matching::Result> serial(num_pairs), par(num_pairs);
+        std::vector<int> low_serial(num_pairs), low_par(num_pairs);
+        for (int i = 0; i < num_pairs; ++i) {
+            const int v1 = (int)(0.5 + std::sqrt(0.25 + 2.0 * i)), v2 = i - v1 * (v1 - 1) / 2;
+            hip->pairwise_match(v1, v2, &serial[i]);
+            low_serial[i] = hip->pairwise_match_lowres(v1, v2, 500);
+        }
+        int failed = 0;
+        for (int round = 0; round < 3; ++round) {
+#pragma omp parallel for schedule(dynamic) num_threads(8)
+            for (int i = 0; i < num_pairs; ++i) {
+                const int v1 = (int)(0.5 + std::sqrt(0.25 + 2.0 * i)), v2 = i - v1 * (v1 - 1) / 2;
+                try {
+                    low_par[i] = hip->pairwise_match_lowres(v1, v2, 500);
+                    hip->pairwise_match(v1, v2, &par[i]);
+                } catch (std::exception const& e) {
+#pragma omp critical
+                    { std::fprintf(stderr, "exception in thread: %s\n", e.what()); failed++; }
+                }
+            }
+            for (int i = 0; i < num_pairs; ++i)
+                if (par[i].matches_1_2 != serial[i].matches_1_2 || par[i].matches_2_1 != serial[i].matches_2_1 ||
+                    low_par[i] != low_serial[i]) failed++;
+        }
+        if (failed) { std::fprintf(stderr, "MISMATCH: %d concurrent calls differ from the serial results\n", failed); return 1; }
+        std::printf("adapter_check ok: %d pairs x 3 rounds from 8 OpenMP threads identical to the serial calls\n", num_pairs);
+    }
 
     bool threw = false;
     try { hip->init(nullptr); } catch (std::invalid_argument const&) { threw = true; }

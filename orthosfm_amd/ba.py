@@ -265,7 +265,7 @@ def run_bundle_adjustment(cameras, tracks, algorithm=None, optimize_points=True,
 
 
 # ---------------------------------------------------------------------------
-# bench / smoke helpers
+# bench helper
 # ---------------------------------------------------------------------------
 
 def bench_global_ba(num_cameras=200, num_points=100000, max_iterations=25, device=0):
@@ -289,21 +289,3 @@ def bench_global_ba(num_cameras=200, num_points=100000, max_iterations=25, devic
                           "cholesky": s.cholesky_ms, "back_pass": s.back_pass_ms,
                           "sum": lm_ms, "linearizations": int(s.linearizations)},
             "pair_entries": int(s.num_pair_entries)}
-
-
-def smoke():
-    """One small BA on device 0, checked against the CPU oracle."""
-    import os
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-    import oracle_lib
-    from . import synth
-    sc = synth.make_ba_scene(synth.MODEL_QUATERNION, 8, 300, config_id=21)
-    ref = sc.copy()
-    so = oracle_lib.oracle_ba_solve(ref)
-    fp = FlatProblem.from_scene(sc)
-    s = solve(fp)
-    assert s.num_iterations == so.num_iterations, (s.num_iterations, so.num_iterations)
-    assert abs(s.final_cost - so.final_cost) <= 1e-9 * max(1.0, so.final_cost), (s.final_cost, so.final_cost)
-    assert np.allclose(fp.cam_params, ref.cam_params, rtol=0, atol=1e-8)
-    print(f"ba smoke ok: {s.num_iterations} LM iterations, final cost {s.final_cost:.6f} == oracle")

@@ -42,7 +42,8 @@ class MatchOptions(C.Structure):
                 ("pairs_per_batch", C.c_int32),
                 ("geometric_verification", C.c_int32), ("ransac_max_iterations", C.c_int32),
                 ("ransac_threshold", C.c_double), ("min_matching_inliers", C.c_int32),
-                ("matcher_type", C.c_int32), ("ransac_seed", C.c_uint64)]
+                ("matcher_type", C.c_int32), ("ransac_seed", C.c_uint64),
+                ("cascade_keep_empty_blocks", C.c_int32), ("reserved", C.c_int32)]
 
 
 class RansacOptions(C.Structure):
@@ -111,7 +112,7 @@ class BaSummary(C.Structure):
 
 # every symbol include/osfm_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = [
-    "osfm_last_error", "osfm_version", "osfm_device_count",
+    "osfm_last_error", "osfm_version", "osfm_device_count", "osfm_device_memory",
     "osfm_match_options_default", "osfm_match_create", "osfm_match_destroy",
     "osfm_quantize_sift", "osfm_quantize_surf",
     "osfm_match_set_view", "osfm_match_set_view_float", "osfm_match_view_size", "osfm_match_set_positions",
@@ -144,6 +145,13 @@ def _ptr(a, ctype):
 
 def device_count() -> int:
     return lib.osfm_device_count()
+
+
+def device_memory(device: int = 0):
+    """(free, total) bytes of the device's HBM."""
+    f, t = C.c_uint64(), C.c_uint64()
+    check(lib.osfm_device_memory(device, C.byref(f), C.byref(t)))
+    return f.value, t.value
 
 
 def default_match_options() -> MatchOptions:

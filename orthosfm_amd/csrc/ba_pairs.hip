@@ -60,6 +60,14 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
     const int M = d.M;
     out->num_pairs = 0; out->num_entries = 0;
     if (M == 0) return OSFM_OK;
+    // per-track counts, offsets and the hipCUB item counts are 32-bit, and the lists take
+    // about 36 bytes per entry up front: long tracks (sum of squared track lengths) are
+    // refused here instead of wrapping the offsets
+    if (max_entries > (int64_t)0x7fffffff) {
+        set_error("ba_solve: %lld observation pairs in the Schur complement lists (sum of squared track "
+                  "lengths) exceed the supported 2^31 - 1", (long long)max_entries);
+        return OSFM_E_RANGE;
+    }
     OSFM_RETURN_IF(out->counts.reserve((size_t)(M + 1) * 4));
     OSFM_RETURN_IF(out->offsets.reserve((size_t)(M + 1) * 4));
     OSFM_RETURN_IF(out->keys_in.reserve((size_t)max_entries * 4));

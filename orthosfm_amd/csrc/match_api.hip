@@ -188,6 +188,12 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
         pl.ns1 = a.ns; pl.nu1 = a.nu; pl.ns2 = b.ns; pl.nu2 = b.nu;
         pl.has_sift = a.ns > 0 && (mode.type_mask & 1);
         pl.has_surf = a.nu > 0 && (mode.type_mask & 2);
+        // sfm::CascadeHashing leaves a type out of the Result altogether when view_2 lacks it
+        // (cascade_hashing.h:341-342; ExhaustiveMatching keeps the -1 filled block)
+        if (cascade && !m->opts.cascade_keep_empty_blocks) {
+            if (b.ns == 0) pl.has_sift = false;
+            if (b.nu == 0) pl.has_surf = false;
+        }
         // exhaustive_matching.cc:153-177: SIFT takes precedence
         if (mode.lowres && pl.has_sift) pl.has_surf = false;
         if (lowres_limit > 0) {
@@ -539,6 +545,22 @@ int osfm_device_count(void)
     return n;
 }
 
+int osfm_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("device_memory: no HIP device available");
+        return OSFM_E_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { set_error("device_memory: device %d out of range [0,%d)", device, ndev); return OSFM_E_ARG; }
+    OSFM_HIP_CHECK(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    OSFM_HIP_CHECK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return OSFM_OK;
+}
+
 int osfm_match_options_default(osfm_match_options *o)
 {
     if (!o) { set_error("options_default: null"); return OSFM_E_ARG; }
@@ -557,6 +579,8 @@ int osfm_match_options_default(osfm_match_options *o)
     o->min_matching_inliers = 30;
     o->matcher_type = OSFM_MATCHER_EXHAUSTIVE;
     o->ransac_seed = 0;
+    o->cascade_keep_empty_blocks = 0;
+    o->reserved = 0;
     return OSFM_OK;
 }
 
@@ -574,7 +598,9 @@ int osfm_match_create(int device, int num_views, const osfm_match_options *opts,
         return OSFM_E_ARG;
     }
     OSFM_HIP_CHECK(hipSetDevice(device));
-    osfm_matcher *m = new osfm_matcher();
+    // owned until the last step succeeded: an error return frees everything made so far
+    struct Owner { osfm_matcher *p; ~Owner() { if (p) osfm_match_destroy(p); } } owner{new osfm_matcher()};
+    osfm_matcher *m = owner.p;
     m->device = device;
     if (opts) m->opts = *opts; else osfm_match_options_default(&m->opts);
     m->views.resize(num_views);
@@ -595,6 +621,7 @@ int osfm_match_create(int device, int num_views, const osfm_match_options *opts,
     m->tab_surf.reject_from = m->lowe_surf.as<int32_t>();
     m->tab_surf.max_d1 = max_d1_for(m->opts.surf_distance_threshold, true);
     m->tab_surf.is_signed = 1;
+    owner.p = nullptr;
     *out = m;
     return OSFM_OK;
 }
@@ -603,23 +630,12 @@ int osfm_match_destroy(osfm_matcher *m)
 {
     if (!m) return OSFM_OK;
     (void)hipSetDevice(m->device);
-    (void)hipStreamSynchronize(m->stream);
-    for (auto &v : m->views) {
-        DeviceBuffer *vb[] = {&v.sift, &v.sift_corr, &v.surf, &v.surf_corr, &v.sift_raw, &v.sift_raw_corr,
-            &v.special, &v.special_corr, &v.special_map, &v.special_slot, &v.positions};
-        for (auto *b : vb) b->release();
-    }
-    DeviceBuffer *bufs[] = {&m->lowe_sift, &m->lowe_surf, &m->d_problems[0], &m->d_problems[1],
-        &m->rowparts, &m->colparts, &m->out, &m->keep, &m->mark_off[0], &m->mark_off[1],
-        &m->counts[0], &m->counts[1], &m->exact_items, &m->exact_count, &m->stage_in, &m->flags,
-        &m->d_m12_off, &m->d_len12, &m->d_corr_off, &m->d_keep_pair, &m->d_corr,
-        &m->d_jobs, &m->d_inl, &m->d_inl_count, &m->d_corr2, &m->d_gather_off};
-    for (auto *b : bufs) b->release();
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2; ++j)
             if (m->ev[i][j]) (void)hipEventDestroy(m->ev[i][j]);
     if (m->stream) (void)hipStreamDestroy(m->stream);
-    delete m;
+    delete m;       // every DeviceBuffer (views, scratch, cascade-hashing data) frees itself
     return OSFM_OK;
 }
 
@@ -924,7 +940,10 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
                 chunk_corr += res.counts[k];
             }
             if (!o.geometric_verification && written + chunk_corr > capacity) overflow = true;
-            if (!overflow && chunk_corr > 0) {
+            // With verification the pre-RANSAC lists are device scratch (d_corr) that the
+            // RANSAC jobs of THIS chunk read: they are built whatever the state of the
+            // caller's buffer; only the copies to the host stop after an overflow.
+            if (chunk_corr > 0 && (o.geometric_verification || !overflow)) {
                 hipStream_t s = m->stream;
                 OSFM_RETURN_IF(m->d_m12_off.reserve(n * 8));
                 OSFM_RETURN_IF(m->d_corr_off.reserve(n * 8));

@@ -30,9 +30,20 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 // Device allocation that only ever grows; contents are NOT preserved on growth.
+// Owns its memory: freed by the destructor (or release()); movable, not copyable.
 struct DeviceBuffer {
     void *ptr = nullptr;
     size_t bytes = 0;
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    DeviceBuffer(DeviceBuffer &&o) noexcept : ptr(o.ptr), bytes(o.bytes) { o.ptr = nullptr; o.bytes = 0; }
+    DeviceBuffer &operator=(DeviceBuffer &&o) noexcept
+    {
+        if (this != &o) { release(); ptr = o.ptr; bytes = o.bytes; o.ptr = nullptr; o.bytes = 0; }
+        return *this;
+    }
+    ~DeviceBuffer() { release(); }
     int reserve(size_t need)
     {
         if (need <= bytes) return OSFM_OK;

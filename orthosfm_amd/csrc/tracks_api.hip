@@ -55,6 +55,10 @@ static int tracks_compute_impl(int32_t num_views, const int32_t *view_sizes, con
     std::vector<int64_t> nxt((size_t)G, -1);
     std::vector<int64_t> head, tail;
     std::vector<int32_t> size;
+    // a self-match (view_1 == view_2, feature matched to itself) makes the reference push
+    // the same FeatureReference twice (:80-86): the track is invalid for good (two features
+    // of one view) and counts one feature more than it has nodes
+    std::vector<uint8_t> twice;
 
     for (int p = 0; p < num_pairs; ++p) {                                       // :66-119
         const int v1 = pairs[p].view_1, v2 = pairs[p].view_2;
@@ -73,7 +77,8 @@ static int tracks_compute_impl(int32_t num_views, const int32_t *view_sizes, con
             if (t1 == -1 && t2 == -1) {
                 const int32_t t = (int32_t)head.size();
                 head.push_back(g1); tail.push_back(g2); size.push_back(2);
-                nxt[g1] = g2;
+                twice.push_back(g1 == g2 ? 1 : 0);
+                if (g1 != g2) nxt[g1] = g2;
                 tid[g1] = t; tid[g2] = t;
             } else if (t1 == -1) {
                 tid[g1] = t2; nxt[tail[t2]] = g1; tail[t2] = g1; size[t2]++;
@@ -85,6 +90,7 @@ static int tracks_compute_impl(int32_t num_views, const int32_t *view_sizes, con
                 if (size[a] < size[b]) { a = t2; b = t1; }
                 for (int64_t g = head[b]; g >= 0; g = nxt[g]) tid[g] = a;
                 nxt[tail[a]] = head[b]; tail[a] = tail[b]; size[a] += size[b];
+                twice[a] |= twice[b];
                 head[b] = -1; tail[b] = -1; size[b] = 0;
             }
         }
@@ -98,7 +104,7 @@ static int tracks_compute_impl(int32_t num_views, const int32_t *view_sizes, con
     int64_t kept_features = 0;
     for (int64_t t = 0; t < nt; ++t) {
         if (size[t] == 0) continue;
-        bool bad = false;
+        bool bad = twice[t] != 0;
         for (int64_t g = head[t]; g >= 0 && !bad; g = nxt[g]) {
             // view of node g: the last voff entry <= g (views are few: binary search)
             int lo = 0, hi = num_views - 1;

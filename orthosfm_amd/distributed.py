@@ -159,12 +159,23 @@ class SharedMatchStore:
         if rank == 0:
             os.unlink(self.path)          # the mappings keep the segment alive; nothing is left behind
         self.slice = self.array[rank * self.rows:(rank + 1) * self.rows]
+        ok = 1
         if str(device) != "cpu" and torch.cuda.is_available():
             # page-lock the own slice so that the matcher's copy runs at PCIe rate
             rc = torch.cuda.cudart().cudaHostRegister(self.slice.ctypes.data, self.slice.nbytes, 0)
             if int(rc) != 0:
-                raise RuntimeError(f"hipHostRegister of the result slice failed ({rc})")
-            self._registered = self.slice.ctypes.data
+                ok = 0
+            else:
+                self._registered = self.slice.ctypes.data
+        # a failure on one rank is everybody's: the ranks agree (one all_reduce) and ALL of
+        # them raise SharedSegmentUnavailable, so no rank is left waiting in a collective
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=device if str(device) != "cpu" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            self.close()
+            raise SharedSegmentUnavailable("hipHostRegister of a result slice failed on some rank")
 
     def collect(self, local_counts, num_pairs: int):
         """After the rank's lists are in its slice (packed in shard order): returns on

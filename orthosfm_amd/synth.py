@@ -119,10 +119,19 @@ class ImageSet:
 def make_image_set(num_views: int, feats_per_view: int, *, seed: int = BASE_SEED,
                    config_id: int = 2, n_surf: int = 0, visibility: float = 0.4,
                    distractor_frac: float = 0.2, noise: float = 0.03,
-                   width: int = 2048, height: int = 2048) -> ImageSet:
+                   width: int = 2048, height: int = 2048, twin_frac: float = 0.0,
+                   unrelated_views: int = 0) -> ImageSet:
     """L landmarks in the ball |p| <= 0.5 with a base descriptor
     each; view v sees a random subset; descriptor = unit(base + noise*N(0,1)),
-    quantised as A1; per-view feature order = descending keypoint scale."""
+    quantised as A1; per-view feature order = descending keypoint scale.
+
+    twin_frac > 0: repeated structure -- that share of the landmarks comes in
+    pairs with the SAME base descriptor at different 3-D positions, so a view
+    that sees one twin matches it to the other twin of a view that sees only
+    that one: mutual matches that pass ratio test and cross-check and are
+    geometrically wrong (work for RANSAC-F).  unrelated_views > 0: the last
+    views show a different scene (landmarks of their own), so their pairs with
+    the others are rejected by the low-res gate / the match-count threshold."""
     n_real = int(round(feats_per_view * (1.0 - distractor_frac)))
     n_dis = feats_per_view - n_real
     L = max(int(round(n_real / visibility)), n_real)
@@ -135,6 +144,13 @@ def make_image_set(num_views: int, feats_per_view: int, *, seed: int = BASE_SEED
     points = d * rad[:, None]
     base_sift = normal(seed, st | 3, 128 * L).reshape(L, 128)
     base_sift_u = _unit_rows(np.minimum(_unit_rows(np.abs(base_sift)), 0.2))
+    if twin_frac > 0.0:
+        n_tw = int(L * twin_frac) // 2
+        base_sift_u[n_tw:2 * n_tw] = base_sift_u[:n_tw]          # landmark n_tw + i is the twin of i
+    if unrelated_views > 0:
+        # a second scene: descriptors of its own (positions may coincide, they never match)
+        other_sift = normal(seed, st | 6, 128 * L).reshape(L, 128)
+        other_sift_u = _unit_rows(np.minimum(_unit_rows(np.abs(other_sift)), 0.2))
     base_surf = _unit_rows(normal(seed, st | 4, 64 * L).reshape(L, 64)) if n_surf else None
     # intrinsic keypoint scale of a landmark: MVE sorts features by scale,
     # largest first (feature_set.cc:70), so the low-res prefix of two views
@@ -154,11 +170,14 @@ def make_image_set(num_views: int, feats_per_view: int, *, seed: int = BASE_SEED
         keys = uniform(seed, sv | 1, L)
         vis = np.argsort(keys, kind="stable")[:n_real]
         g = normal(seed, sv | 2, 128 * n_real).reshape(n_real, 128)
-        f_real = _unit_rows(np.abs(base_sift_u[vis] + noise * g))
+        scene = other_sift_u if v >= num_views - unrelated_views and unrelated_views > 0 else base_sift_u
+        f_real = _unit_rows(np.abs(scene[vis] + noise * g))
         f_real = _unit_rows(np.minimum(f_real, 0.2)).astype(np.float32)
         f_dis = sift_like(normal(seed, sv | 3, 128 * n_dis).reshape(n_dis, 128))
         f = np.concatenate([f_real, f_dis], axis=0)
         lm = np.concatenate([vis, -np.ones(n_dis, dtype=np.int64)])
+        if v >= num_views - unrelated_views and unrelated_views > 0:
+            lm = np.concatenate([vis + L, -np.ones(n_dis, dtype=np.int64)])      # ids of the other scene
         # per-view order: descending scale (landmark scale + detection jitter;
         # distractors get a random scale)
         jit = uniform(seed, sv | 4, feats_per_view)

@@ -642,16 +642,17 @@ class OracleCasHash:
         self.local = [[oracle_cashash_hashes(s, 128, 255.0, self.avg[0], *self.proj[0]) for s in sifts],
                       [oracle_cashash_hashes(u, 64, 127.0, self.avg[1], *self.proj[1]) for u in surfs]]
 
-    def pairwise_match(self, v1, v2):
+    def pairwise_match(self, v1, v2, keep_empty_blocks=False):
         """cascade_hashing.cc:73-104.  A descriptor type takes part iff view 1 has
         descriptors of it (:82,95); with an empty set on side 2 the reference
         leaves that part out of its vectors (oneway_match returns before resizing,
-        cascade_hashing.h:341-342) -- here, as at the flat boundary, it stays in as -1."""
+        cascade_hashing.h:341-342), and so does this unless keep_empty_blocks asks
+        for the exhaustive matcher's layout (the block stays in as -1)."""
         om = oracle_matcher()
         parts = []
         for t, descs in enumerate((self.sifts, self.surfs)):
             a, b = descs[v1], descs[v2]
-            if a.shape[0] == 0:
+            if a.shape[0] == 0 or (b.shape[0] == 0 and not keep_empty_blocks):
                 parts.append((np.zeros(0, np.int32), np.zeros(0, np.int32)))
                 continue
             (h1, b1), (h2, b2) = self.local[t][v1], self.local[t][v2]

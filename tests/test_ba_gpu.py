@@ -163,22 +163,44 @@ def test_run_bundle_adjustment_semantics(ba):
     assert any(not np.allclose(c.params(), sc.cam_params[i]) for i, c in enumerate(cams2) if i)
 
 
-def test_global_ba_properties_config4_quarter(ba):
-    """A quarter-size instance of BASELINE config 4 (200 cameras, 25k tracks):
-    too big for a quick oracle run, checked through properties -- monotone
-    cost, convergence, reprojection error near the noise level, bit-identical
-    repeat (no floating-point atomics anywhere in the solve)."""
-    sc = synth.make_ba_scene(0, 200, 25000, config_id=4)
+def test_global_ba_properties_config4_full_size(ba):
+    """BASELINE config 4 at its stated size (200 quaternion cameras, 100k tracks,
+    ~750k observations): too big for a quick oracle run, checked through properties
+    -- convergence, cost far below the start, reprojection error near the noise
+    level, ground truth recovered, bit-identical repeat (no floating-point atomics
+    anywhere in the solve)."""
+    sc = synth.make_ba_scene(0, 200, 100000, config_id=4)
     fp = ba.FlatProblem.from_scene(sc)
     s = ba.solve(fp)
     assert s.termination in (1, 2, 3)
     assert s.final_cost < 0.05 * s.initial_cost
     err, _ = ba.reprojection_errors(fp)
     assert np.median(err) < 1.5            # 0.5 px noise per axis
+    # camera 0 is fixed at its ground-truth pose, so the gauge is pinned: the other
+    # cameras come back to the ground truth (2 degrees / 0.01 off at the start)
+    q, g = fp.cam_params[:, :4], sc.gt_cams[:, :4]
+    ang = 2.0 * np.arccos(np.clip(np.abs((q * g).sum(1)) / np.linalg.norm(q, axis=1), 0, 1))
+    assert np.rad2deg(ang).max() < 0.05
+    assert np.abs(fp.cam_params[:, 4:6] - sc.gt_cams[:, 4:6]).max() < 1e-3
     fp2 = ba.FlatProblem.from_scene(sc)
     s2 = ba.solve(fp2)
     assert s2.final_cost == s.final_cost and s2.num_iterations == s.num_iterations
     assert np.array_equal(fp2.cam_params, fp.cam_params) and np.array_equal(fp2.points, fp.points)
+
+
+def test_pair_list_bound_is_refused(ba):
+    """The Schur pair lists are 32-bit: a problem whose sum of squared track lengths
+    passes 2^31 - 1 is refused with OSFM_E_RANGE before anything is allocated
+    (one track seen 46341 times is enough: 46341^2 = 2^31 + 4633)."""
+    from orthosfm_amd import capi
+    sc = synth.make_ba_scene(0, 12, 4, config_id=47)
+    n = 46341
+    cam = (np.arange(n) % 11 + 1).astype(np.int32)
+    fp = ba.FlatProblem(0, sc.cam_params, sc.cam_const, sc.img_w, sc.img_h, sc.points[:1],
+                        np.zeros((n, 2)), cam, np.zeros(n, np.int32))
+    with pytest.raises(capi.OsfmError) as e:
+        ba.solve(fp)
+    assert e.value.status == capi.E_RANGE
 
 
 def test_ba_error_behaviour(ba):

@@ -51,6 +51,27 @@ def test_pairwise_match_bit_exact(setup):
     assert (orc.pairwise_match(1, 0)[0] >= 0).sum() > 100
 
 
+def test_keep_empty_blocks_option(setup):
+    """View 2 has no SURF: by default the lists follow sfm::CascadeHashing (the SURF part
+    of a pair with view 2 on side 2 is absent); with cascade_keep_empty_blocks the
+    exhaustive matcher's layout (-1 filled block) comes back."""
+    iset, orc, _, capi = setup
+    from orthosfm_amd.matching import HipCascadeHashing
+    o = capi.default_match_options()
+    o.cascade_keep_empty_blocks = 1
+    m = HipCascadeHashing(4, options=o)
+    for v in range(4):
+        m.set_view(v, iset.sift[v], iset.surf[v])
+    for a, b in ((0, 2), (2, 0), (1, 3)):
+        got = m.pairwise_match(a, b)
+        k12, k21 = orc.pairwise_match(a, b, keep_empty_blocks=True)
+        assert np.array_equal(got.matches_1_2, k12) and np.array_equal(got.matches_2_1, k21), (a, b)
+    assert m.pairwise_match(0, 2).matches_1_2.shape[0] == iset.sift[0].shape[0] + iset.surf[0].shape[0]
+    r12, _ = orc.pairwise_match(0, 2)
+    assert r12.shape[0] == iset.sift[0].shape[0]
+    m.close()
+
+
 def test_lowres_stays_exhaustive_and_compute_runs_the_gates(setup):
     iset, orc, m, capi = setup
     low = oracle_lib.oracle_pairwise_match_lowres(iset.sift[1], iset.surf[1], iset.sift[0], iset.surf[0], 500)

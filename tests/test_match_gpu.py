@@ -251,6 +251,7 @@ def test_cpp_adapter_vs_reference_side_by_side():
     assert out.returncode == 0, out.stdout + out.stderr
     assert "adapter_check ok: 20 pairs identical to sfm::ExhaustiveMatching" in out.stdout
     assert "adapter_check ok: 20 pairs identical to sfm::CascadeHashing" in out.stdout
+    assert "from 8 OpenMP threads identical to the serial calls" in out.stdout
 
 
 def test_special_rows_large_values(hm):
@@ -400,3 +401,97 @@ print("OK")
     if "NOGPU" in out.stdout:
         pytest.skip("torch sees no GPU")
     assert "OK" in out.stdout
+
+
+def test_full_size_bit_parity_20k(hm):
+    """BASELINE cfg2's per-pair shape at its stated size -- 20000 x 20000 SIFT, 79 row
+    blocks x 3 column segments, the correction-free kernel every bench number comes
+    from -- compared with the oracle list by list (two-way lists, then the
+    cross-checked ones), and once more with a few hundred rows holding values > 127
+    in both views (special-row blocks + the corrected column operand)."""
+    iset = synth.make_image_set(2, 20000, config_id=2)
+    om = oracle_lib.oracle_matcher()
+    m = hm(2)
+    for variant in ("plain", "special"):
+        s1, s2 = iset.sift[0].copy(), iset.sift[1].copy()
+        if variant == "special":
+            r = np.random.default_rng(41)
+            for s in (s1, s2):
+                for k in r.choice(20000, 400, replace=False):
+                    d = s[k].copy()
+                    d[r.choice(128, 2, replace=False)] = [int(r.integers(128, 256)), int(r.integers(128, 180))]
+                    s[k] = d
+        e12, e21 = om.twoway(s1, s2, 0.8)
+        c12, c21 = om.remove_inconsistent(e12, e21)
+        m.set_view(0, s1)
+        m.set_view(1, s2)
+        got = m.pairwise_match(0, 1)
+        assert np.array_equal(got.matches_1_2, c12) and np.array_equal(got.matches_2_1, c21), variant
+        assert int((c12 >= 0).sum()) > 5000
+        two = m.twoway_match(0, 1, 0)           # the pre-cross-check seam (masked kernel)
+        assert np.array_equal(two.matches_1_2, e12) and np.array_equal(two.matches_2_1, e21), variant
+    m.close()
+
+
+def test_capacity_overflow_with_verification(hm):
+    """osfm_match_all with geometric verification, chunks of two pairs and a caller
+    buffer that holds only the first chunk: OSFM_E_CAPACITY with the required total,
+    no device fault (the later chunks' RANSAC jobs read THEIR chunk's lists), and the
+    same call with enough room afterwards gives the full result."""
+    from orthosfm_amd import capi
+    V, F = 5, 1500
+    iset = synth.make_image_set(V, F, config_id=13)
+    o = capi.default_match_options()
+    o.geometric_verification = 1
+    o.pairs_per_batch = 2
+    m = hm(V, options=o)
+    for v in range(V):
+        m.set_view(v, iset.sift[v])
+        xy = (iset.pos[v] + 0.5 - np.array([iset.width / 2, iset.height / 2])) / max(iset.width, iset.height)
+        m.set_positions(v, xy.astype(np.float32))
+    full = m.compute()
+    counts = [tv.num_inliers for tv in full if tv.status == capi.PAIR_MATCHED]
+    assert len(counts) == 10 and min(counts) > 100
+    need = sum(counts)
+    small = counts[0] + counts[1] + 3          # room for the first chunk only; later chunks are larger than the slack
+    with pytest.raises(capi.OsfmError) as e:
+        m.compute(capacity=small)
+    assert e.value.status == capi.E_CAPACITY and str(need) in str(e.value)
+    again = m.compute(capacity=need)
+    for a, b in zip(full, again):
+        assert a.status == b.status and np.array_equal(a.matches, b.matches)
+    # same without verification (lists are copied chunk by chunk)
+    o2 = capi.default_match_options()
+    o2.pairs_per_batch = 2
+    m2 = hm(V, options=o2)
+    for v in range(V):
+        m2.set_view(v, iset.sift[v])
+    with pytest.raises(capi.OsfmError) as e:
+        m2.compute(capacity=100)
+    assert e.value.status == capi.E_CAPACITY
+    m.close(); m2.close()
+
+
+def test_matcher_handles_give_their_memory_back():
+    """Creating and destroying matchers (cascade-hashing mode included: its per-view
+    hash tables and candidate scratch are the largest buffers) leaves the device's
+    free memory where it was."""
+    from orthosfm_amd import capi
+    from orthosfm_amd.matching import HipCascadeHashing, HipExhaustiveMatching
+    iset = synth.make_image_set(3, 4000, config_id=14)
+
+    def cycle(cls):
+        m = cls(3)
+        for v in range(3):
+            m.set_view(v, iset.sift[v])
+        out = m.compute()
+        assert len(out) == 3
+        m.close()
+
+    cycle(HipCascadeHashing); cycle(HipExhaustiveMatching)          # first use: code objects, pools
+    free0, _ = capi.device_memory(0)
+    for _ in range(6):
+        cycle(HipCascadeHashing)
+        cycle(HipExhaustiveMatching)
+    free1, _ = capi.device_memory(0)
+    assert free0 - free1 < (8 << 20), (free0, free1)

@@ -134,3 +134,24 @@ def test_ranges_entry_matches_packed_entry():
     bad[0] = -1
     with pytest.raises(capi.OsfmError):
         tracks.compute_flat_ranges(m["view_sizes"], m["colors"], pairs, starts, bad, big)
+
+
+def test_self_match_is_an_invalid_track_not_a_hang():
+    """A pair with view_1 == view_2 whose list matches a feature to itself makes the
+    reference push the same FeatureReference twice (bundler_tracks.cc:80-86): the
+    track is dropped as conflicting, whatever is merged into it later.  Checked
+    against the oracle (and the reference build when present)."""
+    m = {"view_sizes": np.array([6, 5, 4], np.int32), "colors": None,
+         "pairs": np.array([[1, 1], [1, 0], [2, 1], [2, 0]], np.int32),
+         "pair_offsets": np.array([0, 2, 4, 6, 7], np.int64),
+         "corr": np.array([[3, 3], [0, 1],          # (1,1): self-match of feature 3; 0 <-> 1 inside view 1
+                           [3, 2], [4, 4],          # (1,0): the poisoned track grows; a clean track
+                           [1, 3], [2, 4],          # (2,1): joins the poisoned track; joins the clean one
+                           [0, 5]], np.int32)}
+    got = product(m)
+    want = oracle_lib.oracle_tracks(**m)
+    same(got, want)
+    assert got["track_ids"][6 + 3] == -1 and got["num_invalid"] == 2
+    assert got["track_offsets"].shape[0] - 1 == 2
+    if oracle_lib.ref_tracks() is not None:
+        same(oracle_lib.ref_tracks_compute(**m), want)
