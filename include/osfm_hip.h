@@ -302,6 +302,14 @@ typedef struct osfm_ba_options {
     int32_t max_consecutive_invalid_steps;  /* 5 */
     int32_t device;
     int32_t verbose;
+    /* runBundleAdjustment's retriangulatePoints (bundle_adjustment.cpp:77-83): the points
+     * are first replaced by the ray intersections of their observations under the given
+     * cameras (triangulateOrthographicTracks with resetExistingPoints; a point with fewer
+     * than two observations keeps its input value).  The reference does this on a filtered
+     * copy of the tracks that it discards; whether to keep the returned points is the
+     * caller's choice. */
+    int32_t retriangulate_points;      /* 0 */
+    int32_t reserved;
 } osfm_ba_options;
 
 enum {

@@ -86,7 +86,8 @@ class BaOptions(C.Structure):
                 ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
                 ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
                 ("jacobi_scaling", C.c_int32), ("max_consecutive_invalid_steps", C.c_int32),
-                ("device", C.c_int32), ("verbose", C.c_int32)]
+                ("device", C.c_int32), ("verbose", C.c_int32),
+                ("retriangulate_points", C.c_int32), ("reserved", C.c_int32)]
 
 
 class TracksSummary(C.Structure):

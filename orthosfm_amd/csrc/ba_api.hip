@@ -183,6 +183,8 @@ int osfm_ba_options_default(osfm_ba_options *o)
     o->max_consecutive_invalid_steps = 5;
     o->device = 0;
     o->verbose = 0;
+    o->retriangulate_points = 0;
+    o->reserved = 0;
     return OSFM_OK;
 }
 
@@ -216,6 +218,16 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     DeviceProblem D;
     OSFM_RETURN_IF(upload_problem(p, L, o.huber_delta, pdim, s, &D));
     BaDev &d = D.dev;
+    // the points the optimisation starts from (tracksBackup, bundle_adjustment.cpp:99)
+    std::vector<double> pts0((size_t)4 * M);
+    if (M) memcpy(pts0.data(), p->points, (size_t)4 * M * 8);
+    if (o.retriangulate_points && M > 0) {
+        // triangulateTracks(cameras, localTracks, true) in front of the solve (bundle_adjustment.cpp:77-83)
+        OSFM_HIP_CHECK(hipMemcpyAsync(D.points[1].ptr, D.points[0].ptr, (size_t)4 * M * 8, hipMemcpyDeviceToDevice, s));
+        launch_triangulate(d, D.points[1].as<double>(), nullptr, s);
+        OSFM_HIP_CHECK(hipMemcpyAsync(D.points[0].ptr, D.points[1].ptr, (size_t)4 * M * 8, hipMemcpyDeviceToDevice, s));
+        OSFM_HIP_CHECK(hipMemcpyAsync(pts0.data(), D.points[1].ptr, (size_t)4 * M * 8, hipMemcpyDeviceToHost, s));
+    }
     lap("upload problem");
 
     // camera-pair lists of the Schur complement, built on the device
@@ -423,8 +435,6 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     sum->lm_loop_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count();
     lap("LM loop");
     // ---- write back the current iterate --------------------------------------
-    std::vector<double> pts0((size_t)4 * M);
-    if (M) memcpy(pts0.data(), p->points, (size_t)4 * M * 8);
     if (C) OSFM_HIP_CHECK(hipMemcpyAsync(p->cam_params, D.cams[cur].ptr, (size_t)7 * C * 8, hipMemcpyDeviceToHost, s));
     if (M) OSFM_HIP_CHECK(hipMemcpyAsync(p->points, D.points[cur].ptr, (size_t)4 * M * 8, hipMemcpyDeviceToHost, s));
     OSFM_HIP_CHECK(hipStreamSynchronize(s));

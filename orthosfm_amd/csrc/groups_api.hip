@@ -17,6 +17,7 @@
 // reference's single-threaded behaviour; its OpenMP loop breaks ties by thread
 // timing (group.cpp:118-146).
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -72,6 +73,100 @@ group_score_kernel(const uint64_t *__restrict__ bt, int V, int W, const int32_t 
     if (tid == 0) { best_score[s] = s_score[0]; best_idx[s] = s_score[0] > 0 ? s_idx[0] : -1; }
 }
 
+
+// ---------------------------------------------------------------------------
+// Group size 3 (what the reference's algorithms use): incremental form.
+//
+// A seed is a pair (a, b) of used views, its score row row[c] = |T_a & T_b & T_c|
+// over all views c.  Scores never change, so a row is computed ONCE, when the
+// second view of the pair gets used (a new view c* makes |used| new seeds), and
+// kept in HBM (V(V-1)/2 rows of V ints: 250 MB at V = 500).  Every seed caches its
+// best remaining candidate; assigning c* invalidates only the seeds whose pick
+// was c*, and those re-scan their stored row (V ints), not the bitsets.  One
+// iteration = score the new rows, refresh, arg-max over all seeds (a 64-bit
+// atomicMax of (score, ~seed order): order independent, hence deterministic).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ size_t pair_index(int a, int b) { return (size_t)b * (b - 1) / 2 + a; }   // a < b
+
+// grid (new seeds, candidate chunks); a wave scores one candidate at a time:
+// lanes stride over the W words of the three bitsets (row-major [V][W])
+__global__ __launch_bounds__(256) void
+group3_score_rows_kernel(const uint64_t *__restrict__ bits, int V, int W, const int32_t *__restrict__ new_seeds,
+    int32_t *__restrict__ rows)
+{
+    const int a = new_seeds[2 * blockIdx.x], b = new_seeds[2 * blockIdx.x + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t *Ba = bits + (size_t)a * W, *Bb = bits + (size_t)b * W;
+    int32_t *row = rows + pair_index(a, b) * V;
+    constexpr int kCandPerBlock = 32;
+    const int c0 = blockIdx.y * kCandPerBlock;
+    for (int ci = wave; ci < kCandPerBlock; ci += 4) {
+        const int c = c0 + ci;
+        if (c >= V) break;
+        const uint64_t *Bc = bits + (size_t)c * W;
+        uint32_t acc0 = 0, acc1 = 0;
+        int w = lane;
+        for (; w + 64 < W; w += 128) {
+            acc0 += (uint32_t)__popcll(Ba[w] & Bb[w] & Bc[w]);
+            acc1 += (uint32_t)__popcll(Ba[w + 64] & Bb[w + 64] & Bc[w + 64]);
+        }
+        if (w < W) acc0 += (uint32_t)__popcll(Ba[w] & Bb[w] & Bc[w]);
+        uint32_t acc = acc0 + acc1;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+        if (lane == 0) row[c] = (c == a || c == b) ? 0 : (int32_t)acc;      // group.cpp:123-125
+    }
+}
+
+// One thread per pair (a < b) of ranks; pairs with both views used are seeds.
+// state[v]: 0 remaining, 1 used, 2 not (yet) part of anything.
+// best[pair] = (score << 32) | candidate (or 0xffffffff when no candidate shares a
+// track); a seed is refreshed when it is new (best == ~0) or its pick was assigned.
+__global__ __launch_bounds__(256) void
+group3_select_kernel(int V, const uint8_t *__restrict__ state, const int32_t *__restrict__ rows,
+    uint64_t *__restrict__ best, int assigned, unsigned long long *__restrict__ result)
+{
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t P = (size_t)V * (V - 1) / 2;
+    unsigned long long key = 0;
+    if (p < P) {
+        // invert the triangular index: b = largest with b (b - 1) / 2 <= p
+        int b = (int)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5);
+        while ((size_t)b * (b - 1) / 2 > p) --b;
+        while ((size_t)(b + 1) * b / 2 <= p) ++b;
+        const int a = (int)(p - (size_t)b * (b - 1) / 2);
+        if (state[a] == 1 && state[b] == 1) {
+            uint64_t cur = best[p];
+            const uint32_t cand = (uint32_t)(cur & 0xffffffffu);
+            if (cur == ~0ull || (cand != 0xffffffffu && (int)cand == assigned)) {
+                const int32_t *row = rows + p * V;
+                int bs = 0, bc = -1;
+                for (int c = 0; c < V; ++c)
+                    if (state[c] == 0 && row[c] > bs) { bs = row[c]; bc = c; }     // first maximum, ascending id
+                cur = ((uint64_t)(uint32_t)bs << 32) | (uint32_t)bc;
+                best[p] = cur;
+            }
+            // first maximum in the lexicographic (a, b) order of the sorted used views
+            const uint32_t order = (uint32_t)a * (uint32_t)V + (uint32_t)b;
+            key = ((cur >> 32) << 32) | (uint32_t)(~order);
+            key += 1ull << 63;                       // any seed beats "no seed"
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned long long o = __shfl_xor(key, m);
+        key = o > key ? o : key;
+    }
+    if ((threadIdx.x & 63) == 0 && key) atomicMax(result, key);
+}
+
+__global__ void
+group3_init_kernel(uint64_t *best, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) best[i] = ~0ull;
+}
+
 }  // namespace osfm
 
 using namespace osfm;
@@ -110,6 +205,82 @@ int osfm_build_groups(int device, int32_t num_views, const int32_t *view_ids, in
             if (it != rank_of.end()) bt[(size_t)(t >> 6) * V + it->second] |= 1ull << (t & 63);
         }
     OSFM_HIP_CHECK(hipSetDevice(device));
+    if (group_size == 3) {
+        // ---- incremental form (see the kernels above) --------------------------
+        const size_t P = (size_t)V * (V - 1) / 2;
+        const size_t rows_bytes = P * (size_t)V * 4;
+        size_t free_b = 0, total_b = 0;
+        OSFM_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        if (rows_bytes + ((size_t)1 << 30) < free_b) {
+            // row-major bitsets [V][W]
+            std::vector<uint64_t> bits((size_t)V * W, 0);
+            for (int w = 0; w < W; ++w)
+                for (int v = 0; v < V; ++v) bits[(size_t)v * W + w] = bt[(size_t)w * V + v];
+            DeviceBuffer d_bits, d_rows, d_best, d_state, d_new, d_result;
+            OSFM_RETURN_IF(d_bits.reserve(bits.size() * 8));
+            OSFM_RETURN_IF(d_rows.reserve(rows_bytes));
+            OSFM_RETURN_IF(d_best.reserve(P * 8));
+            OSFM_RETURN_IF(d_state.reserve((size_t)V));
+            OSFM_RETURN_IF(d_new.reserve((size_t)V * 8));
+            OSFM_RETURN_IF(d_result.reserve(8));
+            OSFM_HIP_CHECK(hipMemcpy(d_bits.ptr, bits.data(), bits.size() * 8, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(group3_init_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, 0, d_best.as<uint64_t>(), P);
+            std::vector<uint8_t> state(V, 2);
+            for (int i = 2; i < V; ++i) state[rank_of[view_ids[i]]] = 0;
+            const int r0 = rank_of[view_ids[0]], r1 = rank_of[view_ids[1]];
+            if (r0 == r1) { set_error("build_groups: views 0 and 1 are the same view"); return OSFM_E_ARG; }
+            // the first seed (views 0 and 1) counts as used for the selection
+            state[r0] = 1; state[r1] = 1;
+            std::vector<int32_t> new_seeds = {std::min(r0, r1), std::max(r0, r1)};
+            int assigned = -1, remaining_n = V - 2;
+            bool first = true;
+            while (first || remaining_n > 0) {
+                const int nn = (int)(new_seeds.size() / 2);
+                OSFM_HIP_CHECK(hipMemcpyAsync(d_state.ptr, state.data(), (size_t)V, hipMemcpyHostToDevice, 0));
+                if (nn > 0) {
+                    OSFM_HIP_CHECK(hipMemcpyAsync(d_new.ptr, new_seeds.data(), new_seeds.size() * 4, hipMemcpyHostToDevice, 0));
+                    hipLaunchKernelGGL(group3_score_rows_kernel, dim3(nn, (V + 31) / 32), dim3(256), 0, 0, d_bits.as<uint64_t>(), V, W,
+                        d_new.as<int32_t>(), d_rows.as<int32_t>());
+                }
+                OSFM_HIP_CHECK(hipMemsetAsync(d_result.ptr, 0, 8, 0));
+                hipLaunchKernelGGL(group3_select_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, 0, V, d_state.as<uint8_t>(),
+                    d_rows.as<int32_t>(), d_best.as<uint64_t>(), assigned, d_result.as<unsigned long long>());
+                OSFM_HIP_CHECK(hipGetLastError());
+                unsigned long long key = 0;
+                OSFM_HIP_CHECK(hipMemcpy(&key, d_result.ptr, 8, hipMemcpyDeviceToHost));
+                if (!key) { set_error("build_groups: no seed group"); return OSFM_E_STATE; }
+                const uint32_t order = ~(uint32_t)(key & 0xffffffffu);
+                const int a = (int)(order / (uint32_t)V), b = (int)(order % (uint32_t)V);
+                const int added = (int)((key >> 32) & 0x7fffffffu);
+                // the winning seed's pick
+                uint64_t cur = 0;
+                OSFM_HIP_CHECK(hipMemcpy(&cur, d_best.as<uint64_t>() + ((size_t)b * (b - 1) / 2 + a), 8, hipMemcpyDeviceToHost));
+                const int c = (int)(int32_t)(uint32_t)(cur & 0xffffffffu);
+                if (*num_groups >= max_groups) { set_error("build_groups: more than %d groups", max_groups); return OSFM_E_CAPACITY; }
+                if (c < 0) {
+                    set_error("build_groups: a remaining view shares no track with any seed group "
+                              "(the reference loops forever here, group.cpp:64-66)");
+                    return OSFM_E_STATE;
+                }
+                int32_t *g = groups + (size_t)(*num_groups) * 3;
+                if (first) { g[0] = view_ids[0]; g[1] = view_ids[1]; }       // group.cpp:27-30: views 0 and 1 in that order
+                else { g[0] = view_ids[by_id[a]]; g[1] = view_ids[by_id[b]]; }
+                g[2] = view_ids[by_id[c]];
+                group_tracks[*num_groups] = added;
+                ++*num_groups;
+                // the new view joins the used set: its pairs with every used view are the new seeds
+                new_seeds.clear();
+                for (int u = 0; u < V; ++u)
+                    if (state[u] == 1) { new_seeds.push_back(std::min(u, c)); new_seeds.push_back(std::max(u, c)); }
+                state[c] = 1;
+                assigned = c;
+                --remaining_n;
+                first = false;
+            }
+            return OSFM_OK;
+        }
+        // not enough device memory for the score rows: the general path below
+    }
     DeviceBuffer d_bt, d_seeds, d_cand, d_score, d_idx;
     struct Cleanup { DeviceBuffer *b[5]; ~Cleanup() { for (auto *x : b) x->release(); } } cleanup{{&d_bt, &d_seeds, &d_cand, &d_score, &d_idx}};
     OSFM_RETURN_IF(d_bt.reserve(bt.size() * 8));

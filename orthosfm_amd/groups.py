@@ -30,8 +30,15 @@ def flatten_tracks(tracks):
 
 
 def build_groups(view_ids, tracks, group_size: int = 3, device: int = 0, verbose: bool = False):
-    view_ids = np.ascontiguousarray(view_ids, dtype=np.int32)
     offs, views = flatten_tracks(tracks)
+    return build_groups_flat(view_ids, offs, views, group_size, device, verbose)
+
+
+def build_groups_flat(view_ids, offs, views, group_size: int = 3, device: int = 0, verbose: bool = False):
+    """The same on tracks given as CSR: offs [num_tracks + 1], views [..] = Feature::viewID."""
+    view_ids = np.ascontiguousarray(view_ids, dtype=np.int32)
+    offs = np.ascontiguousarray(offs, dtype=np.int64)
+    views = np.ascontiguousarray(views, dtype=np.int32)
     if views.size == 0:
         views = np.zeros(1, np.int32)
     cap = max(len(view_ids), 1)

@@ -1,0 +1,518 @@
+"""End-to-end driver over the C ABI: everything the backend replaces, in the order
+the reference calls it, timed as one job.
+
+    orthosfm::reconstruct                     src/sfm/reconstruct.cpp:32-172
+      calculateTracksUsingMVE                 src/matching/matching_mve.cpp:247-473
+        bundler::Matching::init / compute       (low-res gate, two-way match, cross-check, RANSAC-F)
+        bundler::Tracks::compute
+        MVE track -> orthosfm::Track            :455-466
+      runPoseEstimation                       src/sfm/reconstruct.cpp:174-295
+        buildGroups                             :181-184
+        per group (:193-275): initial alignment, filterTracksWithReprojectionError,
+          local bundle adjustment (retriangulated copy), merge, triangulateTracks,
+          every 3rd group: global bundle adjustment + filterOutlierTracks +
+          filterTracksWithReprojectionError; final bundle adjustment (:281)
+
+What is NOT here, because SURVEY section 8 puts it out of scope: image IO / feature
+extraction (the synthetic ImageSet stands in for the views with their
+descriptors) and the Tomasi-Kanade initial alignment of a group
+(ReconstructionAlgorithm::calculateInitialAlignment).  The pose a new camera
+starts its local bundle adjustment from is its ground-truth pose perturbed by a
+given rotation / offset -- the role TK's estimate plays in the reference; the
+scene is expressed in the frame in which camera 0 is canonical, which is the
+frame normalizeScene (reconstruct.cpp:228,268) keeps the reconstruction in.
+
+The reference drags std::vector<Track> copies through this loop (one copy of all
+tracks per group, :205).  Here the tracks are ONE structure of arrays (features
+in track order) plus alive flags; a per-view inverted index serves the
+three-camera steps, so a group costs what its cameras see, not what the scene
+holds.  All arithmetic -- matching, RANSAC, track merge, group scores,
+triangulation, reprojection errors, LM -- happens behind the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import ba as B
+from . import capi, groups as G, synth, tracks as T
+from .matching import HipCascadeHashing, HipExhaustiveMatching
+
+MAX_REPROJECTION_ERROR = 1.5            # outlier_filtering.cpp:140
+GLOBAL_BA_INTERVAL = 3                  # reconstruct.cpp:187
+
+
+# ---------------------------------------------------------------------------
+# tracks as a structure of arrays
+# ---------------------------------------------------------------------------
+class TrackTable:
+    """All tracks of the scene: features in track order (the order of
+    Tracks::compute), pixel positions as the float32 values Feature::x/y hold
+    (track.h:26-27), the homogeneous point and hasPoint() per track, and the
+    alive flags the filters clear (a filtered std::vector<Track> in the
+    reference is the subset with both flags set here)."""
+
+    def __init__(self, offsets, view, feat, xy, num_views):
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self.view = np.ascontiguousarray(view, dtype=np.int32)
+        self.feat = np.ascontiguousarray(feat, dtype=np.int32)
+        self.xy = np.ascontiguousarray(xy, dtype=np.float32).astype(np.float64)
+        self.num_views = int(num_views)
+        T_ = self.offsets.shape[0] - 1
+        self.track_of = np.repeat(np.arange(T_, dtype=np.int32), np.diff(self.offsets))
+        self.point = np.zeros((T_, 4))
+        self.has_point = np.zeros(T_, dtype=bool)
+        self.alive_t = np.ones(T_, dtype=bool)
+        self.alive_f = np.ones(self.view.shape[0], dtype=bool)
+        order = np.argsort(self.view, kind="stable").astype(np.int64)      # feature ids grouped by view, ascending inside
+        self.by_view = order
+        self.view_start = np.searchsorted(self.view[order], np.arange(self.num_views + 1))
+
+    @classmethod
+    def from_mve(cls, track_offsets, track_features, norm_positions, image_width, num_views):
+        """matching_mve.cpp:455-466: pixel = imageWidth * (normalised + 0.5) for BOTH axes
+        (double arithmetic, stored as float)."""
+        tf = np.asarray(track_features, dtype=np.int32).reshape(-1, 2)
+        view, feat = tf[:, 0], tf[:, 1]
+        voff = np.concatenate([[0], np.cumsum([len(p) for p in norm_positions])]).astype(np.int64)
+        pos_all = np.concatenate([np.asarray(p, dtype=np.float32).reshape(-1, 2) for p in norm_positions])
+        p = pos_all[voff[view] + feat].astype(np.float64)
+        xy = (float(image_width) * (p + 0.5)).astype(np.float32)
+        return cls(track_offsets, view, feat, xy, num_views)
+
+    @property
+    def num_tracks(self):
+        return int(self.alive_t.sum())
+
+    def features_of_views(self, views):
+        """Alive features of alive tracks seen by the given views, in track order."""
+        idx = np.concatenate([self.by_view[self.view_start[v]:self.view_start[v + 1]] for v in views])
+        idx = idx[self.alive_f[idx] & self.alive_t[self.track_of[idx]]]
+        idx.sort()
+        return idx
+
+    def alive_lengths(self):
+        """Features left per track (0 for dead tracks)."""
+        n = np.bincount(self.track_of[self.alive_f], minlength=self.alive_t.shape[0])
+        return np.where(self.alive_t, n, 0)
+
+
+# ---------------------------------------------------------------------------
+# cameras
+# ---------------------------------------------------------------------------
+_Tm = np.array([[1.0, 0, 0], [0, 0, -1.0], [0, 1.0, 0]])
+
+
+def _euler_from_S(S):
+    """(phi, theta, rho) with S = Rz(phi) Rx(theta + pi/2) Rz(rho) (synth.euler_matrix)."""
+    om = np.arccos(np.clip(S[2, 2], -1.0, 1.0))
+    if abs(np.sin(om)) < 1e-12:
+        return np.arctan2(S[1, 0], S[0, 0]), om - 0.5 * np.pi, 0.0
+    phi = np.arctan2(S[0, 2], -S[1, 2])
+    rho = np.arctan2(S[2, 0], S[2, 1])
+    return phi, om - 0.5 * np.pi, rho
+
+
+def _quat_to_mat(q):
+    x, y, z, w = q / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _cam_rotation(model, p):
+    """local -> world rotation of a camera parameter vector."""
+    if model == B.MODEL_QUATERNION:
+        return _quat_to_mat(p[:4])
+    return _Tm.T @ synth.euler_matrix(p[0], p[1], p[2])
+
+
+def _set_cam_rotation(model, p, R):
+    if model == B.MODEL_QUATERNION:
+        q = synth.mat_to_quat(R)
+        if np.dot(q, p[:4]) < 0:
+            q = -q
+        p[:4] = q
+    else:
+        p[0], p[1], p[2] = _euler_from_S(_Tm @ R)
+
+
+def canonical_ground_truth(iset, model):
+    """Ground-truth cameras and landmarks in the frame in which camera 0 is canonical
+    (identity rotation / zero angles), i.e. after normalizeScene.  The half-pixel of
+    the MVE -> pixel conversion (matching_mve.cpp:463) goes into the offsets, so the
+    cameras project the landmarks onto the feature positions the tracks carry."""
+    V = iset.num_views
+    R = [_Tm.T @ synth.euler_matrix(*iset.cams[v]) for v in range(V)]
+    A = R[0].T
+    gt = np.zeros((V, 7))
+    for v in range(V):
+        Rv = A @ R[v]
+        if model == B.MODEL_QUATERNION:
+            gt[v, :4] = synth.mat_to_quat(Rv)
+            gt[v, 4:] = (1.0 / iset.width, 1.0 / iset.height, 1.0)
+        else:
+            gt[v, :3] = _euler_from_S(_Tm @ Rv)
+            gt[v, 3:6] = (1.0 / iset.width, 1.0 / iset.height, 1.0)
+    pts = (A @ iset.points.T).T
+    return gt, pts
+
+
+def euler_dof_of_solver(solver):
+    """setSolverType (OrthographicReconstructionAlgorithm.cpp:15-34): solver 1 -> 1 (phi),
+    2 -> 2 (phi, theta), 3 -> 4 (phi, theta, roll, offsets)."""
+    return {1: 1, 2: 2, 3: 4}.get(int(solver), 4)
+
+
+def default_const_mask(model, fixed=False, euler_dof=4):
+    """SetupParameterBlocks' constancy per parameter: quaternion model rotation/offset
+    free, scale fixed (OrthoQuaternionCamera.h:89-91); Euler model by degrees of freedom
+    (OrthographicCamera.cpp:195-207; solver 3 = 4)."""
+    if model == B.MODEL_QUATERNION:
+        m = np.array([0, 0, 0, 0, 0, 0, 1], dtype=np.uint8)
+    else:
+        d = euler_dof
+        m = np.array([d < 1, d < 2, d < 3, d < 4, d < 4, d < 5, True], dtype=np.uint8)
+    if fixed:
+        m[:] = 1
+    return m
+
+
+def align_to_global(model, local, global_):
+    """alignToGlobalCameras: the rotation that carries the local copies of the shared
+    cameras onto their global poses, applied to all local cameras.  Both models use the
+    least-squares rotation between the camera frames (origin and axes of the shared
+    cameras, as OrthographicReconstructionAlgorithm.cpp:98-139 feeds to umeyama)."""
+    src, dst = [], []
+    for pl, pg in zip(local, global_):
+        if pg is None:
+            continue
+        Rl, Rg = _cam_rotation(model, pl), _cam_rotation(model, pg)
+        for k in range(3):
+            src.append(Rl[:, k]); dst.append(Rg[:, k])
+        src.append(-10.0 * Rl[:, 2]); dst.append(-10.0 * Rg[:, 2])
+    if not src:
+        return
+    S, D = np.array(src).T, np.array(dst).T
+    S = S - S.mean(1, keepdims=True)
+    D = D - D.mean(1, keepdims=True)
+    U, _, Vt = np.linalg.svd(D @ S.T)
+    d = np.sign(np.linalg.det(U @ Vt))
+    Rot = U @ np.diag([1.0, 1.0, d]) @ Vt
+    for pl in local:
+        _set_cam_rotation(model, pl, Rot @ _cam_rotation(model, pl))
+
+
+# ---------------------------------------------------------------------------
+# the job
+# ---------------------------------------------------------------------------
+@dataclass
+class Timings:
+    upload_s: float = 0.0
+    matching_s: float = 0.0
+    tracks_s: float = 0.0
+    convert_s: float = 0.0
+    groups_s: float = 0.0
+    local_ba_s: float = 0.0
+    local_filter_s: float = 0.0
+    triangulate_s: float = 0.0
+    global_ba_s: float = 0.0
+    outlier_filter_s: float = 0.0
+    pose_host_s: float = 0.0
+    pose_s: float = 0.0
+    total_s: float = 0.0
+
+
+@dataclass
+class BaCall:
+    kind: str               # "local" / "global" / "final"
+    cameras: int
+    points: int
+    observations: int
+    iterations: int
+    ms: float
+    lm_ms: float
+
+
+@dataclass
+class Result:
+    cam_params: np.ndarray
+    aligned_views: list
+    tracks: TrackTable
+    groups: list
+    timings: Timings
+    ba_calls: list
+    num_pairs: int = 0
+    matched_pairs: int = 0
+    correspondences: int = 0
+    num_mve_tracks: int = 0
+    invalid_mve_tracks: int = 0
+    captured: dict = field(default_factory=dict)
+    pair_status: np.ndarray | None = None
+
+
+def _problem(model, cams, const, width, height, points, xy, obs_cam, obs_pt):
+    return B.FlatProblem(model, cams, const, np.full(cams.shape[0], width, np.int32),
+                         np.full(cams.shape[0], height, np.int32), points, xy, obs_cam, obs_pt)
+
+
+def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, timings=None, pairs=None):
+    """calculateTracksUsingMVE up to (and including) the track conversion."""
+    tm = timings if timings is not None else Timings()
+    V = iset.num_views
+    o = capi.default_match_options()
+    o.geometric_verification = 1 if verify else 0
+    cls = HipExhaustiveMatching if matcher == "exhaustive" else HipCascadeHashing
+    t0 = time.perf_counter()
+    m = cls(V, device=device, options=o, copy_results=False)
+    norm = []
+    W, H = iset.width, iset.height
+    for v in range(V):
+        m.set_view(v, iset.sift[v], iset.surf[v] if iset.surf[v].shape[0] else None)
+        xy = ((iset.pos[v] + 0.5 - np.array([W / 2, H / 2])) / max(W, H)).astype(np.float32)   # feature_set.cc:42-55
+        if iset.surf[v].shape[0]:
+            xy = np.concatenate([xy, np.zeros((iset.surf[v].shape[0], 2), np.float32)])
+        norm.append(xy)
+        if verify:
+            m.set_positions(v, xy)
+    tm.upload_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    if pairs is None:
+        pairs = [capi.pair_from_index(i) for i in range(V * (V - 1) // 2)]
+    cap = sum(min(iset.sift[a].shape[0] + iset.surf[a].shape[0], iset.sift[b].shape[0] + iset.surf[b].shape[0])
+              for a, b in pairs)
+    out = m.compute(pairs, capacity=cap)
+    tm.matching_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    matched = [tv for tv in out if tv.status == capi.PAIR_MATCHED]
+    sizes = np.array([iset.sift[v].shape[0] + iset.surf[v].shape[0] for v in range(V)], dtype=np.int32)
+    parr, offs, corr = T.flatten_matching(matched)
+    ids, toff, tfeat, tcol, summary = T.compute_flat(sizes, None, parr, offs, corr)
+    tm.tracks_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    tt = TrackTable.from_mve(toff, tfeat, norm, W, V)
+    tm.convert_s = time.perf_counter() - t0
+    info = {"num_pairs": len(pairs), "matched_pairs": len(matched), "correspondences": int(offs[-1]),
+            "num_mve_tracks": int(summary.num_tracks), "invalid_mve_tracks": int(summary.num_invalid_tracks),
+            "pair_status": np.array([tv.status for tv in out], dtype=np.int32)}
+    m.close()
+    return tt, info
+
+
+def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2.0, off_perturb=0.01,
+                        seed=7, timings=None, capture=(), max_groups=None, verbose=False, view_ids=None,
+                        euler_dof=4):
+    """runPoseEstimation (reconstruct.cpp:174-295) on the track table."""
+    tm = timings if timings is not None else Timings()
+    V = iset.num_views
+    W, H = iset.width, iset.height
+    gt, _ = canonical_ground_truth(iset, model)
+    rng = np.random.default_rng(seed)
+    t_pose = time.perf_counter()
+
+    # ---- buildGroups ----------------------------------------------------------
+    t0 = time.perf_counter()
+    fmask = tt.alive_f & tt.alive_t[tt.track_of]
+    offs = np.concatenate([[0], np.cumsum(tt.alive_lengths()[tt.alive_t])]).astype(np.int64)
+    views_flat = tt.view[fmask]
+    vids = np.arange(V, dtype=np.int32) if view_ids is None else np.asarray(view_ids, np.int32)
+    groups = G.build_groups_flat(vids, offs, views_flat, 3, device)
+    tm.groups_s = time.perf_counter() - t0
+    if max_groups is not None:
+        groups = groups[:max_groups]
+
+    cams = np.zeros((V, 7))
+    const = np.zeros((V, 7), dtype=np.uint8)
+    aligned = []                       # view ids in the order they joined (alignedCameras)
+    is_aligned = np.zeros(V, dtype=bool)
+    calls, captured = [], {}
+    opt = B.default_options(device=device)
+    opt_local = B.default_options(device=device, retriangulate_points=1)
+
+    def start_pose(v):
+        p = gt[v].copy()
+        if v == groups[0].ids[0] and not aligned:
+            return p                                     # the first camera: canonical, fixed for the whole run
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        a = np.deg2rad(rot_perturb_deg)
+        if model == B.MODEL_QUATERNION:
+            dq = np.array([*(np.sin(a / 2) * axis), np.cos(a / 2)])
+            p[:4] = synth.quat_mul(dq, p[:4])
+            p[4:6] += off_perturb * rng.normal(size=2)
+        else:
+            p[:3] += a * axis / np.sqrt(3.0)
+            p[3:5] += off_perturb * rng.normal(size=2)
+        return p
+
+    def solve(kind, prob, options):
+        t0 = time.perf_counter()
+        if len(calls) in capture:
+            captured[len(calls)] = (kind, B.FlatProblem(prob.model, prob.cam_params, prob.cam_const, prob.img_w, prob.img_h,
+                                                        prob.points, prob.obs_xy, prob.obs_camera, prob.obs_point),
+                                    int(options.retriangulate_points))
+        s = B.solve(prob, options)
+        dt = time.perf_counter() - t0
+        calls.append(BaCall(kind, prob.cam_params.shape[0], prob.points.shape[0], prob.obs_camera.shape[0],
+                            int(s.num_iterations), dt * 1e3, s.lm_loop_ms))
+        return s, dt
+
+    def triangulate_all():
+        """algorithm->triangulateTracks(alignedCameras, tracks, true): every track with two
+        or more rays under the aligned cameras gets its intersection, the others lose their
+        point (triangulation.cpp:76-91)."""
+        t0 = time.perf_counter()
+        cam_of = np.full(V, -1, dtype=np.int32)
+        cam_of[aligned] = np.arange(len(aligned), dtype=np.int32)
+        fsel = np.nonzero((cam_of[tt.view] >= 0) & tt.alive_f & tt.alive_t[tt.track_of])[0]
+        tr = tt.track_of[fsel]
+        uniq, first = np.unique(tr, return_index=True)          # fsel is in track order
+        obs_pt = np.searchsorted(uniq, tr).astype(np.int32)
+        prob = _problem(model, cams[aligned], const[aligned], W, H, np.tile([0.0, 0, 0, 1], (uniq.size, 1)),
+                        tt.xy[fsel], cam_of[tt.view[fsel]], obs_pt)
+        valid = B.triangulate(prob, device) if uniq.size else np.zeros(0, np.uint8)
+        tt.has_point[:] = False
+        ok = uniq[valid.astype(bool)]
+        tt.has_point[ok] = True
+        tt.point[ok] = prob.points[valid.astype(bool)]
+        tm.triangulate_s += time.perf_counter() - t0
+
+    def reprojection_filter(view_list, cam_p, cam_c, permanent):
+        """filterTracksWithReprojectionError: tracks seen by ALL the cameras are
+        re-triangulated from them and lose the features that reproject 1.5 px or more
+        away; a track left with fewer than two features goes.  Returns the features (in
+        track order) that the tracks seen by at least two of the cameras keep inside the
+        camera set -- what the bundle adjustment that follows works on."""
+        t0 = time.perf_counter()
+        n = len(view_list)
+        idx = tt.features_of_views(view_list)
+        if idx.size == 0:
+            return idx
+        tr = tt.track_of[idx]
+        uniq, first, cnt = np.unique(tr, return_index=True, return_counts=True)
+        cnt_f = cnt[np.searchsorted(uniq, tr)]
+        keep_f = np.ones(idx.shape[0], dtype=bool)
+        full_f = cnt_f == n
+        if full_f.any():
+            fi = idx[full_f]
+            ftr = tr[full_f]
+            fu = uniq[cnt == n]
+            cam_of = np.full(V, -1, dtype=np.int32)
+            cam_of[view_list] = np.arange(n, dtype=np.int32)
+            prob = _problem(model, cam_p, cam_c, W, H, tt.point[fu].copy(), tt.xy[fi], cam_of[tt.view[fi]],
+                            np.searchsorted(fu, ftr).astype(np.int32))
+            st = prob.struct()
+            ok = np.zeros(fi.shape[0], dtype=np.uint8)
+            capi.check(capi.lib.osfm_filter_reprojection(C.byref(st), device, C.c_double(MAX_REPROJECTION_ERROR),
+                                                         capi._ptr(ok, C.c_uint8), None, None))
+            keep_f[full_f] = ok.astype(bool)
+        # features a track keeps outside the camera set count towards "more than one left"
+        total = tt.alive_lengths()[uniq] - cnt + np.add.reduceat(keep_f.astype(np.int64), first)
+        track_ok = np.where(cnt == n, total > 1, True)              # only full-size tracks are judged (:147-149,187-189)
+        if permanent:
+            tt.alive_f[idx[~keep_f]] = False
+            tt.alive_t[uniq[~track_ok]] = False
+        inside = np.add.reduceat(keep_f.astype(np.int64), first)
+        sel = keep_f & (track_ok & (inside > 1))[np.searchsorted(uniq, tr)]
+        tm.local_filter_s += time.perf_counter() - t0
+        return idx[sel]
+
+    processed = 0
+    for g in groups:
+        processed += 1
+        ids = list(g.ids)
+        first_group = not aligned
+        # ---- calculateInitialAlignment (stand-in, see the module docstring) -------
+        lp = np.array([cams[v].copy() if is_aligned[v] else start_pose(v) for v in ids])
+        lc = np.array([default_const_mask(model, euler_dof=euler_dof) for _ in ids])
+        if first_group:
+            lc[0] = default_const_mask(model, fixed=True, euler_dof=euler_dof)          # localCameras[0]->setFixed(true), :215
+        # ---- filterTracksWithReprojectionError(localTracks, localCameras) + local BA on a
+        # filtered, re-triangulated copy (runBundleAdjustment(..., true, true), :212-219) ----
+        fsel = reprojection_filter(ids, lp, lc, permanent=False)
+        t0 = time.perf_counter()
+        tr = tt.track_of[fsel]
+        uniq = np.unique(tr)
+        cam_of = np.full(V, -1, dtype=np.int32)
+        cam_of[ids] = np.arange(len(ids), dtype=np.int32)
+        prob = _problem(model, lp, lc, W, H, np.tile([0.0, 0, 0, 1], (uniq.size, 1)), tt.xy[fsel],
+                        cam_of[tt.view[fsel]], np.searchsorted(uniq, tr).astype(np.int32))
+        tm.pose_host_s += time.perf_counter() - t0
+        s, dt = solve("local", prob, opt_local)
+        tm.local_ba_s += dt
+        lp = prob.cam_params
+        if first_group:
+            # normalizeScene is the identity here: camera 0 is canonical and fixed
+            for k, v in enumerate(ids):
+                cams[v] = lp[k]; const[v] = lc[k]
+                aligned.append(v); is_aligned[v] = True
+            triangulate_all()
+        else:
+            align_to_global(model, lp, [cams[v] if is_aligned[v] else None for v in ids])
+            for k, v in enumerate(ids):                             # mergeIntoGlobal: only the new cameras
+                if not is_aligned[v]:
+                    cams[v] = lp[k]; const[v] = default_const_mask(model, euler_dof=euler_dof)
+                    aligned.append(v); is_aligned[v] = True
+            triangulate_all()
+            if processed % GLOBAL_BA_INTERVAL == 0:
+                _global_ba(tt, model, cams, const, aligned, W, H, V, solve, "global", opt, tm)
+                # filterOutlierTracks + filterTracksWithReprojectionError (:264-265)
+                t0 = time.perf_counter()
+                at = np.nonzero(tt.alive_t)[0]
+                keep, _ = _outlier_flags(tt.point[at], tt.has_point[at], device)
+                tt.alive_t[at[~keep]] = False
+                tm.outlier_filter_s += time.perf_counter() - t0
+                if len(aligned) <= int(tt.alive_lengths().max(initial=0)):
+                    reprojection_filter(list(aligned), cams[aligned], const[aligned], permanent=True)
+        if verbose:
+            print(f"group {processed}/{len(groups)} {ids}: {len(aligned)} cameras, {tt.num_tracks} tracks, "
+                  f"{int(tt.has_point.sum())} points")
+    _global_ba(tt, model, cams, const, aligned, W, H, V, solve, "final", opt, tm)      # :281
+    tm.pose_s = time.perf_counter() - t_pose
+    return cams, aligned, groups, calls, captured
+
+
+def _outlier_flags(points, has_point, device):
+    from . import filters
+    return filters.outlier_track_flags(points, has_point, device)
+
+
+def _global_ba(tt, model, cams, const, aligned, W, H, V, solve, kind, opt, tm):
+    """runBundleAdjustment(alignedCameras, tracks, algorithm, true, false): every track
+    with a point is a parameter block, every feature of such a track whose view has a
+    camera a residual (bundle_adjustment.cpp:86-123); cameras and points updated in place."""
+    t0 = time.perf_counter()
+    cam_of = np.full(V, -1, dtype=np.int32)
+    cam_of[aligned] = np.arange(len(aligned), dtype=np.int32)
+    tsel = np.nonzero(tt.alive_t & tt.has_point)[0]
+    fsel = np.nonzero((cam_of[tt.view] >= 0) & tt.alive_f & (tt.alive_t & tt.has_point)[tt.track_of])[0]
+    prob = _problem(model, cams[aligned], const[aligned], W, H, tt.point[tsel], tt.xy[fsel], cam_of[tt.view[fsel]],
+                    np.searchsorted(tsel, tt.track_of[fsel]).astype(np.int32))
+    tm.pose_host_s += time.perf_counter() - t0
+    s, dt = solve(kind, prob, opt)
+    tm.global_ba_s += dt
+    t0 = time.perf_counter()
+    cams[aligned] = prob.cam_params
+    tt.point[tsel] = prob.points
+    tm.pose_host_s += time.perf_counter() - t0
+    return s
+
+
+def reconstruct(iset, solver=0, matcher="exhaustive", device=0, verify=True, rot_perturb_deg=2.0,
+                off_perturb=0.01, seed=7, capture=(), max_groups=None, verbose=False) -> Result:
+    """orthosfm::reconstruct from the views' descriptors on: one wall clock over matching,
+    track building, group ordering and the incremental pose estimation.
+    solver 0: quaternion cameras (ORTHO_QUATERNION); 1..3: Euler cameras with that many
+    free angle blocks (3 = ORTHO_EULER_ALL_DOF: phi, theta, roll and the offsets)."""
+    tm = Timings()
+    t_all = time.perf_counter()
+    tt, info = match_and_build_tracks(iset, matcher, device, verify, tm)
+    model = B.MODEL_QUATERNION if solver == 0 else B.MODEL_EULER
+    cams, aligned, groups, calls, captured = run_pose_estimation(
+        tt, iset, model, device, rot_perturb_deg, off_perturb, seed, tm, capture, max_groups, verbose,
+        euler_dof=euler_dof_of_solver(solver))
+    tm.total_s = time.perf_counter() - t_all
+    return Result(cams, aligned, tt, groups, tm, calls, captured=captured, **info)

@@ -427,7 +427,10 @@ def test_full_size_bit_parity_20k(hm):
         m.set_view(1, s2)
         got = m.pairwise_match(0, 1)
         assert np.array_equal(got.matches_1_2, c12) and np.array_equal(got.matches_2_1, c21), variant
-        assert int((c12 >= 0).sum()) > 5000
+        if variant == "plain":
+            assert int((c12 >= 0).sum()) > 5000
+        else:       # the over-long rows out-score the true partners of most queries: few matches survive
+            assert 0 < int((c12 >= 0).sum()) < 5000
         two = m.twoway_match(0, 1, 0)           # the pre-cross-check seam (masked kernel)
         assert np.array_equal(two.matches_1_2, e12) and np.array_equal(two.matches_2_1, e21), variant
     m.close()

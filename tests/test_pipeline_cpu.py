@@ -1,0 +1,87 @@
+"""Host logic of the end-to-end driver (orthosfm_amd/pipeline.py) that needs no GPU:
+the canonical ground-truth frame, the camera-model conversions, the alignment of a
+local camera triple to the global cameras and the track table."""
+import numpy as np
+import pytest
+
+from orthosfm_amd import ba as B
+from orthosfm_amd import pipeline as P
+from orthosfm_amd import synth
+
+
+@pytest.fixture(scope="module")
+def iset():
+    return synth.make_image_set(5, 300, config_id=61)
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_canonical_ground_truth_projects_onto_the_track_pixels(iset, model):
+    """Camera 0 is canonical (identity / zero angles) and every camera projects the
+    landmarks onto feature position + 0.5 px -- the pixel the converted tracks carry
+    (matching_mve.cpp:463)."""
+    gt, pts = P.canonical_ground_truth(iset, model)
+    if model == 0:
+        assert np.allclose(np.abs(gt[0, :4]), [0, 0, 0, 1], atol=1e-12)
+    else:
+        assert np.allclose(gt[0, :3], 0, atol=1e-12)
+    for v in range(iset.num_views):
+        lm = iset.landmark[v]
+        sel = lm >= 0
+        if model == 0:
+            xy = synth.project_quat(pts[lm[sel]], gt[v, :4], gt[v, 4], gt[v, 5], gt[v, 6], iset.width, iset.height)
+        else:
+            xy = synth.project_euler(pts[lm[sel]], gt[v, 0], gt[v, 1], gt[v, 2], gt[v, 3], gt[v, 4], gt[v, 5],
+                                     iset.width, iset.height)
+        assert np.abs(xy - (iset.pos[v][sel].astype(np.float64) + 0.5)).max() < 2e-3     # float32 positions
+
+
+def test_euler_angles_round_trip():
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        phi, theta, rho = rng.uniform(-3, 3), rng.uniform(-1.4, 1.4), rng.uniform(-3, 3)
+        S = synth.euler_matrix(phi, theta, rho)
+        a = P._euler_from_S(S)
+        assert np.allclose(synth.euler_matrix(*a), S, atol=1e-12)
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_align_to_global_undoes_a_frame_rotation(iset, model):
+    """Rotate the three local cameras by one common rotation (the gauge freedom of a local
+    bundle adjustment with all cameras free): aligning to the two shared global cameras
+    brings the third one back."""
+    gt, _ = P.canonical_ground_truth(iset, model)
+    glob = [gt[1].copy(), gt[2].copy(), None]
+    axis = np.array([0.3, -0.5, 0.8]); axis /= np.linalg.norm(axis)
+    ang = 0.2
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    Rot = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+    local = [gt[v].copy() for v in (1, 2, 3)]
+    for p in local:
+        P._set_cam_rotation(model, p, Rot @ P._cam_rotation(model, p))
+    P.align_to_global(model, local, glob)
+    assert np.allclose(P._cam_rotation(model, local[2]), P._cam_rotation(model, gt[3]), atol=1e-10)
+
+
+def test_track_table_indexing():
+    offs = np.array([0, 2, 5, 7])
+    view = np.array([0, 2, 1, 2, 3, 0, 3])
+    feat = np.array([5, 1, 2, 0, 4, 6, 3])
+    tt = P.TrackTable(offs, view, feat, np.zeros((7, 2)), 4)
+    assert tt.track_of.tolist() == [0, 0, 1, 1, 1, 2, 2]
+    assert tt.features_of_views([2, 3]).tolist() == [1, 3, 4, 6]
+    tt.alive_f[3] = False
+    assert tt.features_of_views([2, 3]).tolist() == [1, 4, 6]
+    tt.alive_t[2] = False
+    assert tt.features_of_views([0, 3]).tolist() == [0, 4]
+    assert tt.alive_lengths().tolist() == [2, 2, 0] and tt.num_tracks == 2
+    norm = [np.array([[0.1, -0.2]] * 7, np.float32)] * 4
+    t2 = P.TrackTable.from_mve(offs, np.stack([view, feat], 1), norm, 100, 4)
+    assert np.allclose(t2.xy[0], [np.float32(100 * (np.float64(np.float32(0.1)) + 0.5)),
+                                  np.float32(100 * (np.float64(np.float32(-0.2)) + 0.5))])
+
+
+def test_const_masks_follow_the_solver():
+    assert P.default_const_mask(B.MODEL_QUATERNION).tolist() == [0, 0, 0, 0, 0, 0, 1]
+    assert P.default_const_mask(B.MODEL_EULER, euler_dof=P.euler_dof_of_solver(3)).tolist() == [0, 0, 0, 0, 0, 1, 1]
+    assert P.default_const_mask(B.MODEL_EULER, euler_dof=P.euler_dof_of_solver(1)).tolist() == [0, 1, 1, 1, 1, 1, 1]
+    assert P.default_const_mask(B.MODEL_EULER, fixed=True).all()
