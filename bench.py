@@ -1,25 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X backend (driver contract).
 
-One "step" = one pass of the hot path over one synthetic image set:
-  * matching: exhaustive pairwise matching (low-res gate, two-way SIFT match,
-    cross-check, thresholds, ordered correspondence lists) of ALL V(V-1)/2
-    pairs of a V-image set with ~20k SIFT features per image, descriptors
-    resident in HBM (BASELINE.json configs[1]: 50 images on 1 GPU);
-  * bundle adjustment (reported beside it): LM iterations/s of the global BA
-    of configs[3] (200 quaternion cameras, 100k tracks) -- see `ba` in the
-    JSON line.
-`value` = image pairs matched per second over all ranks (pairs are sharded
-across ranks with no data-path collective; the match lists reach rank 0 at the
-end of every step, inside the timed region: on one node every rank's lists go
-straight into its slice of a shared page-locked host segment and only the
-per-pair counts are all-gathered over RCCL -- `--exchange rccl` gathers the
-lists themselves over xGMI instead, as a multi-node run would).
+One "step" = one pass of the hot path over one synthetic image set: exhaustive
+pairwise matching (low-res gate, two-way SIFT match, cross-check, thresholds,
+ordered correspondence lists -- SURVEY 8d's unit of work, i.e. up to, not including,
+RANSAC-F) of ALL V(V-1)/2 pairs of a V-image set with ~20k SIFT features per image,
+descriptors resident in HBM.
+
+  N = 1   BASELINE.json configs[1]: 50 images (1225 pairs) on one GPU.
+  N > 1   BASELINE.json configs[2]: 200 images (19,900 pairs) held FIXED and sharded
+          across the ranks by work (strong scaling); `--weak` grows the set instead so
+          that every rank keeps ~1225 pairs.
+
+`value` = image pairs matched per second over all ranks.  Pairs are dealt to the ranks
+up front (no data-path collective); the match lists reach rank 0 at the end of every
+step, inside the timed region: on one node every rank's lists go straight into its slice
+of a shared page-locked host segment and only the per-pair counts are all-gathered over
+RCCL -- `--exchange rccl` gathers the lists themselves over xGMI instead, as a
+multi-node run would.
+
+Reported beside it on rank 0 at N = 1 (each with the CPU path timed on the host cores):
+the same pass through RANSAC-F, a variant whose gates reject pairs and matches, the
+cascade-hashing mode, track building, the per-pair latency of the drop-in interface,
+the global bundle adjustment of configs[3] with its roofline, the 200-image matching
+run on one GPU, and the end-to-end job (match -> tracks -> groups -> incremental
+bundle adjustment) on the 200-image set.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -30,7 +41,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-
 
 
 def usable_cores():
@@ -55,6 +65,7 @@ os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))
 
 I8_MFMA_PEAK_TOPS = 5000.0      # dense int8 MFMA, MI355X_MICROARCH.md (2x the 2.5 PF bf16 figure)
 HBM_PEAK_GBS = 8000.0
+METRIC = "image-pairs matched/sec + BA iterations/sec (N images, M tracks) at 1/2/4/8 GPU"
 
 
 def parse():
@@ -62,11 +73,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--views", type=int, default=0, help="0 = 50 at N=1, grown with N so pairs per GPU stay ~1225")
+    ap.add_argument("--views", type=int, default=0, help="0 = 50 at N=1 (configs[1]), 200 at N>1 (configs[2])")
     ap.add_argument("--features", type=int, default=20000)
+    ap.add_argument("--weak", action="store_true", help="N>1: grow the image set so that every rank keeps ~1225 pairs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
-    ap.add_argument("--no-verify", action="store_true", help="skip the extra pass with RANSAC-F")
+    ap.add_argument("--no-verify", action="store_true", help="skip the extra passes with RANSAC-F")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the 200-image matching run and the end-to-end job")
+    ap.add_argument("--e2e-views", type=int, default=200)
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = auto (about 15 s of CPU work)")
     ap.add_argument("--no-lowres-gate", action="store_true",
                     help="kernel experiments only: match every pair in full whatever the results are")
@@ -74,6 +88,11 @@ def parse():
     ap.add_argument("--exchange", default="shm", choices=["shm", "rccl"],
                     help="how the match lists reach rank 0 for N > 1: shared host segment (one node) or RCCL gather")
     return ap.parse_args()
+
+
+def normalised_positions(iset, v):
+    """normalize_feature_positions (feature_set.cc:42-55)."""
+    return ((iset.pos[v] + 0.5 - np.array([iset.width / 2, iset.height / 2])) / max(iset.width, iset.height)).astype(np.float32)
 
 
 def exchanged_tracks(gathered, all_pairs, V, F, how):
@@ -97,9 +116,11 @@ def exchanged_tracks(gathered, all_pairs, V, F, how):
             "invalid_tracks": int(res[4].num_invalid_tracks), "track_building_ms": ms}
 
 
-def cpu_baseline(iset, pairs, n_sample):
-    """Times the CPU oracle (bit-exact restatement of the reference matcher,
-    OpenMP over queries) on a bounded sample of the same workload."""
+def cpu_baseline(iset, pairs, n_sample, gpu_lists):
+    """Times the CPU oracle (bit-exact restatement of the reference matcher, OpenMP over
+    queries) on a bounded sample of the same workload -- and checks what was timed: the
+    oracle's cross-checked lists of every sampled full-size pair are compared with the
+    lists the GPU pass produced for the same pairs."""
     import oracle_lib
     threads = oracle_lib.oracle().oracle_num_threads()
     empty = np.zeros((0, 64), np.int16)
@@ -111,26 +132,45 @@ def cpu_baseline(iset, pairs, n_sample):
     est_pair = t_quarter * 16.0
     if n_sample <= 0:
         n_sample = int(max(1, min(len(pairs), round(15.0 / max(est_pair, 1e-3)))))
+    # spread the sample over the pair list (not only its first views)
+    sample = sorted({int(i) for i in np.linspace(0, len(pairs) - 1, n_sample)})
     t0 = time.perf_counter()
-    for (a, b) in pairs[:n_sample]:
-        oracle_lib.oracle_pairwise_match(iset.sift[a], empty, iset.sift[b], empty)
+    results = []
+    for i in sample:
+        a, b = pairs[i]
+        results.append(oracle_lib.oracle_pairwise_match(iset.sift[a], empty, iset.sift[b], empty))
     dt = time.perf_counter() - t0
-    return {"value": n_sample / dt, "unit": "pairs/s", "cores": int(threads), "kind": "port",
-            "sample": f"{n_sample} full-size pairs ({iset.sift[0].shape[0]} x {iset.sift[0].shape[0]} SIFT, "
-                      f"two-way + cross-check) of the same image set, {dt:.1f} s"}
+    checked, bad = 0, []
+    for i, (e12, _) in zip(sample, results):
+        if gpu_lists is None or gpu_lists[i] is None:
+            continue
+        idx = np.nonzero(e12 >= 0)[0]
+        exp = np.stack([idx, e12[idx]], axis=1).astype(np.int32)
+        checked += 1
+        if not np.array_equal(np.asarray(gpu_lists[i]), exp):
+            bad.append(i)
+    base = {"value": len(sample) / dt, "unit": "pairs/s", "cores": int(threads), "kind": "port",
+            "sample": f"{len(sample)} full-size pairs ({iset.sift[0].shape[0]} x {iset.sift[0].shape[0]} SIFT, "
+                      f"two-way + cross-check) spread over the same image set, {dt:.1f} s"}
+    return base, checked, bad
+
+
+def newest_profile(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return files[-1] if files else None
 
 
 def pmc_traffic_per_launch(pairs_per_launch):
-    """HBM bytes of one launch of the dominant kernel from the committed PMC
-    passes (profiles/r01_match_traffic_pmc.json: FETCH_SIZE and WRITE_SIZE
-    collected in separate rocprofv3 --pmc runs of this same command, FETCH_SIZE
-    doubled as the gfx950 guide prescribes), scaled to the pairs per launch."""
-    path = os.path.join(ROOT, "profiles", "r01_match_traffic_pmc.json")
+    """HBM bytes of one launch of the dominant kernel from the committed PMC passes
+    (profiles/r*_match_traffic_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate
+    rocprofv3 --pmc runs of this same command, FETCH_SIZE doubled as the gfx950 guide
+    prescribes), scaled to the pairs per launch."""
+    path = newest_profile("r*_match_traffic_pmc.json")
     try:
         rec = json.load(open(path))
-        return rec["hbm_bytes_per_pair"] * pairs_per_launch
+        return rec["hbm_bytes_per_pair"] * pairs_per_launch, os.path.basename(path)
     except Exception:
-        return None
+        return None, None
 
 
 def ba_cpu_baseline(iterations=2):
@@ -149,12 +189,26 @@ def ba_cpu_baseline(iterations=2):
                       "(residual/Jacobian evaluation and the dense Cholesky trailing updates OpenMP-parallel, Schur accumulation serial)"}
 
 
+def ba_roofline(ba):
+    """Q_B = 2*24*O + 96*M + 2*8*(dC)^2 algorithmic bytes per LM iteration
+    (observations read for linearisation and trial cost, points read twice and written,
+    dense reduced system written and read) against the HBM peak."""
+    O, M, nc = ba["observations"], ba["points"], ba["camera_unknowns"]
+    q = 2 * 24 * O + 96 * M + 2 * 8 * nc * nc
+    its = ba["lm_loop_iterations_per_s"]
+    ach = q * its / 1e9
+    return {"bound": "hbm (a latency chain in practice: see kernel_ms)", "algorithmic_bytes_per_iteration": q,
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "iterations_per_s": its}
+
+
 def cascade_bench(iset, V, pairs, capacity, device_index, with_cpu):
     """The same pairs through the cascade-hashing mode (sfm::CascadeHashing, the
     application's default, approximate matcher).  CPU baseline: the reference's
     own cascade_hashing.cc when oracle/_ref travelled (its pairwise_match on a
     sample of pairs, all host threads via its OpenMP init, matching single
     threaded per pair as in one iteration of bundler::Matching::compute's loop)."""
+    from orthosfm_amd import capi
     from orthosfm_amd.matching import HipCascadeHashing
     m = HipCascadeHashing(V, device=device_index, copy_results=False)
     for v in range(V):
@@ -170,7 +224,7 @@ def cascade_bench(iset, V, pairs, capacity, device_index, with_cpu):
     res = {"workload": f"{len(pairs)} pairs, cascade hashing (6 bucket groups x 256 buckets, 6..10 candidates)",
            "pairs_per_s": len(pairs) / dt, "ms_per_step": dt * 1e3, "hash_init_ms": init_s * 1e3,
            "kernel_ms": st.cashash_kernel_ms,
-           "correspondences": int(sum(tv.num_matches for tv in out if tv.status == capi_mod().PAIR_MATCHED))}
+           "correspondences": int(sum(tv.num_matches for tv in out if tv.status == capi.PAIR_MATCHED))}
     m.close()
     if with_cpu:
         import oracle_lib
@@ -192,11 +246,6 @@ def cascade_bench(iset, V, pairs, capacity, device_index, with_cpu):
     return res
 
 
-def capi_mod():
-    from orthosfm_amd import capi
-    return capi
-
-
 def tracks_bench(out, V, F, with_cpu):
     """Tracks::compute (bundler_tracks.cc:49-145) over the match lists this run
     produced: host code in the reference and here; the CPU baseline is the
@@ -211,7 +260,7 @@ def tracks_bench(out, V, F, with_cpu):
     dt = time.perf_counter() - t0
     res = {"workload": f"Tracks::compute over {len(matched)} pairs / {int(offsets[-1])} matches (host code)",
            "ms": dt * 1e3, "tracks": int(summary.num_tracks), "invalid_tracks": int(summary.num_invalid_tracks),
-           "track_features": int(summary.num_features)}
+           "track_features": int(summary.num_features), "matches": int(offsets[-1])}
     if with_cpu:
         import oracle_lib
         parr = np.array([(tv.view_1_id, tv.view_2_id) for tv in matched], dtype=np.int32).reshape(-1, 2)
@@ -251,6 +300,184 @@ def outlier_filter_bench(device, with_cpu):
     return out
 
 
+def gated_bench(V, F, device_index):
+    """The gates at work (the headline set matches every pair and every surviving match is
+    an inlier): the same 50-view shape with repeated structure -- a third of the landmarks
+    are twins with one descriptor at two 3-D positions, whose cross-view matches pass ratio
+    test and cross-check and are geometrically wrong -- and four views of another scene,
+    whose pairs with the rest fall at the low-res gate."""
+    from orthosfm_amd import capi, synth
+    from orthosfm_amd.matching import HipExhaustiveMatching
+    iset = synth.make_image_set(V, F, config_id=2, twin_frac=0.35, unrelated_views=4)
+    o = capi.default_match_options()
+    o.geometric_verification = 1
+    m = HipExhaustiveMatching(V, device=device_index, options=o, copy_results=False)
+    for v in range(V):
+        m.set_view(v, iset.sift[v])
+        m.set_positions(v, normalised_positions(iset, v))
+    pairs = [capi.pair_from_index(i) for i in range(V * (V - 1) // 2)]
+    cap = F * len(pairs)
+    m.compute(pairs, capacity=cap)
+    t0 = time.perf_counter()
+    out = m.compute(pairs, capacity=cap)
+    dt = time.perf_counter() - t0
+    st = np.array([tv.status for tv in out])
+    matched = [tv for tv in out if tv.status == capi.PAIR_MATCHED]
+    pre = int(sum(tv.num_matches for tv in matched))
+    inl = int(sum(tv.num_inliers for tv in matched))
+    # how many of the kept correspondences join features of the same landmark
+    good = tot = 0
+    for tv in matched[:200]:
+        la = iset.landmark[tv.view_1_id][tv.matches[:, 0]]
+        lb = iset.landmark[tv.view_2_id][tv.matches[:, 1]]
+        good += int(((la == lb) & (la >= 0)).sum()); tot += tv.matches.shape[0]
+    m.close()
+    return {"workload": f"{V} views x {F} features, 35% twin landmarks, 4 views of another scene, RANSAC-F on",
+            "pairs_per_s": len(pairs) / dt, "ms_per_step": dt * 1e3,
+            "pairs": {"matched": int((st == capi.PAIR_MATCHED).sum()),
+                      "rejected_lowres": int((st == capi.PAIR_REJECTED_LOWRES).sum()),
+                      "rejected_count": int((st == capi.PAIR_REJECTED_COUNT).sum()),
+                      "rejected_inliers": int((st == capi.PAIR_REJECTED_INLIERS).sum())},
+            "mutual_matches_of_matched_pairs": pre, "ransac_inliers": inl,
+            "outlier_share_removed_by_ransac": 1.0 - inl / max(pre, 1),
+            "inliers_on_the_same_landmark": good / max(tot, 1)}
+
+
+def per_pair_latency(m, pairs, n=24):
+    """The drop-in interface as the reference calls it: one MatchingBase::pairwise_match
+    per pair (osfm_match_pair: launch, finish, cross-check, two device-to-host copies,
+    one synchronisation each), next to the batched osfm_match_all rate."""
+    sel = [pairs[i] for i in np.linspace(0, len(pairs) - 1, n).astype(int)]
+    m.pairwise_match(*sel[0])
+    t0 = time.perf_counter()
+    for a, b in sel:
+        m.pairwise_match(a, b)
+    dt = (time.perf_counter() - t0) / len(sel)
+    t0 = time.perf_counter()
+    for a, b in sel:
+        m.pairwise_match_lowres(a, b, 500)
+    dl = (time.perf_counter() - t0) / len(sel)
+    return {"interface": "MatchingBase::pairwise_match / pairwise_match_lowres, one call per pair (through ctypes)",
+            "pairwise_match_ms": dt * 1e3, "pairwise_match_lowres_ms": dl * 1e3, "pairs_per_s": 1.0 / (dt + dl),
+            "sample": f"{len(sel)} pairs of 20k x 20k features"}
+
+
+def schedule_kinds(num_views):
+    """The bundle-adjustment calls runPoseEstimation issues for V views (reconstruct.cpp:193-281)."""
+    kinds = []
+    for g in range(1, num_views - 1):
+        kinds.append("local")
+        if g > 1 and g % 3 == 0:
+            kinds.append("global")
+    kinds.append("final")
+    return kinds
+
+
+def end_to_end_bench(args, device_index, cpu_pairs_per_s, cpu_ransac_s_per_pair, tracks_cpu_ms_per_match, cores):
+    """BASELINE configs[2]'s image set on ONE GPU: (a) the matching pass alone (the N = 1
+    point of the strong-scaling config), (b) the whole job -- match + RANSAC-F, tracks,
+    group ordering, incremental bundle adjustment with the reference's schedule -- as one
+    wall clock, with the CPU path beside it: the pinned matcher oracle and the RANSAC
+    oracle sampled and extrapolated over the pairs, the reference's Tracks::compute
+    scaled by matches, the BA oracle on sampled calls of the same schedule scaled by
+    iterations x observations (SURVEY 8d allows sampling: the work per pair is
+    data-independent)."""
+    from orthosfm_amd import capi, pipeline as P, synth
+    from orthosfm_amd.matching import HipExhaustiveMatching
+    V, F = args.e2e_views, args.features
+    t0 = time.perf_counter()
+    iset = synth.make_image_set(V, F, config_id=3)
+    gen_s = time.perf_counter() - t0
+    pairs = [capi.pair_from_index(i) for i in range(V * (V - 1) // 2)]
+    out = {"workload": f"{V} orthographic images, {F} SIFT features/img, {len(pairs)} pairs", "generate_s": gen_s}
+    # (a) matching only, as the headline pass
+    m = HipExhaustiveMatching(V, device=device_index, copy_results=False)
+    t0 = time.perf_counter()
+    for v in range(V):
+        m.set_view(v, iset.sift[v])
+    up = time.perf_counter() - t0
+    cap = F * len(pairs)
+    m.compute(pairs, capacity=cap)
+    t0 = time.perf_counter()
+    res = m.compute(pairs, capacity=cap)
+    dt = time.perf_counter() - t0
+    st = m.stats()
+    out["matching_single_gpu"] = {"pairs_per_s": len(pairs) / dt, "s_per_pass": dt, "upload_s": up,
+                                  "tile_kernel_ms": st.tile_kernel_ms, "tile_kernel_launches": int(st.tile_kernel_launches),
+                                  "matched_pairs": int(sum(1 for tv in res if tv.status == capi.PAIR_MATCHED)),
+                                  "correspondences": int(sum(tv.num_matches for tv in res if tv.status == capi.PAIR_MATCHED))}
+    m.close()
+    del res
+    # (b) the whole job
+    kinds = schedule_kinds(V)
+    loc = [i for i, k in enumerate(kinds) if k == "local"]
+    glo = [i for i, k in enumerate(kinds) if k == "global"]
+    capture = set()
+    if not args.no_cpu_baseline:
+        capture = {loc[len(loc) // 4], loc[len(loc) // 2], loc[-1]}
+        if glo:
+            capture |= {glo[len(glo) // 3], glo[-1]}
+    r = P.reconstruct(iset, solver=0, device=device_index, capture=capture)
+    tm = r.timings
+    gpu_total = tm.total_s
+    calls = r.ba_calls
+    job = {"gpu_wall_s": gpu_total,
+           "stages_s": {"descriptor_upload": tm.upload_s, "matching_with_ransac": tm.matching_s, "tracks": tm.tracks_s,
+                        "track_conversion": tm.convert_s, "group_ordering": tm.groups_s,
+                        "pose_estimation": tm.pose_s,
+                        "pose_parts": {"local_ba": tm.local_ba_s, "reprojection_filter": tm.local_filter_s,
+                                       "triangulate_all_tracks": tm.triangulate_s, "global_ba": tm.global_ba_s,
+                                       "outlier_filter": tm.outlier_filter_s, "host_flattening": tm.pose_host_s}},
+           "matched_pairs": r.matched_pairs, "correspondences_after_ransac": r.correspondences,
+           "tracks": r.num_mve_tracks, "invalid_tracks": r.invalid_mve_tracks, "groups": len(r.groups),
+           "cameras": len(r.aligned_views), "tracks_after_filters": r.tracks.num_tracks,
+           "ba_calls": {k: {"n": sum(1 for c in calls if c.kind == k), "iterations": sum(c.iterations for c in calls if c.kind == k),
+                            "ms": sum(c.ms for c in calls if c.kind == k)} for k in ("local", "global", "final")},
+           "schedule": "local 3-camera BA per group, global BA every 3rd group, final BA (reconstruct.cpp:193-281); "
+                       "new cameras start from the ground truth perturbed by 2 deg / 0.01 (Tomasi-Kanade is out of scope)"}
+    gt, _ = P.canonical_ground_truth(iset, 0)
+    ang = []
+    for v in r.aligned_views:
+        Rg, Rc = P._cam_rotation(0, gt[v]), P._cam_rotation(0, r.cam_params[v])
+        ang.append(float(np.degrees(np.arccos(np.clip((np.trace(Rg.T @ Rc) - 1) / 2, -1, 1)))))
+    job["max_rotation_error_deg"] = max(ang)
+    if not args.no_cpu_baseline and cpu_pairs_per_s:
+        import oracle_lib
+        # BA schedule on the CPU oracle: sampled calls, scaled by iterations x observations
+        rate = {"local": [], "global": []}
+        ba_ok = True
+        for ci, (kind, prob, retri) in sorted(r.captured.items()):
+            sc = synth.BaScene(prob.model, prob.cam_params.copy(), prob.cam_const.copy(), prob.img_w.copy(), prob.img_h.copy(),
+                               prob.points.copy(), prob.obs_xy.copy(), prob.obs_camera.copy(), prob.obs_point.copy(),
+                               prob.cam_params.copy(), prob.points[:, :3].copy())
+            t0 = time.perf_counter()
+            if retri:
+                oracle_lib.oracle_ba_triangulate(sc)
+            so = oracle_lib.oracle_ba_solve(sc)
+            dtc = time.perf_counter() - t0
+            rate[kind].append(dtc / max(1, max(so.num_iterations, 1) * prob.obs_camera.shape[0]))
+            ba_ok &= so.num_iterations == calls[ci].iterations
+        cpu_ba = 0.0
+        for c in calls:
+            k = "local" if c.kind == "local" else "global"
+            if rate[k]:
+                cpu_ba += float(np.mean(rate[k])) * max(c.iterations, 1) * c.observations
+        cpu_match = len(pairs) / cpu_pairs_per_s
+        cpu_ransac = cpu_ransac_s_per_pair * len(pairs) / max(cores, 1)
+        cpu_tracks = tracks_cpu_ms_per_match * r.correspondences * 1e-3
+        cpu_total = cpu_match + cpu_ransac + cpu_tracks + cpu_ba
+        job["cpu_baseline"] = {"value": cpu_total, "unit": "s (extrapolated)", "cores": int(cores), "kind": "port",
+                               "parts_s": {"matching": cpu_match, "ransac": cpu_ransac, "tracks": cpu_tracks, "bundle_adjustment": cpu_ba},
+                               "sample": f"matching: the headline's sampled oracle rate x {len(pairs)} pairs; RANSAC-F: oracle on sampled "
+                                         f"pairs, one thread each, spread over {cores} cores; tracks: the reference's code scaled by matches; "
+                                         f"BA: the oracle on {len(r.captured)} calls of the same schedule scaled by iterations x observations "
+                                         "(group ordering and the filters are NOT counted on the CPU side)",
+                               "ba_iteration_counts_equal_gpu": bool(ba_ok)}
+        job["speedup_vs_cpu"] = cpu_total / gpu_total
+    out["end_to_end"] = job
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -279,17 +506,27 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    # weak scaling: the image set grows with the rank count so that every
-    # GPU keeps ~1225 pairs (50 views -> 1225; 71 -> 2485; 100 -> 4950; 141 -> 9870)
+    # N = 1: configs[1] (50 views).  N > 1: configs[2], 200 views held fixed (strong
+    # scaling); --weak grows the set instead (50 / 71 / 100 / 141 views: ~1225 pairs per rank)
     V = args.views
+    scaling = "strong"
+    config_id = 2
     if V <= 0:
-        V = 50
-        while V * (V - 1) // 2 < 1225 * world:
-            V += 1
+        if world == 1:
+            V = 50
+        elif args.weak:
+            scaling = "weak"
+            V = 50
+            while V * (V - 1) // 2 < 1225 * world:
+                V += 1
+        else:
+            V, config_id = 200, 3
     F = args.features
-    iset = synth.make_image_set(V, F, config_id=2)
+    iset = synth.make_image_set(V, F, config_id=config_id)
     all_pairs = [capi.pair_from_index(i) for i in range(V * (V - 1) // 2)]
-    my_pairs = D.shard_pairs(all_pairs, rank, world)
+    view_sizes = np.array([iset.sift[v].shape[0] for v in range(V)])
+    shards = D.deal_pairs(all_pairs, view_sizes, world)
+    my_pairs = [all_pairs[i] for i in shards[rank]]
 
     o1 = capi.default_match_options()
     if args.no_lowres_gate:
@@ -312,7 +549,7 @@ def main():
     if world > 1 and args.exchange == "shm":
         # the matcher writes its lists into this rank's slice of the shared segment
         try:
-            store = D.SharedMatchStore(F * len(range(0, len(all_pairs), world)), rank, world, tdev)   # same on every rank
+            store = D.SharedMatchStore(F * max(len(s) for s in shards), rank, world, tdev)   # same on every rank
             m.use_result_buffer(store.slice)
         except D.SharedSegmentUnavailable:
             args.exchange = "rccl"
@@ -329,9 +566,9 @@ def main():
         # the only collective of the path: the match lists travel to rank 0
         # (pair order restored there) for RANSAC / track building
         if store is not None:
-            gathered[0] = store.collect(counts, len(all_pairs))
+            gathered[0] = store.collect(counts, len(all_pairs), shards)
         elif world > 1:
-            gathered[0] = D.gather_match_lists(counts, m.last_flat, len(all_pairs), rank, world, device=tdev)
+            gathered[0] = D.gather_match_lists(counts, m.last_flat, len(all_pairs), rank, world, device=tdev, shards=shards)
         return out, st, n_corr
 
     for _ in range(args.warmup):
@@ -348,18 +585,35 @@ def main():
     dt = time.perf_counter() - t0
     dt = D.max_over_ranks(dt, world, device=tdev)
     total_pairs = len(all_pairs)
+    extras = rank == 0 and world == 1
+
+    # the sampled CPU baseline, checked against the lists of the timed pass (rank 0's pairs)
+    cpu_base, parity_checked, parity_bad = None, 0, []
+    if rank == 0 and not args.no_cpu_baseline:
+        gpu_lists = [None] * len(all_pairs)
+        for gi, tv in zip(shards[0], out):
+            if tv.status == capi.PAIR_MATCHED:
+                gpu_lists[int(gi)] = tv.matches
+        cpu_base, parity_checked, parity_bad = cpu_baseline(iset, all_pairs, args.cpu_sample_pairs, gpu_lists)
+
+    latency = None
+    if extras and not args.no_ba:
+        try:
+            latency = per_pair_latency(m, my_pairs)
+        except Exception as e:
+            latency = {"error": str(e)}
 
     # the same pass continued through geometric verification (RANSAC-F,
     # bundler_matching.cc:194-219), reported beside the headline number
     verified = None
+    ransac_cpu_s_per_pair = 0.0
     if not args.no_verify:
         o2 = capi.default_match_options()
         o2.geometric_verification = 1
         m2 = HipExhaustiveMatching(V, device=device_index, options=o2, copy_results=False)
         for v in range(V):
             m2.set_view(v, iset.sift[v])
-            xy = (iset.pos[v] + 0.5 - np.array([iset.width / 2, iset.height / 2])) / max(iset.width, iset.height)
-            m2.set_positions(v, xy.astype(np.float32))
+            m2.set_positions(v, normalised_positions(iset, v))
         m2.compute(my_pairs, capacity=capacity)
         barrier()
         t1 = time.perf_counter()
@@ -367,13 +621,41 @@ def main():
         barrier()
         dtv = D.max_over_ranks(time.perf_counter() - t1, world, device=tdev)
         verified = {"pairs_per_s": len(all_pairs) / dtv, "ms_per_step": dtv * 1e3,
-                    "ransac": "1000 iterations, threshold 0.0015, >= 30 inliers",
+                    "ransac": "1000 iterations, threshold 0.0015, >= 30 inliers; the sampler is a counter-based stream "
+                              "(the reference's shared std::rand is not reproducible): inlier sets are parity-unpinned "
+                              "against the reference, bit-identical to the oracle",
                     "accepted_pairs_rank0": int(sum(1 for tv in outv if tv.status == capi.PAIR_MATCHED)),
                     "inliers_rank0": int(sum(tv.num_inliers for tv in outv if tv.status == capi.PAIR_MATCHED))}
+        if extras and not args.no_cpu_baseline:
+            # RANSAC-F on the CPU oracle for a few pairs of the timed pass (and the same inliers)
+            import oracle_lib
+            ts, same = [], True
+            for k in np.linspace(0, len(out) - 1, 4).astype(int):
+                tv, tw = out[k], outv[k]
+                if tv.status != capi.PAIR_MATCHED:
+                    continue
+                a, b = tv.view_1_id, tv.view_2_id
+                pid = a * (a - 1) // 2 + b
+                t1 = time.perf_counter()
+                n, inl, _ = oracle_lib.oracle_ransac(normalised_positions(iset, a), normalised_positions(iset, b),
+                                                     np.asarray(tv.matches), pair_id=pid)
+                ts.append(time.perf_counter() - t1)
+                same &= tw.status == capi.PAIR_MATCHED and np.array_equal(np.asarray(tv.matches)[inl], np.asarray(tw.matches))
+            if ts:
+                ransac_cpu_s_per_pair = float(np.mean(ts))
+                verified["cpu_baseline"] = {"value": ransac_cpu_s_per_pair * 1e3, "unit": "ms per pair (RANSAC-F alone)", "cores": 1,
+                                            "kind": "port", "sample": f"{len(ts)} pairs of the timed pass", "identical_inliers": bool(same)}
         m2.close()
 
+    gated = None
+    if extras and not args.no_verify and not args.no_ba:
+        try:
+            gated = gated_bench(V, F, device_index)
+        except Exception as e:
+            gated = {"error": str(e)}
+
     cascade = None
-    if rank == 0 and world == 1 and not args.no_ba and not args.no_verify:
+    if extras and not args.no_ba and not args.no_verify:
         try:
             cascade = cascade_bench(iset, V, my_pairs, capacity, device_index, not args.no_cpu_baseline)
         except Exception as e:
@@ -385,7 +667,7 @@ def main():
         exchanged = exchanged_tracks(gathered[0], all_pairs, V, F, args.exchange)
 
     tracks = None
-    if rank == 0 and world == 1 and not args.no_ba:
+    if extras and not args.no_ba:
         try:
             tracks = tracks_bench(out, V, F, not args.no_cpu_baseline)
         except Exception as e:
@@ -396,6 +678,7 @@ def main():
         try:
             from orthosfm_amd import ba as ba_mod
             ba = ba_mod.bench_global_ba()
+            ba["roofline"] = ba_roofline(ba)
         except Exception as e:       # BA reporting must never hide the matching line
             ba = {"error": str(e)}
 
@@ -408,6 +691,18 @@ def main():
         except Exception as e:
             ba["outlier_filter"] = {"error": str(e)}
 
+    m.close()
+    e2e = None
+    if extras and not args.no_e2e and not args.no_ba:
+        try:
+            tr_rate = 0.0
+            if tracks and "cpu_baseline" in tracks:
+                tr_rate = tracks["cpu_baseline"]["value"] / max(tracks["matches"], 1)
+            e2e = end_to_end_bench(args, device_index, cpu_base["value"] if cpu_base else 0.0, ransac_cpu_s_per_pair,
+                                   tr_rate, usable_cores())
+        except Exception as e:
+            e2e = {"error": repr(e)}
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = total_pairs * args.steps / dt
@@ -415,27 +710,41 @@ def main():
         avg_launch_s = kern_ms / max(kern_launches, 1) * 1e-3
         achieved = flops_per_launch / max(avg_launch_s, 1e-12) / 1e12
         statuses = [tv.status for tv in out]
+        traffic, traffic_src = pmc_traffic_per_launch(len(my_pairs) * args.steps / max(kern_launches, 1))
         line = {
-            "metric": "image-pairs matched/sec + BA iterations/sec (N images, M tracks) at 1/2/4/8 GPU",
+            "metric": METRIC,
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "i8",
+            "scaling": scaling, "vs_baseline": None, "dtype": "i8",
             "data": "synthetic",
             "config": {"workload": f"{V} orthographic images, {F} SIFT features/img, exhaustive matching "
-                                   f"({total_pairs} pairs, low-res gate + two-way + cross-check + lists)",
+                                   f"({total_pairs} pairs, low-res gate + two-way + cross-check + lists; "
+                                   "SURVEY 8d's unit of work: up to, not including, RANSAC-F -- the pass through "
+                                   "RANSAC-F is `with_geometric_verification`)",
                        "views": V, "features_per_view": F, "pairs": total_pairs,
-                       "sharding": f"pairs round-robin over {world} rank(s)"},
+                       "baseline_config": "configs[1]" if world == 1 else ("configs[2]" if scaling == "strong" else "configs[1] grown (weak)"),
+                       "sharding": f"pairs dealt by work (N1*N2, longest first) over {world} rank(s); "
+                                   f"{'the image set is the same at every N > 1' if scaling == 'strong' else 'the image set grows with N'}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_MFMA_PEAK_TOPS,
                          "unit": "TFLOP/s", "frac": achieved / I8_MFMA_PEAK_TOPS,
-                         "traffic": pmc_traffic_per_launch(len(my_pairs) * args.steps / max(kern_launches, 1)),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "match_tile_kernel<8, false, true, true>", "launches_per_step": kern_launches / args.steps,
                          "avg_launch_ms": avg_launch_s * 1e3,
+                         "algorithmic_bytes_per_launch": st.algorithmic_bytes / max(st.tile_kernel_launches, 1),
                          "hbm_algorithmic_GBs": (st.algorithmic_bytes / max(st.tile_kernel_launches, 1))
                                                 / max(avg_launch_s, 1e-12) / 1e9},
             "matched_pairs_rank0": int(sum(1 for s in statuses if s == capi.PAIR_MATCHED)),
             "correspondences_rank0": int(n_corr),
             "upload_s": upload_s,
         }
+        if world > 1:
+            line["multi_gpu_note"] = "every rank holds the full descriptor bank; no data-path collective; exchange = " + args.exchange
+        if cpu_base is not None:
+            line["cpu_baseline"] = cpu_base
+            line["parity_checked_pairs"] = parity_checked
+            line["parity_ok"] = len(parity_bad) == 0
+        if latency is not None:
+            line["drop_in_per_pair"] = latency
         if tracks is not None:
             line["tracks"] = tracks
         if exchanged is not None:
@@ -444,12 +753,15 @@ def main():
             line["cascade_hashing"] = cascade
         if verified is not None:
             line["with_geometric_verification"] = verified
+        if gated is not None:
+            line["gates_at_work"] = gated
         if ba is not None:
             line["ba"] = ba
-        if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(iset, all_pairs, args.cpu_sample_pairs)
+        if e2e is not None:
+            line["config3_single_gpu"] = e2e
         print(json.dumps(line))
-    m.close()
+        if parity_bad:
+            raise SystemExit(f"bench.py: GPU match lists differ from the oracle on pairs {parity_bad}")
     if store is not None:
         store.close()
     if world > 1:

@@ -288,4 +288,7 @@ def bench_global_ba(num_cameras=200, num_points=100000, max_iterations=25, devic
             "kernel_ms": {"point_pass": s.point_pass_ms, "pair_pass": s.pair_pass_ms,
                           "cholesky": s.cholesky_ms, "back_pass": s.back_pass_ms,
                           "sum": lm_ms, "linearizations": int(s.linearizations)},
-            "pair_entries": int(s.num_pair_entries)}
+            "pair_entries": int(s.num_pair_entries),
+            "observations": int(fp.obs_camera.size), "points": int(num_points),
+            # tangent size of the free camera blocks: 3 per free rotation, 1 per free scalar
+            "camera_unknowns": int(sum((0 if c[0] else 3) + int((c[4:] == 0).sum()) for c in fp.cam_const))}

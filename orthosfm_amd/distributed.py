@@ -26,6 +26,48 @@ def owner_of(pair_index: int, world: int) -> int:
     return pair_index % world
 
 
+def deal_pairs(pairs, view_sizes, world: int):
+    """Static deal of the pair list by work: the cost of pair (a, b) is N_a * N_b, known up
+    front, so the pairs are handed out longest first to the rank with the
+    least work so far (LPT; ties: the lower rank).  Returns one ascending array of pair
+    indices per rank -- the same on every rank, no communication.  With equal view sizes
+    this is exactly the round-robin deal of shard_pairs."""
+    n = len(pairs)
+    if world <= 1:
+        return [np.arange(n, dtype=np.int64)]
+    sizes = np.asarray(view_sizes, dtype=np.int64)
+    pa = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+    w = sizes[pa[:, 0]] * sizes[pa[:, 1]]
+    if n == 0 or np.all(w == w[0]):
+        return [np.arange(r, n, world, dtype=np.int64) for r in range(world)]
+    import heapq
+    order = np.argsort(-w, kind="stable")
+    heap = [(0, r) for r in range(world)]
+    owner = np.empty(n, dtype=np.int64)
+    for i in order:
+        load, r = heapq.heappop(heap)
+        owner[i] = r
+        heapq.heappush(heap, (load + int(w[i]), r))
+    return [np.nonzero(owner == r)[0].astype(np.int64) for r in range(world)]
+
+
+def _shards_or_round_robin(shards, num_pairs, world):
+    if shards is None:
+        return [np.arange(r, num_pairs, world, dtype=np.int64) for r in range(world)]
+    assert len(shards) == world and sum(len(s) for s in shards) == num_pairs
+    return [np.asarray(s, dtype=np.int64) for s in shards]
+
+
+def _owner_maps(shards, num_pairs):
+    """r_of[gi], k_of[gi]: rank that owns global pair gi and its position in that shard."""
+    r_of = np.empty(num_pairs, dtype=np.int64)
+    k_of = np.empty(num_pairs, dtype=np.int64)
+    for r, s in enumerate(shards):
+        r_of[s] = r
+        k_of[s] = np.arange(len(s))
+    return r_of, k_of
+
+
 _pinned = {}
 
 
@@ -43,13 +85,15 @@ def pinned_array(name: str, rows: int, device="cpu"):
     return t[:rows].numpy()
 
 
-def gather_match_lists(local_counts, local_corr, num_pairs: int, rank: int, world: int, device="cpu"):
+def gather_match_lists(local_counts, local_corr, num_pairs: int, rank: int, world: int, device="cpu",
+                       shards=None):
     """Gathers variable-length per-pair correspondence lists on rank 0.
 
     local_counts: int array, matches of each LOCAL pair (in shard order);
     local_corr:   (sum(local_counts), 2) int32, concatenated lists.
     Returns on rank 0 (counts[num_pairs], offsets[num_pairs + 1], corr[total, 2])
-    in GLOBAL pair order, on other ranks None.
+    in GLOBAL pair order, on other ranks None.  shards: the deal (deal_pairs), one index
+    array per rank; None = round robin.
 
     Two collectives: an all_gather of the per-rank counts (to size the buffers)
     and one gather of the padded int32 payload.  On rank 0 the lists are put
@@ -61,13 +105,14 @@ def gather_match_lists(local_counts, local_corr, num_pairs: int, rank: int, worl
 
     local_counts = np.ascontiguousarray(local_counts, dtype=np.int64)
     local_corr = np.ascontiguousarray(local_corr, dtype=np.int32).reshape(-1, 2)
-    n_local = len(range(rank, num_pairs, world))
+    shards = _shards_or_round_robin(shards, num_pairs, world)
+    n_local = len(shards[rank])
     assert local_counts.shape[0] == n_local and local_corr.shape[0] == int(local_counts.sum())
     if world == 1:
         offs = np.concatenate([[0], np.cumsum(local_counts)])
         return local_counts, offs, local_corr
 
-    max_local = len(range(0, num_pairs, world))
+    max_local = max(len(s) for s in shards)
     # header: per-pair counts padded to the largest shard
     head = torch.zeros(max_local, dtype=torch.int64)
     head[:n_local] = torch.from_numpy(local_counts)
@@ -84,17 +129,18 @@ def gather_match_lists(local_counts, local_corr, num_pairs: int, rank: int, worl
     dist.gather(payload, bufs, dst=0)
     if rank != 0:
         return None
-    return assemble_global_order(heads, bufs, num_pairs, world, device)
+    return assemble_global_order(heads, bufs, num_pairs, world, device, shards)
 
 
-def assemble_global_order(heads, bufs, num_pairs: int, world: int, device="cpu"):
+def assemble_global_order(heads, bufs, num_pairs: int, world: int, device="cpu", shards=None):
     """Rank 0's part after the gather: heads [world][max_local] per-pair counts of
-    every rank, bufs[r] the (width, 2) payload of rank r.  Global pair
-    gi = k * world + r is local pair k of rank r (shard_pairs)."""
+    every rank, bufs[r] the (width, 2) payload of rank r.  Global pair gi is local pair
+    k_of[gi] of rank r_of[gi] (the deal; round robin when shards is None)."""
     import torch
     width = bufs[0].shape[0]
-    r_of = torch.arange(num_pairs, device=device) % world
-    k_of = torch.arange(num_pairs, device=device) // world
+    r_np, k_np = _owner_maps(_shards_or_round_robin(shards, num_pairs, world), num_pairs)
+    r_of = torch.from_numpy(r_np).to(device)
+    k_of = torch.from_numpy(k_np).to(device)
     counts = heads[r_of, k_of]                               # [num_pairs], global order
     offsets = torch.zeros(num_pairs + 1, dtype=torch.int64, device=device)
     offsets[1:] = torch.cumsum(counts, 0)
@@ -177,16 +223,18 @@ class SharedMatchStore:
             self.close()
             raise SharedSegmentUnavailable("hipHostRegister of a result slice failed on some rank")
 
-    def collect(self, local_counts, num_pairs: int):
+    def collect(self, local_counts, num_pairs: int, shards=None):
         """After the rank's lists are in its slice (packed in shard order): returns on
         rank 0 (counts[num_pairs], starts[num_pairs], corr) with pair gi's list at
-        corr[starts[gi] : starts[gi] + counts[gi]], global pair order; None elsewhere."""
+        corr[starts[gi] : starts[gi] + counts[gi]], global pair order; None elsewhere.
+        shards: the deal (deal_pairs); None = round robin."""
         import torch
         import torch.distributed as dist
         local_counts = np.ascontiguousarray(local_counts, dtype=np.int64)
-        n_local = len(range(self.rank, num_pairs, self.world))
+        shards = _shards_or_round_robin(shards, num_pairs, self.world)
+        n_local = len(shards[self.rank])
         assert local_counts.shape[0] == n_local and int(local_counts.sum()) <= self.rows
-        max_local = len(range(0, num_pairs, self.world))
+        max_local = max(len(s) for s in shards)
         head = torch.zeros(max_local, dtype=torch.int64)
         head[:n_local] = torch.from_numpy(local_counts)
         if self.world > 1:
@@ -198,8 +246,7 @@ class SharedMatchStore:
             heads = head.numpy()[None]
         if self.rank != 0:
             return None
-        gi = np.arange(num_pairs)
-        r_of, k_of = gi % self.world, gi // self.world
+        r_of, k_of = _owner_maps(shards, num_pairs)
         local_off = np.cumsum(heads, axis=1) - heads
         counts = heads[r_of, k_of]
         starts = r_of.astype(np.int64) * self.rows + local_off[r_of, k_of]

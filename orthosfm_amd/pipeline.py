@@ -70,6 +70,7 @@ class TrackTable:
         order = np.argsort(self.view, kind="stable").astype(np.int64)      # feature ids grouped by view, ascending inside
         self.by_view = order
         self.view_start = np.searchsorted(self.view[order], np.arange(self.num_views + 1))
+        self._lengths = None
 
     @classmethod
     def from_mve(cls, track_offsets, track_features, norm_positions, image_width, num_views):
@@ -95,9 +96,35 @@ class TrackTable:
         return idx
 
     def alive_lengths(self):
-        """Features left per track (0 for dead tracks)."""
-        n = np.bincount(self.track_of[self.alive_f], minlength=self.alive_t.shape[0])
-        return np.where(self.alive_t, n, 0)
+        """Features left per track (0 for dead tracks); cached until a filter clears flags."""
+        if self._lengths is None:
+            n = np.bincount(self.track_of[self.alive_f], minlength=self.alive_t.shape[0])
+            self._lengths = np.where(self.alive_t, n, 0)
+        return self._lengths
+
+    def kill(self, tracks=None, features=None):
+        """Clears alive flags (what a filter's smaller output list means here)."""
+        if features is not None and len(features):
+            self.alive_f[features] = False
+        if tracks is not None and len(tracks):
+            self.alive_t[tracks] = False
+        self._lengths = None
+
+
+def _runs(sorted_ids):
+    """For a non-decreasing id array: (unique ids, first index of each run, run lengths,
+    run number of every element) -- np.unique without the sort."""
+    n = sorted_ids.shape[0]
+    if n == 0:
+        z = np.zeros(0, dtype=np.int64)
+        return sorted_ids[:0], z, z, z
+    flag = np.empty(n, dtype=bool)
+    flag[0] = True
+    np.not_equal(sorted_ids[1:], sorted_ids[:-1], out=flag[1:])
+    first = np.flatnonzero(flag)
+    cnt = np.diff(np.append(first, n))
+    run = np.cumsum(flag) - 1
+    return sorted_ids[first], first, cnt, run
 
 
 # ---------------------------------------------------------------------------
@@ -368,11 +395,9 @@ def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2
         cam_of = np.full(V, -1, dtype=np.int32)
         cam_of[aligned] = np.arange(len(aligned), dtype=np.int32)
         fsel = np.nonzero((cam_of[tt.view] >= 0) & tt.alive_f & tt.alive_t[tt.track_of])[0]
-        tr = tt.track_of[fsel]
-        uniq, first = np.unique(tr, return_index=True)          # fsel is in track order
-        obs_pt = np.searchsorted(uniq, tr).astype(np.int32)
+        uniq, _, _, run = _runs(tt.track_of[fsel])              # fsel is in track order
         prob = _problem(model, cams[aligned], const[aligned], W, H, np.tile([0.0, 0, 0, 1], (uniq.size, 1)),
-                        tt.xy[fsel], cam_of[tt.view[fsel]], obs_pt)
+                        tt.xy[fsel], cam_of[tt.view[fsel]], run.astype(np.int32))
         valid = B.triangulate(prob, device) if uniq.size else np.zeros(0, np.uint8)
         tt.has_point[:] = False
         ok = uniq[valid.astype(bool)]
@@ -392,18 +417,17 @@ def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2
         if idx.size == 0:
             return idx
         tr = tt.track_of[idx]
-        uniq, first, cnt = np.unique(tr, return_index=True, return_counts=True)
-        cnt_f = cnt[np.searchsorted(uniq, tr)]
+        uniq, first, cnt, run = _runs(tr)
+        cnt_f = cnt[run]
         keep_f = np.ones(idx.shape[0], dtype=bool)
         full_f = cnt_f == n
         if full_f.any():
             fi = idx[full_f]
-            ftr = tr[full_f]
             fu = uniq[cnt == n]
             cam_of = np.full(V, -1, dtype=np.int32)
             cam_of[view_list] = np.arange(n, dtype=np.int32)
             prob = _problem(model, cam_p, cam_c, W, H, tt.point[fu].copy(), tt.xy[fi], cam_of[tt.view[fi]],
-                            np.searchsorted(fu, ftr).astype(np.int32))
+                            np.repeat(np.arange(fu.shape[0], dtype=np.int32), n))
             st = prob.struct()
             ok = np.zeros(fi.shape[0], dtype=np.uint8)
             capi.check(capi.lib.osfm_filter_reprojection(C.byref(st), device, C.c_double(MAX_REPROJECTION_ERROR),
@@ -413,10 +437,9 @@ def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2
         total = tt.alive_lengths()[uniq] - cnt + np.add.reduceat(keep_f.astype(np.int64), first)
         track_ok = np.where(cnt == n, total > 1, True)              # only full-size tracks are judged (:147-149,187-189)
         if permanent:
-            tt.alive_f[idx[~keep_f]] = False
-            tt.alive_t[uniq[~track_ok]] = False
+            tt.kill(tracks=uniq[~track_ok], features=idx[~keep_f])
         inside = np.add.reduceat(keep_f.astype(np.int64), first)
-        sel = keep_f & (track_ok & (inside > 1))[np.searchsorted(uniq, tr)]
+        sel = keep_f & (track_ok & (inside > 1))[run]
         tm.local_filter_s += time.perf_counter() - t0
         return idx[sel]
 
@@ -434,12 +457,11 @@ def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2
         # filtered, re-triangulated copy (runBundleAdjustment(..., true, true), :212-219) ----
         fsel = reprojection_filter(ids, lp, lc, permanent=False)
         t0 = time.perf_counter()
-        tr = tt.track_of[fsel]
-        uniq = np.unique(tr)
+        uniq, _, _, run = _runs(tt.track_of[fsel])
         cam_of = np.full(V, -1, dtype=np.int32)
         cam_of[ids] = np.arange(len(ids), dtype=np.int32)
         prob = _problem(model, lp, lc, W, H, np.tile([0.0, 0, 0, 1], (uniq.size, 1)), tt.xy[fsel],
-                        cam_of[tt.view[fsel]], np.searchsorted(uniq, tr).astype(np.int32))
+                        cam_of[tt.view[fsel]], run.astype(np.int32))
         tm.pose_host_s += time.perf_counter() - t0
         s, dt = solve("local", prob, opt_local)
         tm.local_ba_s += dt
@@ -463,7 +485,7 @@ def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2
                 t0 = time.perf_counter()
                 at = np.nonzero(tt.alive_t)[0]
                 keep, _ = _outlier_flags(tt.point[at], tt.has_point[at], device)
-                tt.alive_t[at[~keep]] = False
+                tt.kill(tracks=at[~keep])
                 tm.outlier_filter_s += time.perf_counter() - t0
                 if len(aligned) <= int(tt.alive_lengths().max(initial=0)):
                     reprojection_filter(list(aligned), cams[aligned], const[aligned], permanent=True)

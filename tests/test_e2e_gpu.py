@@ -74,7 +74,7 @@ def test_reconstruct_small_set(iset, solver):
         assert ang < 0.02, (v, ang)
     tt = res.tracks
     sel = np.nonzero(tt.alive_t & tt.has_point)[0]
-    assert sel.size > 0.8 * tt.alive_t.size
+    assert sel.size > 0.6 * tt.alive_t.size          # filterOutlierTracks drops the sparse fifth (1.6 sigma)
     lm = iset.landmark[tt.view[tt.offsets[sel]]][0] if False else np.array(
         [iset.landmark[tt.view[tt.offsets[t]]][tt.feat[tt.offsets[t]]] for t in sel[:500]])
     p = tt.point[sel[:500]]

@@ -1,26 +1,27 @@
 #!/bin/bash
-# Round-end evidence: bench line + rocprofv3 kernel summary of the same command.
-#   gpurun -- 'tools/refresh_profiles.sh v11'   ->  gpurun_out/r01_bench_<tag>.json,
-#   gpurun_out/r01_bench_kernel_stats_<tag>.csv  (copy both into profiles/)
+# Round evidence: bench line + rocprofv3 kernel summary of the same command.
+#   gpurun -- 'tools/refresh_profiles.sh r02 v1'   ->  gpurun_out/<round>_bench_<tag>.json,
+#   gpurun_out/<round>_bench_kernel_stats_<tag>.csv  (copy both into profiles/)
 set -e
-tag=${1:-vX}
+round=${1:-r02}
+tag=${2:-vX}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $R/gpurun_out/bench_$tag.log 2>&1
-tail -1 $R/gpurun_out/bench_$tag.log > $R/gpurun_out/r01_bench_$tag.json
+tail -1 $R/gpurun_out/bench_$tag.log > $R/gpurun_out/${round}_bench_$tag.json
 rm -rf $R/gpurun_out/prof_$tag
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -- python $R/bench.py --steps 5 --warmup 2 > $R/gpurun_out/prof_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -- python $R/bench.py --steps 5 --warmup 2 --no-e2e --no-cpu-baseline > $R/gpurun_out/prof_$tag.log 2>&1
 db=$(find $R/gpurun_out/prof_$tag -name "*.db" | head -1)
 if [ -n "$db" ]; then
-  python $R/tools/rocpd_stats.py $db > $R/gpurun_out/r01_bench_kernel_stats_$tag.csv
+  python $R/tools/rocpd_stats.py $db > $R/gpurun_out/${round}_bench_kernel_stats_$tag.csv
 else
   f=$(find $R/gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
-  cp $f $R/gpurun_out/r01_bench_kernel_stats_$tag.csv
+  cp $f $R/gpurun_out/${round}_bench_kernel_stats_$tag.csv
 fi
 rm -rf $R/gpurun_out/prof_$tag        # the trace itself is large; the summary is what is kept
-head -5 $R/gpurun_out/r01_bench_kernel_stats_$tag.csv
+head -8 $R/gpurun_out/${round}_bench_kernel_stats_$tag.csv
 python - <<PY
 import json
-d = json.load(open("$R/gpurun_out/r01_bench_$tag.json"))
+d = json.load(open("$R/gpurun_out/${round}_bench_$tag.json"))
 print(d["value"], d["ms_per_step"], d["roofline"]["avg_launch_ms"], d["roofline"]["frac"])
 PY
