@@ -78,8 +78,13 @@ def test_reconstruct_small_set(iset, solver):
     lm = iset.landmark[tt.view[tt.offsets[sel]]][0] if False else np.array(
         [iset.landmark[tt.view[tt.offsets[t]]][tt.feat[tt.offsets[t]]] for t in sel[:500]])
     p = tt.point[sel[:500]]
-    err = np.linalg.norm(p[:, :3] / p[:, 3:4] - pts[lm], axis=1)
-    assert np.median(err) < 1e-3
+    d = p[:, :3] / p[:, 3:4] - pts[lm]
+    # orthographic cameras with free offsets leave ONE gauge freedom once camera 0 is pinned: a
+    # shift of the scene along camera 0's viewing axis (z in the canonical frame), absorbed by
+    # the other cameras' offsets
+    shift = np.median(d, axis=0)
+    assert np.abs(shift[:2]).max() < 1e-4
+    assert np.median(np.linalg.norm(d - shift, axis=1)) < 1e-4
     assert res.timings.total_s > 0 and res.timings.pose_s > 0
 
 
