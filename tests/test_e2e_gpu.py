@@ -105,3 +105,22 @@ def test_incremental_group_builder_matches_the_oracle():
     assert want is not None
     assert np.array_equal(np.array([g.ids for g in got]), want[0])
     assert np.array_equal(np.array([g.tracks for g in got]), want[1])
+
+
+def test_config1_three_views_quaternion():
+    """BASELINE configs[0]: three views, --solver=0 (quaternion): match -> verify -> tracks ->
+    one group -> filter -> local BA (camera 0 fixed) -> triangulate -> final BA.  (The
+    reference's own three-image subset is a download the tree does not hold; the landmarks
+    here are the synthetic scene's, as for the other configs.)"""
+    from orthosfm_amd import pipeline as P
+    iset = synth.make_image_set(3, 3000, config_id=72)
+    res = P.reconstruct(iset, solver=0, seed=3)
+    assert len(res.groups) == 1 and sorted(res.groups[0].ids) == [0, 1, 2]
+    assert [c.kind for c in res.ba_calls] == ["local", "final"]
+    assert res.ba_calls[0].cameras == 3 and res.ba_calls[1].cameras == 3
+    assert res.matched_pairs == 3 and res.num_mve_tracks > 500
+    gt, _ = P.canonical_ground_truth(iset, 0)
+    for v in range(3):
+        Rg, Rc = P._cam_rotation(0, gt[v]), P._cam_rotation(0, res.cam_params[v])
+        assert np.degrees(np.arccos(np.clip((np.trace(Rg.T @ Rc) - 1) / 2, -1, 1))) < 0.02
+    assert int((res.tracks.alive_t & res.tracks.has_point).sum()) > 300
