@@ -212,3 +212,54 @@ def _numpy_residuals_obs(sc):
     t.points = np.concatenate([sc.gt_points, np.ones((sc.gt_points.shape[0], 1))], axis=1)
     t.obs_xy = np.zeros_like(sc.obs_xy)
     return _numpy_residuals(t)
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_huber_active_optimum_vs_scipy(model):
+    """Huber ACTIVE (planted gross outliers): Ceres' cost is 1/2 sum rho(|r_k|^2) per 2-D
+    block, rho(s) = s for s <= 1, 2 sqrt(s) - 1 beyond.  Giving scipy the re-weighted
+    residual r * sqrt(rho(s) / s) makes its plain least-squares objective exactly that cost
+    (scipy's own loss='huber' is per SCALAR residual and cannot be used), so the oracle's
+    optimum -- corrector, robustified Jacobian, LM -- is pinned independently."""
+    scipy_opt = pytest.importorskip("scipy.optimize")
+    sc = synth.make_ba_scene(model, 6, 70, config_id=18, noise_px=0.3, rot_perturb_deg=0.7)
+    sc.obs_xy[::13] += np.array([9.0, -7.0])            # about 8 % gross outliers
+    ref = sc.copy()
+    s = oracle_lib.oracle_ba_solve(sc, function_tolerance=1e-14, max_num_iterations=300)
+    C_, M_ = ref.cam_params.shape[0], ref.points.shape[0]
+    ncp = 5
+    nfree = (C_ - 1) * ncp
+
+    def unpack(x):
+        t = ref.copy()
+        for c in range(1, C_):
+            v = x[(c - 1) * ncp:(c - 1) * ncp + ncp]
+            if model == 0:
+                d = v[:3]
+                nd = np.linalg.norm(d)
+                if nd > 0:
+                    dq = np.array([*(np.sin(nd) / nd * d), np.cos(nd)])
+                    t.cam_params[c, :4] = synth.quat_mul(dq, ref.cam_params[c, :4])
+                t.cam_params[c, 4:6] = ref.cam_params[c, 4:6] + v[3:5]
+            else:
+                t.cam_params[c, :5] = ref.cam_params[c, :5] + v
+        t.points[:, :3] = x[nfree:].reshape(M_, 3)
+        return t
+
+    def fun(x):
+        r = _numpy_residuals(unpack(x)).reshape(-1, 2)
+        sq = (r ** 2).sum(1)
+        rho = np.where(sq <= 1.0, sq, 2.0 * np.sqrt(np.maximum(sq, 1e-300)) - 1.0)
+        w = np.sqrt(rho / np.maximum(sq, 1e-300))
+        return (r * w[:, None]).reshape(-1)
+
+    x0 = np.concatenate([np.zeros(nfree), ref.points[:, :3].reshape(-1)])
+    assert np.isclose(0.5 * float((fun(x0) ** 2).sum()), s.initial_cost, rtol=1e-10)
+    # start scipy from the oracle's optimum as well as from the common start: a local
+    # minimiser must not be able to improve on the oracle's point
+    sol = scipy_opt.least_squares(fun, x0, method="trf", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=600)
+    cost_scipy = 0.5 * float((sol.fun ** 2).sum())
+    active = ((_numpy_residuals(sc).reshape(-1, 2) ** 2).sum(1) > 1.0).mean()
+    assert active > 0.05                                   # the loss is active at the optimum
+    assert np.isclose(s.final_cost, cost_scipy, rtol=2e-4), (s.final_cost, cost_scipy)
+    assert s.final_cost <= cost_scipy * (1 + 2e-4)

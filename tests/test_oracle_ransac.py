@@ -144,3 +144,61 @@ def test_ransac_statistics_vs_reference():
         assert np.mean(counts_or) > 0.9 * np.mean(counts_ref), (counts_ref, counts_or)
         if frac <= 0.2:
             assert abs(np.mean(counts_ref) - np.mean(counts_or)) < 0.01 * inlier.sum() + 2
+
+
+@needs_ref
+@pytest.mark.ref
+def test_hypothesis_inlier_sets_vs_reference_on_identical_samples():
+    """The one place where the oracle does not follow the reference's digits: the 8-point
+    solve (exact null vector vs MVE's one-sided Jacobi SVD).  Same 8-index samples into
+    both, the resulting F scored with the (bit-identical) Sampson distance over all
+    matches of a realistic pair: how often does a hypothesis' INLIER SET differ, and does
+    it change what RANSAC returns -- the best hypothesis and the pair's accept decision?
+    (Numbers quoted in DESIGN.md section 2.5.)"""
+    ref = oracle_lib.ref_ransac()
+    f64 = np.ctypeslib.ndpointer(np.float64)
+    ref.ref_fundamental_8_point.argtypes = [f64, f64, f64]
+    ref.ref_fundamental_8_point.restype = None
+    n, thr = 1200, 0.0015
+    stats = []
+    for frac, seed in ((0.15, 11), (0.35, 12)):
+        pos1, pos2, corr, inlier = two_view_scene(n, frac, seed)
+        p1 = pos1[corr[:, 0]].astype(np.float64)
+        p2 = pos2[corr[:, 1]].astype(np.float64)
+        h = np.concatenate([p1, np.ones((n, 1))], 1), np.concatenate([p2, np.ones((n, 1))], 1)
+
+        def inlier_set(F):
+            # sampson_distance (fundamental.cc:225-246), vectorised: (p2^T F p1)^2 / (|F p1|_xy^2 + |F^T p2|_xy^2)
+            F = F.reshape(3, 3)
+            Fp1 = h[0] @ F.T
+            Ftp2 = h[1] @ F
+            num = (h[1] * Fp1).sum(1) ** 2
+            den = Fp1[:, 0] ** 2 + Fp1[:, 1] ** 2 + Ftp2[:, 0] ** 2 + Ftp2[:, 1] ** 2
+            return num / den < thr ** 2
+
+        r = np.random.default_rng(seed)
+        differ = 0
+        best_ref = best_or = 0
+        total = 10000
+        size_gap = []
+        for _ in range(total):
+            idx = r.choice(n, 8, replace=False)
+            a, b = np.ascontiguousarray(p1[idx]), np.ascontiguousarray(p2[idx])
+            ok, Fo = oracle_lib.oracle_fundamental_8_point(a, b)
+            Fr = np.zeros(9)
+            ref.ref_fundamental_8_point(a.reshape(-1), b.reshape(-1), Fr)
+            so, sr = inlier_set(Fo), inlier_set(Fr)
+            if not np.array_equal(so, sr):
+                differ += 1
+                size_gap.append(int(so.sum()) - int(sr.sum()))
+            best_ref, best_or = max(best_ref, int(sr.sum())), max(best_or, int(so.sum()))
+        stats.append((frac, differ / total, best_ref, best_or, int(inlier.sum()),
+                      float(np.mean(np.abs(size_gap))) if size_gap else 0.0))
+    for frac, share, best_ref, best_or, planted, gap in stats:
+        print(f"outliers {frac:.2f}: {100 * share:.2f} % of 10000 hypotheses differ in their inlier set "
+              f"(mean |size gap| {gap:.1f}); best hypothesis: reference {best_ref}, oracle {best_or} of {planted} planted")
+        # the sets differ for a minority of (near-degenerate) samples, and never where it counts:
+        # the best hypotheses agree to a few matches, far above the accept threshold of 30
+        assert share < 0.25
+        assert abs(best_ref - best_or) <= max(3, 0.01 * planted)
+        assert best_or >= 0.95 * planted
