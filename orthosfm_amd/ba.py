@@ -278,6 +278,13 @@ def bench_global_ba(num_cameras=200, num_points=100000, max_iterations=25, devic
     solve(warm, max_num_iterations=2, device=device)          # warm-up (allocator, code objects)
     s = solve(fp, max_num_iterations=max_iterations, device=device)
     its = s.num_iterations
+    # the per-family device times come from a second, instrumented solve (verbose = 1 records
+    # an event pair around every kernel family of every iteration)
+    prof = FlatProblem.from_scene(sc)
+    sp = solve(prof, max_num_iterations=max_iterations, device=device, verbose=1)
+    assert sp.num_iterations == its and sp.final_cost == s.final_cost
+    s.point_pass_ms, s.pair_pass_ms, s.cholesky_ms, s.back_pass_ms = (sp.point_pass_ms, sp.pair_pass_ms,
+                                                                      sp.cholesky_ms, sp.back_pass_ms)
     lm_ms = s.point_pass_ms + s.pair_pass_ms + s.cholesky_ms + s.back_pass_ms
     return {"workload": f"{num_cameras} quaternion cameras, {num_points} tracks, "
                         f"{fp.obs_camera.size} observations, Schur + dense Cholesky",

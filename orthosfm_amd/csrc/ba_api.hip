@@ -133,6 +133,7 @@ int upload_problem(const osfm_ba_problem *p, const Layout &L, double huber, int 
     launch_fill(D->scale_c.as<double>(), (size_t)L.nc, 1.0, s);
     launch_fill(D->scale_p.as<double>(), (size_t)3 * M, 1.0, s);
     BaDev &d = D->dev;
+    memset(&d, 0, sizeof(d));          // lm == nullptr: the plain pointers below are used as they are
     d.model = p->model; d.C = C; d.M = M; d.O = O; d.nc = L.nc; d.pdim = pdim;
     d.cams = D->cams[0].as<double>(); d.points = D->points[0].as<double>();
     d.obs_xy = D->obs_xy.as<double>(); d.obs_cam = D->obs_cam.as<int32_t>(); d.obs_pt = D->obs_pt.as<int32_t>();
@@ -213,7 +214,6 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     StreamGuard sg;
     OSFM_RETURN_IF(sg.acquire());
     hipStream_t s = sg.s;
-    EventPair *ev = sg.ev;
 
     DeviceProblem D;
     OSFM_RETURN_IF(upload_problem(p, L, o.huber_delta, pdim, s, &D));
@@ -246,6 +246,7 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
 
     const int blocksM = std::max(1, (int)(((int64_t)M * kPointLanes + 255) / 256));
     const int N = cholesky_padded_dim(std::max(nc, 1));
+    DevArray Lmat;
     DevArray obsrec, diag_c, diag_p, vinv, ge, S, Ldiag, y_c, partA, partB, partC, part_cam, gmax_cam, scalars, info;
     OSFM_RETURN_IF(obsrec.alloc((size_t)std::max(p->num_observations, 1) * kObsRec * 8));
     OSFM_RETURN_IF(diag_c.alloc((size_t)nc * 8));
@@ -254,6 +255,7 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     OSFM_RETURN_IF(ge.alloc((size_t)3 * M * 8));
     const size_t s_elems = (size_t)(N + 32) * N;
     OSFM_RETURN_IF(S.alloc(s_elems * 8));
+    OSFM_RETURN_IF(Lmat.alloc(s_elems * 8));
     OSFM_RETURN_IF(Ldiag.alloc((size_t)N * 32 * 8));
     OSFM_RETURN_IF(y_c.alloc((size_t)N * 8));
     OSFM_RETURN_IF(partA.alloc((size_t)3 * blocksM * 8));
@@ -281,45 +283,70 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     qa.diag_c = diag_c.as<double>(); qa.scale_c_out = D.scale_c.as<double>();
     qa.S = S.as<double>(); qa.ldS = N; qa.rhs = S.as<double>() + (size_t)N * N;
 
-    double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
-    bool reuse_diagonal = false;
-    int cur = 0;       // index of the current iterate in cams[] / points[]
-    double h_scal[16];
-    double t_point = 0, t_pair = 0, t_chol = 0, t_back = 0;
+    // ---- Levenberg-Marquardt, control on the device ---------------------------------
+    // Every iteration is the same fixed sequence of launches; what they do (which iterate
+    // is current, the radius, refresh of the LM diagonal, nothing at all once the solve has
+    // stopped) is read from the LmDev state that ba_lm_decide / ba_lm_post keep.  The host
+    // enqueues iteration i + 1 before it looks at the state iteration i left behind, so
+    // the stream never waits for it; the one iteration enqueued past the end is a row of
+    // kernels that return at once.
+    DevArray lmdev;
+    OSFM_RETURN_IF(lmdev.alloc(sizeof(LmDev)));
+    LmDev init;
+    memset(&init, 0, sizeof(init));
+    init.radius = o.initial_trust_region_radius; init.decrease_factor = 2.0;
+    init.update_diag = 1; init.want_gradient = 1; init.term = OSFM_BA_NO_CONVERGENCE;
+    LmDev *lm = lmdev.as<LmDev>();
+    const int max_slots = o.max_num_iterations + 3;
+    OSFM_RETURN_IF(sg.set->ensure_pinned((size_t)max_slots * sizeof(LmDev)));
+    OSFM_RETURN_IF(sg.set->ensure_events((size_t)max_slots + (o.verbose ? 8 * (size_t)max_slots : 0)));
+    LmDev *h_state = static_cast<LmDev *>(sg.set->pinned);
+    memcpy(&h_state[0], &init, sizeof(init));
+    OSFM_HIP_CHECK(hipMemcpyAsync(lm, &h_state[0], sizeof(LmDev), hipMemcpyHostToDevice, s));
+    d.cams2[0] = D.cams[0].as<double>(); d.cams2[1] = D.cams[1].as<double>();
+    d.points2[0] = D.points[0].as<double>(); d.points2[1] = D.points[1].as<double>();
+    // iteration 0 (Jacobi scaling) runs on the plain pointers, the state comes after it
+    LmParams prm;
+    prm.function_tolerance = o.function_tolerance; prm.gradient_tolerance = o.gradient_tolerance;
+    prm.parameter_tolerance = o.parameter_tolerance; prm.min_relative_decrease = o.min_relative_decrease;
+    prm.max_radius = o.max_trust_region_radius; prm.min_radius = o.min_trust_region_radius;
+    prm.max_iterations = o.max_num_iterations; prm.max_invalid_steps = o.max_consecutive_invalid_steps;
+    LmScratch sc;
+    sc.partA = partA.as<double>(); sc.partB = partB.as<double>(); sc.partC = partC.as<double>();
+    sc.part_cam = part_cam.as<double>(); sc.gmax_cam = gmax_cam.as<double>();
+    sc.chol_info = info.as<int32_t>(); sc.blocksM = blocksM; sc.C = std::max(C, 1);
+    OSFM_HIP_CHECK(hipMemsetAsync(info.ptr, 0, 16, s));
+    OSFM_HIP_CHECK(hipMemsetAsync(part_cam.ptr, 0, (size_t)2 * std::max(C, 1) * 8, s));
+
+    // kernel-family timing (o.verbose): event pairs per iteration, read after the loop
+    std::vector<hipEvent_t> &evs = sg.set->events;
+    size_t ev_next = (size_t)max_slots;
+    std::vector<std::pair<size_t, int>> ev_pairs;     // (first event of the pair, family)
+    auto tic = [&](int family) -> int {
+        if (!o.verbose) return OSFM_OK;
+        OSFM_HIP_CHECK(hipEventRecord(evs[ev_next], s));
+        ev_pairs.push_back({ev_next, family});
+        return OSFM_OK;
+    };
+    auto toc = [&]() -> int {
+        if (!o.verbose) return OSFM_OK;
+        OSFM_HIP_CHECK(hipEventRecord(evs[ev_next + 1], s));
+        ev_next += 2;
+        return OSFM_OK;
+    };
     int n_lin = 0;
 
-    auto set_current = [&](int idx) {
-        cur = idx;
-        d.cams = D.cams[idx].as<double>();
-        d.points = D.points[idx].as<double>();
-    };
-
-    // Evaluates cost / gradient norm at the current iterate and prepares the
-    // normal equations for the current radius:
-    //   h_scal[0] = cost, [1] = gradient max norm (points), [2] = not-PD flag,
-    //   [3] = gradient max norm (cameras)
-    auto linearize = [&](bool new_point) -> int {
-        pa.mode = kPassNormal; pa.update_diag = reuse_diagonal ? 0 : 1; pa.want_gradient = new_point ? 1 : 0;
-        pa.radius = radius;
-        qa.mode = kPassNormal; qa.update_diag = pa.update_diag; qa.want_gradient = pa.want_gradient;
-        qa.radius = radius;
-        OSFM_HIP_CHECK(hipEventRecord(ev[0].a, s));
+    auto linearize = [&]() -> int {
+        pa.mode = kPassNormal; qa.mode = kPassNormal;
+        OSFM_RETURN_IF(tic(0));
         launch_point_pass(d, pa, blocksM, s);
-        OSFM_HIP_CHECK(hipEventRecord(ev[0].b, s));
+        OSFM_RETURN_IF(toc());
         OSFM_HIP_CHECK(hipMemsetAsync(S.ptr, 0, s_elems * 8, s));
         launch_pad_diag(S.as<double>(), N, nc, N, s);
-        OSFM_HIP_CHECK(hipEventRecord(ev[1].a, s));
+        OSFM_RETURN_IF(tic(1));
         launch_pair_pass(d, qa, s);
-        OSFM_HIP_CHECK(hipEventRecord(ev[1].b, s));
-        if (new_point) launch_cam_gradient(d, qa, gmax_cam.as<double>(), s);
-        launch_reduce(partA.as<double>(), blocksM, 3, 0x6u, scalars.as<double>(), nullptr, 0, 0, 0, s);
-        launch_max_reduce(gmax_cam.as<double>(), std::max(C, 1), scalars.as<double>() + 3, s);
-        OSFM_HIP_CHECK(hipGetLastError());
-        OSFM_HIP_CHECK(hipMemcpyAsync(h_scal, scalars.ptr, 4 * 8, hipMemcpyDeviceToHost, s));
-        OSFM_HIP_CHECK(hipStreamSynchronize(s));
-        float ms = 0.f;
-        OSFM_HIP_CHECK(hipEventElapsedTime(&ms, ev[0].a, ev[0].b)); t_point += ms;
-        OSFM_HIP_CHECK(hipEventElapsedTime(&ms, ev[1].a, ev[1].b)); t_pair += ms;
+        OSFM_RETURN_IF(toc());
+        launch_cam_gradient(d, qa, gmax_cam.as<double>(), s);
         n_lin++;
         return OSFM_OK;
     };
@@ -327,109 +354,78 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     // ---- iteration 0: Jacobi scaling from the unscaled column norms ---------
     if (o.jacobi_scaling) {
         pa.mode = kPassScaleInit; qa.mode = kPassScaleInit;
-        pa.radius = qa.radius = radius;
+        pa.radius = qa.radius = o.initial_trust_region_radius;
         launch_point_pass(d, pa, blocksM, s);
         launch_pair_pass(d, qa, s);
         OSFM_HIP_CHECK(hipGetLastError());
     }
+    d.lm = lm;
     lap("alloc + lists up");
-    OSFM_RETURN_IF(linearize(true));
+    OSFM_RETURN_IF(linearize());
+    launch_lm_post(lm, prm, sc, 1, s);
+    OSFM_HIP_CHECK(hipGetLastError());
     lap("first linearize");
     const auto t_loop = std::chrono::steady_clock::now();
-    double x_cost = h_scal[0];
-    double grad_max = std::max(h_scal[1], h_scal[3]);
-    sum->initial_cost = x_cost;
-    int iteration = 0, invalid_steps = 0, term = OSFM_BA_NO_CONVERGENCE;
-    bool last_successful = false, lin_failed = h_scal[2] != 0.0;
-    reuse_diagonal = true;
 
-    if (!std::isfinite(x_cost)) {
-        set_error("ba_solve: non-finite initial cost");
-        return OSFM_E_NUMERIC;
-    }
-    if (grad_max <= o.gradient_tolerance) term = OSFM_BA_CONVERGENCE_GRADIENT;
-    else for (;;) {
-        // FinalizeIterationAndCheckIfMinimizerCanContinue
-        if (iteration >= o.max_num_iterations) { term = OSFM_BA_NO_CONVERGENCE; break; }
-        if (last_successful && grad_max <= o.gradient_tolerance) { term = OSFM_BA_CONVERGENCE_GRADIENT; break; }
-        if (radius <= o.min_trust_region_radius) { term = OSFM_BA_CONVERGENCE_TRUST_REGION; break; }
-        iteration++;
-        last_successful = false;
-
-        // ---- solve the reduced system, back-substitute, evaluate candidate ----
-        bool step_valid = false;
-        double model_cost_change = 0.0, cand_cost = 0.0, step_norm = 0.0, x_norm = 0.0;
-        if (!lin_failed) {
-            const int nxt = cur ^ 1;
-            OSFM_HIP_CHECK(hipMemsetAsync(info.ptr, 0, 16, s));
-            OSFM_HIP_CHECK(hipEventRecord(ev[2].a, s));
-            if (nc > 0) launch_cholesky_solve(S.as<double>(), nc, Ldiag.as<double>(), y_c.as<double>(), info.as<int>(), s);
-            OSFM_HIP_CHECK(hipEventRecord(ev[2].b, s));
-            OSFM_HIP_CHECK(hipEventRecord(ev[3].a, s));
-            launch_cam_update(d, y_c.as<double>(), D.cams[nxt].as<double>(), part_cam.as<double>(), s);
-            BackPassArgs ba;
-            ba.y_c = y_c.as<double>(); ba.vinv = vinv.as<double>(); ba.ge = ge.as<double>(); ba.obsrec = obsrec.as<double>();
-            ba.points_out = D.points[nxt].as<double>(); ba.partials = partB.as<double>();
-            launch_back_pass(d, ba, blocksM, s);
-            OSFM_HIP_CHECK(hipEventRecord(ev[3].b, s));
-            launch_cost_pass(d, D.cams[nxt].as<double>(), D.points[nxt].as<double>(), partC.as<double>(), blocksM, s);
-            // scalars: [0..2] back pass (mcc, |dx|^2, |x|^2), [3..4] cameras (|dx|^2, |x|^2), [5] candidate cost
-            launch_reduce(partB.as<double>(), blocksM, 3, 0u, scalars.as<double>(), part_cam.as<double>(), C, 2, 2, s);
-            launch_reduce(partC.as<double>(), blocksM, 1, 0u, scalars.as<double>() + 5, nullptr, 0, 0, 0, s);
-            OSFM_HIP_CHECK(hipGetLastError());
-            int h_info[4] = { 0, 0, 0, 0 };
-            OSFM_HIP_CHECK(hipMemcpyAsync(h_scal, scalars.ptr, 6 * 8, hipMemcpyDeviceToHost, s));
-            OSFM_HIP_CHECK(hipMemcpyAsync(h_info, info.ptr, 16, hipMemcpyDeviceToHost, s));
-            OSFM_HIP_CHECK(hipStreamSynchronize(s));
-            float ms = 0.f;
-            OSFM_HIP_CHECK(hipEventElapsedTime(&ms, ev[2].a, ev[2].b)); t_chol += ms;
-            OSFM_HIP_CHECK(hipEventElapsedTime(&ms, ev[3].a, ev[3].b)); t_back += ms;
-            model_cost_change = h_scal[0];
-            step_norm = std::sqrt(h_scal[1] + h_scal[3]);
-            x_norm = std::sqrt(h_scal[2] + h_scal[4]);
-            cand_cost = h_scal[5];
-            const bool solve_ok = h_info[0] == 0 && std::isfinite(model_cost_change) && std::isfinite(step_norm);
-            step_valid = solve_ok && model_cost_change > 0.0;
+    // Small systems (a handful of cameras: the local adjustments of the incremental
+    // reconstruction) are bound by launch latency: the host runs a whole iteration ahead of
+    // what it knows and pays one row of do-nothing kernels at the end.  Large ones are bound
+    // by the device: there the host waits for the decision of iteration i (it has the
+    // linearisation of i still queued behind it, so the device does not idle) and never
+    // enqueues the 30+ Cholesky launches of an iteration that will not happen.
+    const bool eager = N / 32 <= 4;
+    LmDev fin;
+    memset(&fin, 0, sizeof(fin));
+    for (int it = 0; it < max_slots - 2; ++it) {
+        const int slot = it + 1;          // h_state[slot]: the state this iteration leaves
+        OSFM_RETURN_IF(tic(2));
+        if (nc > 0) launch_cholesky_solve(S.as<double>(), Lmat.as<double>(), nc, Ldiag.as<double>(), y_c.as<double>(), info.as<int>(), lm, s);
+        OSFM_RETURN_IF(toc());
+        OSFM_RETURN_IF(tic(3));
+        launch_cam_update(d, y_c.as<double>(), nullptr, part_cam.as<double>(), s);
+        BackPassArgs ba;
+        ba.y_c = y_c.as<double>(); ba.vinv = vinv.as<double>(); ba.ge = ge.as<double>(); ba.obsrec = obsrec.as<double>();
+        ba.points_out = nullptr; ba.partials = partB.as<double>();
+        launch_back_pass(d, ba, blocksM, s);
+        OSFM_RETURN_IF(toc());
+        launch_cost_pass(d, nullptr, nullptr, partC.as<double>(), blocksM, s);
+        launch_lm_decide(lm, prm, sc, s);
+        if (!eager) {
+            OSFM_HIP_CHECK(hipMemcpyAsync(&h_state[slot], lm, sizeof(LmDev), hipMemcpyDeviceToHost, s));
+            OSFM_HIP_CHECK(hipEventRecord(evs[slot], s));
         }
-        if (!step_valid) {
-            // HandleInvalidStep -> LevenbergMarquardtStrategy::StepIsInvalid
-            if (++invalid_steps >= o.max_consecutive_invalid_steps) { term = OSFM_BA_FAILURE; break; }
-            radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
-            sum->num_unsuccessful_steps++;
-            OSFM_RETURN_IF(linearize(false));
-            lin_failed = h_scal[2] != 0.0;
-            continue;
-        }
-        invalid_steps = 0;
-        if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
-
-        // ParameterToleranceReached / FunctionToleranceReached
-        if (step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) { term = OSFM_BA_CONVERGENCE_PARAMETER; break; }
-        const double cost_change = x_cost - cand_cost;
-        if (std::fabs(cost_change) <= o.function_tolerance * x_cost) { term = OSFM_BA_CONVERGENCE_FUNCTION; break; }
-
-        const double relative_decrease = cost_change / model_cost_change;
-        if (relative_decrease > o.min_relative_decrease) {
-            // HandleSuccessfulStep + LevenbergMarquardtStrategy::StepAccepted
-            set_current(cur ^ 1);
-            radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * relative_decrease - 1.0, 3));
-            radius = std::min(o.max_trust_region_radius, radius);
-            decrease_factor = 2.0; reuse_diagonal = false;
-            sum->num_successful_steps++;
-            last_successful = true;
-            OSFM_RETURN_IF(linearize(true));
-            reuse_diagonal = true;
-            x_cost = h_scal[0];
-            grad_max = std::max(h_scal[1], h_scal[3]);
+        OSFM_RETURN_IF(linearize());
+        launch_lm_post(lm, prm, sc, 0, s);
+        OSFM_HIP_CHECK(hipGetLastError());
+        if (eager) {
+            OSFM_HIP_CHECK(hipMemcpyAsync(&h_state[slot], lm, sizeof(LmDev), hipMemcpyDeviceToHost, s));
+            OSFM_HIP_CHECK(hipEventRecord(evs[slot], s));
+            if (it >= 1) {
+                // what iteration it - 1 left behind (this iteration is already queued after it)
+                OSFM_HIP_CHECK(hipEventSynchronize(evs[slot - 1]));
+                if (h_state[slot - 1].stop) break;
+            }
         } else {
-            // LevenbergMarquardtStrategy::StepRejected
-            radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
-            sum->num_unsuccessful_steps++;
-            OSFM_RETURN_IF(linearize(false));
+            OSFM_HIP_CHECK(hipEventSynchronize(evs[slot]));
+            if (h_state[slot].stop) break;
         }
-        lin_failed = h_scal[2] != 0.0;
-        if (o.verbose)
-            fprintf(stderr, "[osfm ba] it %d cost %.9e radius %.3e\n", iteration, x_cost, radius);
+    }
+    OSFM_HIP_CHECK(hipMemcpyAsync(&h_state[max_slots - 1], lm, sizeof(LmDev), hipMemcpyDeviceToHost, s));
+    OSFM_HIP_CHECK(hipStreamSynchronize(s));
+    fin = h_state[max_slots - 1];
+    if (fin.nonfinite) { set_error("ba_solve: non-finite initial cost"); return OSFM_E_NUMERIC; }
+    const int cur = fin.cur;
+    const double x_cost = fin.x_cost;
+    const int iteration = fin.iteration, term = fin.term;
+    sum->initial_cost = fin.initial_cost;
+    sum->num_successful_steps = fin.num_success;
+    sum->num_unsuccessful_steps = fin.num_unsuccess;
+    double t_point = 0, t_pair = 0, t_chol = 0, t_back = 0;
+    for (auto &pr : ev_pairs) {
+        float ms = 0.f;
+        if (pr.first + 1 >= ev_next + 1) continue;
+        OSFM_HIP_CHECK(hipEventElapsedTime(&ms, evs[pr.first], evs[pr.first + 1]));
+        (pr.second == 0 ? t_point : pr.second == 1 ? t_pair : pr.second == 2 ? t_chol : t_back) += ms;
     }
 
     sum->lm_loop_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count();
@@ -450,7 +446,8 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     sum->num_iterations = iteration;
     sum->termination = term;
     sum->point_pass_ms = t_point; sum->pair_pass_ms = t_pair; sum->cholesky_ms = t_chol; sum->back_pass_ms = t_back;
-    sum->linearizations = n_lin;
+    sum->linearizations = fin.num_success + fin.num_unsuccess + 1;   // the speculative ones past the end do nothing
+    (void)n_lin;
     sum->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return OSFM_OK;
 }

@@ -41,21 +41,34 @@ __device__ __forceinline__ double rsqrt_newton(double d)
     return y;
 }
 
-// One wave per workgroup.  Every workgroup factors the 32x32 diagonal block
-// with its rows held in registers (lane r = row r; the pivot column is
-// broadcast with v_readlane; pivots enter as reciprocal square roots),
-// workgroup 0 publishes the factor, the others solve X L_kk^T = A_ik for 64 rows
-// of the panel (lane = row, X in registers, L broadcast from LDS, stored
-// transposed so that two multipliers arrive per ds_read_b128).
-__global__ __launch_bounds__(64, 1) void
-chol_panel_kernel(double *A, int ld, int nblk, int k, double *Ldiag, int *info)
+// Factor of one 32 x 32 diagonal block by ONE wave, then inv(L_kk) for the neighbours'
+// triangular solves and the backward substitution.  The pivots form a serial chain, so
+// what counts is the latency of one link and the instructions hanging off it.  Lane r (and
+// its twin r + 32, which does the same work: no divergent code anywhere) holds row r in
+// registers.  Link j: the pivot comes by v_readlane, enters as a reciprocal square root
+// (v_rsq_f64 + two Newton steps; a sqrt and a divide are ~70 dependent instructions), the
+// scaled column goes to LDS once and comes back as broadcast ds_read_b128s, two
+// multipliers each (one v_readlane pair per multiplier was 2.5x the instructions).
+// Msrc: the block, row-major with leading dimension lds_ld, in LDS.  All 64 lanes of one
+// wave call this; workgroup barriers around it are the caller's.
+__device__ __forceinline__ double swap_halves(double v)
 {
-    __shared__ __attribute__((aligned(16))) double LsT[NB][NB];     // LsT[c][m] = L[m][c]
-    const int lane = threadIdx.x, r = lane & 31;
-    const double *Akk = A + (size_t)(k * NB + r) * ld + k * NB;
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap((unsigned)lo, (unsigned)lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap((unsigned)hi, (unsigned)hi, false, false);
+    // lanes 0-31 receive what lanes 32-63 held and vice versa
+    const int lane_hi = (int)(threadIdx.x & 63) >> 5;
+    return __hiloint2double(lane_hi ? (int)b[0] : (int)b[1], lane_hi ? (int)a[0] : (int)a[1]);
+}
+
+__device__ __forceinline__ void
+factor_diag_block(const double *Msrc, int lds_ld, double (*LsT)[NB], int kblock, double *Ldiag, int *info)
+{
+    __shared__ __attribute__((aligned(16))) double colbuf[2][NB];      // [pivot parity][row]
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     double L[NB], dinv[NB];
 #pragma unroll
-    for (int c = 0; c < NB; ++c) L[c] = Akk[c];
+    for (int c = 0; c < NB; ++c) L[c] = Msrc[r * lds_ld + c];
     int bad = 0;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -65,86 +78,151 @@ chol_panel_kernel(double *A, int ld, int nblk, int k, double *Ldiag, int *info)
         dinv[j] = rinv;
         const double lj = (r == j && bad == j + 1) ? 1.0 : L[j] * rinv;   // lane j: d / sqrt(d) = sqrt(d)
         L[j] = lj;
+        if (j + 1 < NB) {
+            colbuf[j & 1][r] = lj;          // both twins store the same value
+            // The LDS executes one wave's operations in order, so no wait is needed -- but the
+            // COMPILER must be told that other lanes wrote what this lane is about to read
+            // (without the fence it re-used values a lane had loaded two pivots earlier)
+            asm volatile("" ::: "memory");
 #pragma unroll
-        for (int c = j + 1; c < NB; ++c) L[c] -= lj * readlane_d(lj, c);   // meaningful for r >= c
-    }
-    if (blockIdx.x == 0) {
-        // Publishes inv(L_kk) for the backward substitution (a 32x32 product there
-        // instead of a 32-step chain).  Lane j solves L x = e_j for column j of the
-        // inverse: x stays in its own registers, the multipliers L[i][c] arrive as
-        // LDS broadcasts -- no cross-lane traffic in the chain.  This workgroup has
-        // no panel rows to solve, so the extra work hides behind the others.
-        if (bad && lane == 0) atomicMax(info, k * NB + bad);
-        if (lane < NB) {
-#pragma unroll
-            for (int c = 0; c < NB; ++c) LsT[r][c] = c <= r ? L[c] : 0.0;      // row-major here: LsT[i][c] = L[i][c]
+            for (int c = j + 1; c < NB; ++c) L[c] = fma(-lj, colbuf[j & 1][c], L[c]);   // meaningful for r >= c
         }
-        __syncthreads();
-        double x[NB];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            double acc = (i == r) ? 1.0 : 0.0;
-#pragma unroll
-            for (int c = 0; c < i; ++c) acc -= LsT[i][c] * x[c];
-            x[i] = acc * dinv[i];
-        }
-        if (lane < NB) {
-            double *Lk = Ldiag + (size_t)k * NB * NB;                          // [i][j] = inv(L)[i][j]
-#pragma unroll
-            for (int i = 0; i < NB; ++i) Lk[i * NB + r] = x[i];
-        }
-        return;
     }
-    if (lane < NB) {
+    if (bad && lane == 0) atomicMax(info, kblock * NB + bad);
+    // L, row-major, for the inverse: LsT[i][c] = L[i][c] (zero above the diagonal)
+    if (h == 0) {
 #pragma unroll
-        for (int c = 0; c < NB; ++c) LsT[c][r] = c <= r ? L[c] : 0.0;
+        for (int c = 0; c < NB; ++c) LsT[r][c] = c <= r ? L[c] : 0.0;
     }
-    __syncthreads();
-    const int row = (k + 1) * NB + (blockIdx.x - 1) * 64 + lane;
-    if (row >= (nblk + 1) * NB) return;
-    double *Ar = A + (size_t)row * ld + k * NB;
-    double X[NB];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // one wave: its LDS writes land in order
+    // inv(L): lane (j, h) solves L x = e_j, the two halves sharing every dot product
+    // (columns c of parity h each, folded with one swap)
+    double x[NB];
 #pragma unroll
-    for (int c = 0; c < NB; ++c) X[c] = Ar[c];
-    // right-looking forward substitution: once x_c is final, retire it from
-    // the later columns (keeps only X live and bounds the loads in flight)
+    for (int i = 0; i < NB; ++i) {
+        double acc = 0.0;
 #pragma unroll
-    for (int c = 0; c < NB; ++c) {
-        asm volatile("" ::: "memory");    // keep the LDS reads of step c behind step c-1
-        const double xc = X[c] * dinv[c];
-        X[c] = xc;
-#pragma unroll
-        for (int m = c + 1; m < NB; ++m) X[m] -= xc * LsT[c][m];
+        for (int c = 0; c < i; ++c)
+            if ((c & 1) == 0) { if (h == 0) acc = fma(-LsT[i][c], x[c], acc); }
+            else { if (h == 1) acc = fma(-LsT[i][c], x[c], acc); }
+        acc += swap_halves(acc);
+        x[i] = (acc + ((i == r) ? 1.0 : 0.0)) * dinv[i];
     }
+    if (h == 0) {
+        double *Lk = Ldiag + (size_t)kblock * NB * NB;                          // [i][j] = inv(L)[i][j]
 #pragma unroll
-    for (int c = 0; c < NB; ++c) Ar[c] = X[c];
+        for (int i = 0; i < NB; ++i) Lk[i * NB + r] = x[i];
+    }
 }
 
-__global__ __launch_bounds__(256) void
-chol_update_kernel(double *A, int ld, int nblk, int k)
+// Block 0: nothing to update, just the factor.
+__global__ __launch_bounds__(64, 1) void
+chol_first_kernel(const double *A, int ld, double *Ldiag, int *info, const LmDev *lm)
 {
-    // tile (i, j), k < j <= i <= nblk (i == nblk is the rhs block row, j < nblk)
+    if (lm && (lm->stop || lm->lin_failed)) return;
+    __shared__ __attribute__((aligned(16))) double M[NB][NB + 1];
+    __shared__ __attribute__((aligned(16))) double LsT[NB][NB];
+    const int lane = threadIdx.x, r = lane & 31;
+    if (lane < NB) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) M[r][c] = A[(size_t)r * ld + c];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    factor_diag_block(&M[0][0], NB + 1, LsT, 0, Ldiag, info);
+}
+
+// Step k of the right-looking factorisation as ONE launch: tile (i, j), k < j <= i <= nblk
+// (i == nblk: the right-hand side riding along), first turns its two panel blocks into L
+// itself -- L_ik = A_ik inv(L_kk)^T, a 32^3 product with the inverse the previous step left
+// in Ldiag, instead of waiting for a panel kernel to solve them -- then subtracts
+// L_ik L_jk^T.  The tiles of column k + 1 store their L_ik (the finished panel, into Lout: the
+// factor and the solved right-hand side live in a matrix of their own); tile
+// (k+1, k+1) goes on to factor itself and publish inv(L_{k+1,k+1}), so the next step can
+// start as soon as this launch ends: one kernel boundary per block column instead of two.
+__global__ __launch_bounds__(256) void
+chol_step_kernel(double *A, double *Lout, int ld, int nblk, int k, double *Ldiag, int *info, const LmDev *lm)
+{
+    if (lm && (lm->stop || lm->lin_failed)) return;
     const int j = k + 1 + blockIdx.x;
     const int i = k + 1 + blockIdx.y;
     if (j > i || j >= nblk) return;
-    __shared__ double Li[NB][NB + 1];
-    __shared__ double Lj[NB][NB + 1];
+    __shared__ __attribute__((aligned(16))) double Li[NB][NB + 1];      // inv(L_kk)
+    __shared__ __attribute__((aligned(16))) double Ai[NB][NB + 1];      // A_ik, then the updated diagonal tile
+    __shared__ __attribute__((aligned(16))) double Aj[NB][NB + 1];      // A_jk
+    __shared__ __attribute__((aligned(16))) double Xi[NB][NB + 1];      // L_ik
+    __shared__ __attribute__((aligned(16))) double Xj[NB][NB + 1];      // L_jk
+    __shared__ __attribute__((aligned(16))) double LsT[NB][NB];
     const int tid = threadIdx.x;
     const int r = tid >> 3, c0 = (tid & 7) * 4;
-    const double *Aik = A + (size_t)(i * NB) * ld + k * NB;
+    const double *Lk = Ldiag + (size_t)k * NB * NB;
+    double *Aik = A + (size_t)(i * NB) * ld + k * NB;
     const double *Ajk = A + (size_t)(j * NB) * ld + k * NB;
+    double *Aij = A + (size_t)(i * NB) * ld + j * NB;
+    double cur[4];
+#pragma unroll
     for (int c = 0; c < 4; ++c) {
-        Li[r][c0 + c] = Aik[(size_t)r * ld + c0 + c];
-        Lj[r][c0 + c] = Ajk[(size_t)r * ld + c0 + c];
+        Li[r][c0 + c] = Lk[r * NB + c0 + c];
+        Ai[r][c0 + c] = Aik[(size_t)r * ld + c0 + c];
+        Aj[r][c0 + c] = Ajk[(size_t)r * ld + c0 + c];
+        cur[c] = Aij[(size_t)r * ld + c0 + c];
     }
     __syncthreads();
-    double *Aij = A + (size_t)(i * NB) * ld + j * NB;
-    double acc[4] = { 0, 0, 0, 0 };
+    // L_ik[r][c] = sum_{m <= c} A_ik[r][m] inv(L)[c][m]   (inv(L) is lower triangular)
+    double xi[4] = {0, 0, 0, 0}, xj[4] = {0, 0, 0, 0};
+#pragma unroll
     for (int m = 0; m < NB; ++m) {
-        const double a = Li[r][m];
-        for (int c = 0; c < 4; ++c) acc[c] += a * Lj[c0 + c][m];
+        const double ai = Ai[r][m], aj = Aj[r][m];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double l = Li[c0 + c][m];         // zero above the diagonal
+            xi[c] = fma(ai, l, xi[c]);
+            xj[c] = fma(aj, l, xj[c]);
+        }
     }
-    for (int c = 0; c < 4; ++c) Aij[(size_t)r * ld + c0 + c] -= acc[c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { Xi[r][c0 + c] = xi[c]; Xj[r][c0 + c] = xj[c]; }
+    if (j == k + 1) {
+        // the finished panel block goes to the factor's own matrix: A_ik itself is still being
+        // read (unsolved) by the other tiles of row i in this launch
+        double *Lik = Lout + (size_t)(i * NB) * ld + k * NB;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Lik[(size_t)r * ld + c0 + c] = xi[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+        const double a = Xi[r][m];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cur[c] = fma(-a, Xj[c0 + c][m], cur[c]);
+    }
+    const bool next_diag = i == k + 1 && j == k + 1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        Aij[(size_t)r * ld + c0 + c] = cur[c];
+        if (next_diag) Ai[r][c0 + c] = cur[c];
+    }
+    if (!next_diag) return;
+    __syncthreads();
+    if (tid < 64) factor_diag_block(&Ai[0][0], NB + 1, LsT, k + 1, Ldiag, info);
+}
+
+// The right-hand side's last block: y_k = b_k inv(L_kk)^T for k = nblk - 1 (every earlier
+// block of the row is solved by the step that finishes its panel column).
+__global__ __launch_bounds__(64) void
+chol_rhs_tail_kernel(const double *A, double *Lout, int ld, int nblk, const double *Ldiag, const LmDev *lm)
+{
+    if (lm && (lm->stop || lm->lin_failed)) return;
+    const int k = nblk - 1, c = threadIdx.x;
+    if (c >= NB) return;
+    const double *y = A + (size_t)(nblk * NB) * ld + k * NB;
+    const double *Lk = Ldiag + (size_t)k * NB * NB;
+    double acc = 0.0;
+    double b[NB];
+#pragma unroll
+    for (int m = 0; m < NB; ++m) b[m] = y[m];
+#pragma unroll
+    for (int m = 0; m < NB; ++m) acc = fma(b[m], m <= c ? Lk[c * NB + m] : 0.0, acc);
+    Lout[(size_t)(nblk * NB) * ld + k * NB + c] = acc;
 }
 
 // x = L^-T y with y in row N (= nblk * NB) of A; result written to x[0..n).
@@ -160,8 +238,9 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 __global__ __launch_bounds__(1024) void
-chol_backsolve_kernel(const double *A, int ld, int nblk, int n, const double *Ldiag, double *x)
+chol_backsolve_kernel(const double *A, int ld, int nblk, int n, const double *Ldiag, double *x, const LmDev *lm)
 {
+    if (lm && (lm->stop || lm->lin_failed)) return;
     extern __shared__ double ys[];           // y [N], then x [N]
     __shared__ double xk[NB];
     __shared__ double Li[NB][NB];            // inv(L_kk), row-major
@@ -211,19 +290,22 @@ int cholesky_padded_dim(int n) { return (n + NB - 1) / NB * NB; }
 
 // A: (N + 32) x N row-major, rows/cols >= n padded with identity, rhs in row N.
 // Ldiag: N * 32 doubles of scratch for the inverses of the factored diagonal blocks.
-void launch_cholesky_solve(double *A, int n, double *Ldiag, double *x, int *info, hipStream_t s)
+void launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double *x, int *info, const LmDev *lm, hipStream_t s)
 {
     const int N = cholesky_padded_dim(n);
     const int nblk = N / NB;
+    hipLaunchKernelGGL(chol_first_kernel, dim3(1), dim3(64), 0, s, A, N, Ldiag, info, lm);
     for (int k = 0; k < nblk; ++k) {
-        const int below = (nblk - k) * NB;      // rows under the diagonal block (incl. the rhs block row)
-        hipLaunchKernelGGL(chol_panel_kernel, dim3(1 + (below + 63) / 64), dim3(64), 0, s, A, N, nblk, k, Ldiag, info);
+        // tiles (i, j), k < j <= i <= nblk, j < nblk: for k = nblk - 1 only the right-hand-side
+        // row is left, and it has no tile with j < nblk: its forward substitution is the
+        // triangular solve of the rhs block against every column, done by the steps before
         const int t = nblk - k - 1;
         if (t > 0)
-            hipLaunchKernelGGL(chol_update_kernel, dim3(t, t + 1), dim3(256), 0, s, A, N, nblk, k);
+            hipLaunchKernelGGL(chol_step_kernel, dim3(t, t + 1), dim3(256), 0, s, A, Lmat, N, nblk, k, Ldiag, info, lm);
     }
-    hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(1024), (size_t)2 * N * sizeof(double), s, A, N,
-        nblk, n, Ldiag, x);
+    hipLaunchKernelGGL(chol_rhs_tail_kernel, dim3(1), dim3(64), 0, s, A, Lmat, N, nblk, Ldiag, lm);
+    hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(1024), (size_t)2 * N * sizeof(double), s, Lmat, N,
+        nblk, n, Ldiag, x, lm);
 }
 
 }  // namespace osfm

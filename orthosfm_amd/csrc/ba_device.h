@@ -20,10 +20,30 @@ namespace osfm {
 
 enum { kModelQuat = 0, kModelEuler = 1 };
 
+// Levenberg-Marquardt state, device resident: the accept / reject decisions of
+// ceres::TrustRegionMinimizer are taken by a one-workgroup kernel at the end of every
+// iteration, the kernels of the next iteration read what it decided (which of the two
+// iterate buffers is current, the radius, whether to refresh the LM diagonal), and the
+// host only looks at `stop` -- one iteration late, so the queue never runs dry.
+struct LmDev {
+    double radius, decrease_factor, x_cost, grad_max;
+    double cand_cost, model_cost_change, step_norm, x_norm;
+    double initial_cost;
+    int32_t cur;                 // index of the current iterate in cams2 / points2
+    int32_t iteration, term, stop;
+    int32_t num_success, num_unsuccess, invalid_steps, last_successful;
+    int32_t update_diag, want_gradient, lin_failed, nonfinite;
+};
+
 struct BaDev {
     int model, C, M, O, nc, pdim;
     const double *cams;          // [C][7]
     const double *points;        // [M][4]
+    // LM solve: both iterate buffers and the state that says which one is current
+    // (lm == nullptr: cams / points above are used as they are)
+    double *cams2[2];
+    double *points2[2];
+    const LmDev *lm;
     const double *obs_xy;        // [O][2]
     const int32_t *obs_cam;      // [O]
     const int32_t *obs_pt;       // [O]
@@ -36,6 +56,18 @@ struct BaDev {
     const double *scale_p;       // [3M]
     double huber;
 };
+
+// The iterate the LM state points at (kernels of the solve call this first; a stopped solve
+// makes them return at once: the host enqueues one iteration ahead of what it knows).
+__device__ __forceinline__ bool lm_resolve(BaDev &d)
+{
+    if (!d.lm) return true;
+    if (d.lm->stop) return false;
+    const int cur = d.lm->cur;
+    d.cams = d.cams2[cur];
+    d.points = d.points2[cur];
+    return true;
+}
 
 // Residual (uncorrected) and FULL tangent Jacobians of one observation:
 //   Jc[2][6]: QUAT  columns = (rot d0, d1, d2, offX, offY, scale)

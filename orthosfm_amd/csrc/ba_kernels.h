@@ -55,9 +55,32 @@ struct BackPassArgs {
     double *partials;         // [3][blocks]: model cost change, |dx|^2, |x|^2
 };
 
+// Tolerances and limits of the LM loop (ceres::Solver::Options as set in
+// bundle_adjustment.cpp:126-133 plus the defaults it leaves alone).
+struct LmParams {
+    double function_tolerance, gradient_tolerance, parameter_tolerance;
+    double min_relative_decrease, max_radius, min_radius;
+    int32_t max_iterations, max_invalid_steps;
+};
+
+// scratch the decision kernels reduce: per-block partials of the passes
+struct LmScratch {
+    const double *partA;     // [3][blocksM]  point pass: cost, gradient max, not-PD flag
+    const double *partB;     // [3][blocksM]  back pass: model cost change, |dx|^2, |x|^2
+    const double *partC;     // [blocksM]     cost pass: candidate cost
+    const double *part_cam;  // [C][2]        camera update: |dx|^2, |x|^2
+    const double *gmax_cam;  // [C]           camera gradient norms
+    int32_t *chol_info;      // [1]           first non-positive pivot + 1 (reset after reading)
+    int32_t blocksM, C;
+};
+
+void launch_lm_decide(LmDev *lm, const LmParams &prm, const LmScratch &sc, hipStream_t s);
+void launch_lm_post(LmDev *lm, const LmParams &prm, const LmScratch &sc, int initial, hipStream_t s);
+
 void launch_point_pass(const BaDev &d, const PointPassArgs &a, int blocks, hipStream_t s);
 void launch_pair_pass(const BaDev &d, const PairPassArgs &a, hipStream_t s);
 void launch_cam_gradient(const BaDev &d, const PairPassArgs &a, double *gmax_out, hipStream_t s);
+// cams_out == nullptr (LM solve): the candidate goes to the iterate buffer that is not current
 void launch_cam_update(const BaDev &d, const double *y_c, double *cams_out, double *partials_cam, hipStream_t s);
 void launch_back_pass(const BaDev &d, const BackPassArgs &a, int blocks, hipStream_t s);
 void launch_cost_pass(const BaDev &d, const double *cams, const double *points, double *partials,
@@ -86,6 +109,9 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
 
 // dense Cholesky solve of the reduced camera system (ba_cholesky.hip)
 int cholesky_padded_dim(int n);
-void launch_cholesky_solve(double *A, int n, double *Ldiag, double *x, int *info, hipStream_t s);
+// lm != nullptr: nothing happens when the solve has stopped or the last linearisation failed
+// Lmat: (N + 32) x N scratch for the factor and the solved right-hand side (A keeps the
+// reduced system's trailing updates)
+void launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double *x, int *info, const LmDev *lm, hipStream_t s);
 
 }  // namespace osfm

@@ -124,6 +124,11 @@ ba_point_pass_kernel(BaDev dg, PointPassArgs a, int staged)
 {
     extern __shared__ __attribute__((aligned(16))) char cam_lds[];
     __shared__ double sh[4];
+    if (!lm_resolve(dg)) return;
+    if (dg.lm && a.mode == kPassNormal) {
+        // the LM state decides what this linearisation is for
+        a.radius = dg.lm->radius; a.update_diag = dg.lm->update_diag; a.want_gradient = dg.lm->want_gradient;
+    }
     const double *cams = dg.cams;
     const BaDev d = stage_cameras(dg, cam_lds, staged != 0, cams, nullptr);
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
@@ -228,6 +233,8 @@ void launch_point_pass(const BaDev &d, const PointPassArgs &a, int blocks, hipSt
 __global__ __launch_bounds__(256) void
 ba_pair_pass_kernel(BaDev d, PairPassArgs a)
 {
+    if (!lm_resolve(d)) return;
+    if (d.lm && a.mode == kPassNormal) { a.radius = d.lm->radius; a.update_diag = d.lm->update_diag; }
     const int lane = threadIdx.x & 63;
     const int pi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (pi >= a.num_pairs) return;
@@ -350,6 +357,8 @@ void launch_pair_pass(const BaDev &d, const PairPassArgs &a, hipStream_t s)
 __global__ __launch_bounds__(256) void
 ba_cam_gradient_kernel(BaDev d, PairPassArgs a, double *gmax_out)
 {
+    if (!lm_resolve(d)) return;
+    if (d.lm && !d.lm->want_gradient) return;
     const int lane = threadIdx.x & 63;
     const int pi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (pi >= a.num_pairs) return;
@@ -399,6 +408,8 @@ void launch_cam_gradient(const BaDev &d, const PairPassArgs &a, double *gmax_out
 __global__ void
 ba_cam_update_kernel(BaDev d, const double *y_c, double *cams_out, double *partials_cam)
 {
+    if (!lm_resolve(d)) return;
+    if (d.lm) { if (d.lm->lin_failed) return; cams_out = d.cams2[d.lm->cur ^ 1]; }
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.C) return;
     const double *cam = d.cams + 7 * c;
@@ -444,6 +455,8 @@ ba_back_pass_kernel(BaDev dg, BackPassArgs a, int staged)
 {
     extern __shared__ __attribute__((aligned(16))) char cam_lds[];
     __shared__ double sh[4];
+    if (!lm_resolve(dg)) return;
+    if (dg.lm) { if (dg.lm->lin_failed) return; a.points_out = dg.points2[dg.lm->cur ^ 1]; }
     const double *cams = dg.cams;
     const BaDev d = stage_cameras(dg, cam_lds, staged != 0, cams, &a.y_c);
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
@@ -524,6 +537,11 @@ ba_cost_pass_kernel(BaDev dg, const double *cams, const double *points, double *
 {
     extern __shared__ __attribute__((aligned(16))) char cam_lds[];
     __shared__ double sh[4];
+    if (dg.lm) {
+        // LM solve: the cost of the CANDIDATE (the iterate buffer that is not current)
+        if (dg.lm->stop || dg.lm->lin_failed) return;
+        cams = dg.cams2[dg.lm->cur ^ 1]; points = dg.points2[dg.lm->cur ^ 1];
+    }
     const BaDev d = stage_cameras(dg, cam_lds, staged != 0, cams, nullptr);
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = gt / kPointLanes, sub = gt % kPointLanes;
@@ -599,6 +617,127 @@ ba_max_reduce_kernel(const double *v, int n, double *out)
         __syncthreads();
     }
     if (threadIdx.x == 0) *out = sh[0];
+}
+
+// ---------------------------------------------------------------------------
+// LM control on the device.  Fixed-order reductions of the per-block partials, then the
+// decisions of TrustRegionMinimizer / LevenbergMarquardtStrategy by thread 0.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double block_reduce_256(double v, bool is_max, double *sh)
+{
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st)
+            sh[threadIdx.x] = is_max ? fmax(sh[threadIdx.x], sh[threadIdx.x + st]) : sh[threadIdx.x] + sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ double strided_reduce(const double *p, int n, int stride, bool is_max, double *sh)
+{
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double x = p[(size_t)i * stride];
+        v = is_max ? fmax(v, x) : v + x;
+    }
+    return block_reduce_256(v, is_max, sh);
+}
+
+// After the candidate of an iteration has been evaluated: step validity, the parameter /
+// function tolerance tests, accept or reject, the new radius, and what the linearisation
+// that follows has to do.
+__global__ __launch_bounds__(256) void
+ba_lm_decide_kernel(LmDev *lm, LmParams prm, LmScratch sc)
+{
+    __shared__ double sh[256];
+    if (lm->stop) return;
+    const bool solved = !lm->lin_failed;
+    double mcc = 0.0, sn = 0.0, xn = 0.0, cand = 0.0;
+    if (solved) {
+        mcc = strided_reduce(sc.partB, sc.blocksM, 1, false, sh);
+        sn = strided_reduce(sc.partB + sc.blocksM, sc.blocksM, 1, false, sh) + strided_reduce(sc.part_cam, sc.C, 2, false, sh);
+        xn = strided_reduce(sc.partB + 2 * (size_t)sc.blocksM, sc.blocksM, 1, false, sh) + strided_reduce(sc.part_cam + 1, sc.C, 2, false, sh);
+        cand = strided_reduce(sc.partC, sc.blocksM, 1, false, sh);
+    }
+    if (threadIdx.x != 0) return;
+    const int info = *sc.chol_info;
+    *sc.chol_info = 0;
+    const double step_norm = sqrt(sn), x_norm = sqrt(xn);
+    lm->model_cost_change = mcc; lm->step_norm = step_norm; lm->x_norm = x_norm; lm->cand_cost = cand;
+    const bool solve_ok = solved && info == 0 && isfinite(mcc) && isfinite(step_norm);
+    const bool step_valid = solve_ok && mcc > 0.0;
+    if (!step_valid) {
+        // HandleInvalidStep -> LevenbergMarquardtStrategy::StepIsInvalid
+        if (++lm->invalid_steps >= prm.max_invalid_steps) { lm->term = OSFM_BA_FAILURE; lm->stop = 1; return; }
+        lm->radius = lm->radius / lm->decrease_factor; lm->decrease_factor *= 2.0;
+        lm->num_unsuccess++;
+        lm->update_diag = 0; lm->want_gradient = 0;
+        return;
+    }
+    lm->invalid_steps = 0;
+    if (!isfinite(cand)) cand = 1.7976931348623157e308;
+    // ParameterToleranceReached / FunctionToleranceReached
+    if (step_norm <= prm.parameter_tolerance * (x_norm + prm.parameter_tolerance)) { lm->term = OSFM_BA_CONVERGENCE_PARAMETER; lm->stop = 1; return; }
+    const double cost_change = lm->x_cost - cand;
+    if (fabs(cost_change) <= prm.function_tolerance * lm->x_cost) { lm->term = OSFM_BA_CONVERGENCE_FUNCTION; lm->stop = 1; return; }
+    const double relative_decrease = cost_change / mcc;
+    if (relative_decrease > prm.min_relative_decrease) {
+        // HandleSuccessfulStep + LevenbergMarquardtStrategy::StepAccepted
+        lm->cur ^= 1;
+        const double t = 2.0 * relative_decrease - 1.0;
+        lm->radius = fmin(prm.max_radius, lm->radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+        lm->decrease_factor = 2.0;
+        lm->num_success++;
+        lm->last_successful = 1;
+        lm->update_diag = 1; lm->want_gradient = 1;
+    } else {
+        // LevenbergMarquardtStrategy::StepRejected
+        lm->radius = lm->radius / lm->decrease_factor; lm->decrease_factor *= 2.0;
+        lm->num_unsuccess++;
+        lm->update_diag = 0; lm->want_gradient = 0;
+    }
+}
+
+// After a linearisation: cost / gradient norm of a new iterate, the not-positive-definite
+// flag, then FinalizeIterationAndCheckIfMinimizerCanContinue for the iteration that follows.
+__global__ __launch_bounds__(256) void
+ba_lm_post_kernel(LmDev *lm, LmParams prm, LmScratch sc, int initial)
+{
+    __shared__ double sh[256];
+    if (lm->stop) return;
+    const double cost = strided_reduce(sc.partA, sc.blocksM, 1, false, sh);
+    const double gp = strided_reduce(sc.partA + sc.blocksM, sc.blocksM, 1, true, sh);
+    const double bad = strided_reduce(sc.partA + 2 * (size_t)sc.blocksM, sc.blocksM, 1, true, sh);
+    const double gc = strided_reduce(sc.gmax_cam, sc.C, 1, true, sh);
+    if (threadIdx.x != 0) return;
+    if (lm->want_gradient) { lm->x_cost = cost; lm->grad_max = fmax(gp, gc); }
+    lm->lin_failed = bad != 0.0 ? 1 : 0;
+    if (initial) {
+        lm->initial_cost = cost;
+        if (!isfinite(cost)) { lm->nonfinite = 1; lm->term = OSFM_BA_FAILURE; lm->stop = 1; return; }
+        if (lm->grad_max <= prm.gradient_tolerance) { lm->term = OSFM_BA_CONVERGENCE_GRADIENT; lm->stop = 1; return; }
+    }
+    // the LM diagonal is refreshed by the linearisation that follows an accepted step only
+    lm->update_diag = 0; lm->want_gradient = 0;
+    if (lm->iteration >= prm.max_iterations) { lm->term = OSFM_BA_NO_CONVERGENCE; lm->stop = 1; return; }
+    if (lm->last_successful && lm->grad_max <= prm.gradient_tolerance) { lm->term = OSFM_BA_CONVERGENCE_GRADIENT; lm->stop = 1; return; }
+    if (lm->radius <= prm.min_radius) { lm->term = OSFM_BA_CONVERGENCE_TRUST_REGION; lm->stop = 1; return; }
+    lm->iteration++;
+    lm->last_successful = 0;
+}
+
+void launch_lm_decide(LmDev *lm, const LmParams &prm, const LmScratch &sc, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_lm_decide_kernel, dim3(1), dim3(256), 0, s, lm, prm, sc);
+}
+
+void launch_lm_post(LmDev *lm, const LmParams &prm, const LmScratch &sc, int initial, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_lm_post_kernel, dim3(1), dim3(256), 0, s, lm, prm, sc, initial);
 }
 
 // identity on the padding diagonal of the (zeroed) reduced system

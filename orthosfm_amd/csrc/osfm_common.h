@@ -71,6 +71,28 @@ struct StreamSet {
     int device = -1;
     hipStream_t s = nullptr;
     EventPair ev[4];
+    // page-locked host scratch (the LM state lands here, one slot per iteration) and events
+    // created on demand; both live as long as the set and are reused by later calls
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
+    std::vector<hipEvent_t> events;
+    int ensure_pinned(size_t bytes)
+    {
+        if (bytes <= pinned_bytes) return OSFM_OK;
+        if (pinned) { (void)hipHostFree(pinned); pinned = nullptr; pinned_bytes = 0; }
+        OSFM_HIP_CHECK(hipHostMalloc(&pinned, bytes, hipHostMallocDefault));
+        pinned_bytes = bytes;
+        return OSFM_OK;
+    }
+    int ensure_events(size_t n)
+    {
+        while (events.size() < n) {
+            hipEvent_t e = nullptr;
+            OSFM_HIP_CHECK(hipEventCreate(&e));
+            events.push_back(e);
+        }
+        return OSFM_OK;
+    }
 };
 inline std::mutex g_stream_pool_mutex;
 inline std::vector<StreamSet *> g_stream_pool;

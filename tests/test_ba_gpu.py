@@ -265,5 +265,6 @@ def test_cpp_adapter_equals_python_mirror(ba, model, retri, tmp_path):
         assert np.array_equal(c.params()[:6], row[:6])
     for t, row in zip(py_t, pt_rows):
         assert bool(int(row[0])) == bool(t.has_point)
-        assert np.array_equal(np.asarray(t.point, dtype=np.float64), np.array(row[1:], dtype=np.float64))
+        if t.has_point:           # a track without a point has no value to compare (the double holds zeros)
+            assert np.array_equal(np.asarray(t.point, dtype=np.float64), np.array(row[1:], dtype=np.float64))
     assert "Average point change" in out.stdout
