@@ -30,7 +30,8 @@ typedef enum osfm_status {
     OSFM_E_RANGE = -3,     /* descriptor value outside the quantised range */
     OSFM_E_CAPACITY = -4,  /* caller buffer too small; required size reported */
     OSFM_E_STATE = -5,     /* call order violated (e.g. view not set) */
-    OSFM_E_NUMERIC = -6    /* BA: linear solve failed / non-finite values */
+    OSFM_E_NUMERIC = -6,   /* BA: linear solve failed / non-finite values */
+    OSFM_E_IO = -7         /* text formats: file cannot be opened / malformed line */
 } osfm_status;
 
 OSFM_API const char *osfm_last_error(void);
@@ -455,6 +456,79 @@ OSFM_API int osfm_build_groups(int device, int32_t num_views, const int32_t *vie
     int32_t num_tracks, const int64_t *track_offsets, const int32_t *track_views,
     int32_t group_size, int32_t max_groups, int32_t *groups, int32_t *group_tracks,
     int32_t *num_groups);
+
+/* ---------------------------------------------------------------------------
+ * On-disk text formats of the pipeline either side of the path (SURVEY 8f rank
+ * 4): what `orthosfm-app --calculated-tracks` reads and the testbench parses.
+ * Host code.  Numbers are written by the same C++ stream operations the
+ * reference uses (`ostream << float/double/unsigned`, `std::to_string(double)`),
+ * so the bytes agree by construction.  Files that cannot be opened and lines
+ * that do not parse give OSFM_E_IO (the reference's std::stoi/stod throw there).
+ * ------------------------------------------------------------------------- */
+
+/* orthosfm::Feature (src/data_structures/track.h:21-31), one record per track feature */
+typedef struct osfm_track_feature {
+    uint32_t view_id, local_feature_id, global_feature_id;
+    float x, y;                   /* pixel coordinates */
+    uint32_t r, g, b;
+} osfm_track_feature;
+
+/* saveTracksToFile (src/matching/matching_io.cpp:16-48): one line per track,
+ * "count;view;local;global;x;y;r;g;b;view;..." -- tracks as CSR over features. */
+OSFM_API int osfm_tracks_file_write(const char *path, int64_t num_tracks,
+    const int64_t *track_offsets, const osfm_track_feature *features);
+
+/* loadTracksFromFile (matching_io.cpp:50-97).  *num_tracks / *num_features are
+ * always set to what the file holds; with capacities below that the call fails
+ * with OSFM_E_CAPACITY and writes nothing else (call once with 0 capacities to
+ * size the buffers).  track_offsets takes num_tracks + 1 entries. */
+OSFM_API int osfm_tracks_file_read(const char *path, int64_t track_capacity,
+    int64_t feature_capacity, int64_t *track_offsets, osfm_track_feature *features,
+    int64_t *num_tracks, int64_t *num_features);
+
+/* saveTracksToPairwiseFiles (matching_io.cpp:99-141): for every pair i < j of
+ * view_ids the tracks reduced to exactly those two views
+ * (filterTracksToAvailableCameras(ids, tracks, true, false), common.cpp:85-138),
+ * one line "x_i y_i x_j y_j" each, in `folder`/%03d_%03d.txt; no file for a pair
+ * without such tracks.  *files_written (may be NULL) counts the files. */
+OSFM_API int osfm_tracks_pairwise_files_write(const char *folder, int32_t num_views,
+    const uint32_t *view_ids, int64_t num_tracks, const int64_t *track_offsets,
+    const osfm_track_feature *features, int64_t *files_written);
+
+/* MVE tracks -> orthosfm tracks (src/matching/matching_mve.cpp:455-466):
+ * feature (v, f) of an MVE track becomes Feature(v, f, 32768 v + f,
+ * width (pos.x + 0.5), width (pos.y + 0.5)) -- the reference scales BOTH axes by
+ * the image width -- with the feature's colour.
+ *   track_features [num_features][2]  (view, feature), osfm_tracks_compute's output
+ *   view_starts    [num_views + 1]    first row of each view in positions / colors
+ *   positions      [..][2] float      FeatureSet::positions, views concatenated
+ *   colors         [..][3]            FeatureSet::colors (NULL: 0) */
+OSFM_API int osfm_tracks_from_mve(int64_t num_features, const int32_t *track_features,
+    int32_t num_views, const int64_t *view_starts, const float *positions,
+    const uint8_t *colors, double image_width, osfm_track_feature *features);
+
+/* exportCamerasToFile / importCameraFileAsMatrix
+ * (src/data_structures/camera_io.cpp:15-40, :42-71): "name;m00,m01,...,m33" with
+ * the row-major 4x4 camera-to-world matrix [x y z origin; 0 0 0 1] in
+ * std::to_string format.  Reading: names come back NUL-separated in names_buf;
+ * *num_cameras / *names_bytes are always set, OSFM_E_CAPACITY as above. */
+OSFM_API int osfm_cameras_file_write(const char *path, int32_t num_cameras,
+    const char *const *image_names, const double *matrices);
+OSFM_API int osfm_cameras_file_read(const char *path, int32_t camera_capacity,
+    int64_t names_capacity, char *names_buf, double *matrices, int32_t *num_cameras,
+    int64_t *names_bytes);
+
+/* savePointsToPLY (src/util/common.cpp:141-188): ASCII PLY of the tracks that
+ * have a point (has_point[t] != 0), xyz of the homogeneous point as written by
+ * `ostream << double`, colour of the track's first feature. */
+OSFM_API int osfm_sparse_cloud_write(const char *path, int64_t num_tracks,
+    const int64_t *track_offsets, const osfm_track_feature *features,
+    const double *points, const uint8_t *has_point);
+
+/* saveRuntimesToTxt / runtimesFromTxt (src/util/timing.cpp:18-53); seconds[4] =
+ * initialisation, track building, pose estimation, total. */
+OSFM_API int osfm_time_measurements_write(const char *path, const double *seconds);
+OSFM_API int osfm_time_measurements_read(const char *path, double *seconds);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ class OsfmError(RuntimeError):
         self.status = status
 
 
-OK, E_ARG, E_DEVICE, E_RANGE, E_CAPACITY, E_STATE, E_NUMERIC = 0, -1, -2, -3, -4, -5, -6
+OK, E_ARG, E_DEVICE, E_RANGE, E_CAPACITY, E_STATE, E_NUMERIC, E_IO = 0, -1, -2, -3, -4, -5, -6, -7
 MATCHER_EXHAUSTIVE, MATCHER_CASCADE_HASHING = 0, 1
 PAIR_MATCHED, PAIR_REJECTED_LOWRES, PAIR_REJECTED_COUNT, PAIR_SKIPPED_EMPTY, PAIR_REJECTED_INLIERS = 0, 1, 2, 3, 4
 
@@ -124,7 +124,14 @@ EXPORTS = [
     "osfm_ba_triangulate",
     "osfm_nn_distances", "osfm_filter_outlier_tracks", "osfm_filter_reprojection",
     "osfm_tracks_compute", "osfm_tracks_compute_ranges", "osfm_build_groups",
+    "osfm_tracks_file_write", "osfm_tracks_file_read", "osfm_tracks_pairwise_files_write",
+    "osfm_tracks_from_mve", "osfm_cameras_file_write", "osfm_cameras_file_read",
+    "osfm_sparse_cloud_write", "osfm_time_measurements_write", "osfm_time_measurements_read",
 ]
+
+# osfm_track_feature as a numpy record (32 bytes, no padding)
+TRACK_FEATURE = np.dtype([("view_id", "<u4"), ("local_feature_id", "<u4"), ("global_feature_id", "<u4"),
+                          ("x", "<f4"), ("y", "<f4"), ("r", "<u4"), ("g", "<u4"), ("b", "<u4")])
 
 lib.osfm_last_error.restype = C.c_char_p
 lib.osfm_version.restype = C.c_int

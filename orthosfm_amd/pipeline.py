@@ -32,6 +32,7 @@ triangulation, reprojection errors, LM -- happens behind the C ABI.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import time
 from dataclasses import dataclass, field
 
@@ -538,3 +539,44 @@ def reconstruct(iset, solver=0, matcher="exhaustive", device=0, verify=True, rot
         euler_dof=euler_dof_of_solver(solver))
     tm.total_s = time.perf_counter() - t_all
     return Result(cams, aligned, tt, groups, tm, calls, captured=captured, **info)
+
+
+CAMERA_DISTANCE = 10.0                  # OrthoQuaternionCamera.cpp:70, OrthographicCamera.h:119
+
+
+def camera_to_world_matrices(model, cam_params):
+    """The 4x4 matrices exportCamerasToFile writes (camera_io.cpp:24-29):
+    columns x axis, y axis, z axis, origin = R (0, 0, -10)."""
+    out = np.zeros((len(cam_params), 4, 4))
+    for i, p in enumerate(cam_params):
+        R = _cam_rotation(model, p)
+        out[i, :3, :3] = R
+        out[i, :3, 3] = R @ np.array([0.0, 0.0, -CAMERA_DISTANCE])
+        out[i, 3, 3] = 1.0
+    return out
+
+
+def save_project(res: Result, model, folder, image_names=None):
+    """The files orthosfm::reconstruct leaves in the project folder (reconstruct.cpp:125,
+    :160, :168, :290), written through the C ABI of the text formats: tracks.txt (all
+    tracks, as built), cameras.txt (aligned cameras), sparse_cloud.ply (surviving tracks
+    with a point), time_measurements.txt."""
+    from . import formats as F
+    os.makedirs(folder, exist_ok=True)
+    tt = res.tracks
+    feats = np.zeros(tt.view.shape[0], dtype=capi.TRACK_FEATURE)
+    feats["view_id"] = tt.view
+    feats["local_feature_id"] = tt.feat
+    feats["global_feature_id"] = 32768 * tt.view.astype(np.int64) + tt.feat
+    feats["x"] = tt.xy[:, 0]
+    feats["y"] = tt.xy[:, 1]
+    F.save_tracks_to_file_native(tt.offsets, feats, os.path.join(folder, "tracks.txt"))
+    names = image_names or ["view_%04d" % v for v in range(tt.num_views)]
+    al = list(res.aligned_views)
+    F.export_cameras_to_file_native([names[v] for v in al], camera_to_world_matrices(model, res.cam_params[al]),
+                                    os.path.join(folder, "cameras.txt"))
+    F.save_points_to_ply_native(os.path.join(folder, "sparse_cloud.ply"), tt.offsets, feats, tt.point,
+                                tt.has_point & tt.alive_t)
+    tm = res.timings
+    F.save_runtimes_to_txt_native(os.path.join(folder, "time_measurements.txt"), tm.upload_s,
+                                  tm.matching_s + tm.tracks_s + tm.convert_s, tm.groups_s + tm.pose_s, tm.total_s)

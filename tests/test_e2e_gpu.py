@@ -6,6 +6,8 @@ Checked here: (1) the track count equals the CPU path's -- oracle matcher + orac
 RANSAC (same sample streams) + the reference's own Tracks::compute when oracle/_ref
 travelled -- on the same views; (2) both camera models come back to the ground truth
 from perturbed starts; (3) the schedule issued the calls reconstruct.cpp would."""
+import os
+
 import numpy as np
 import pytest
 
@@ -86,6 +88,34 @@ def test_reconstruct_small_set(iset, solver):
     assert np.abs(shift[:2]).max() < 1e-4
     assert np.median(np.linalg.norm(d - shift, axis=1)) < 1e-4
     assert res.timings.total_s > 0 and res.timings.pose_s > 0
+    if solver == 0:
+        _check_project_files(res, model, iset)
+
+
+def _check_project_files(res, model, iset):
+    """The project folder orthosfm::reconstruct leaves (reconstruct.cpp:125,:160,:168,:290),
+    written through the C ABI of the text formats and read back."""
+    import tempfile
+    from orthosfm_amd import formats as F, pipeline as P
+    with tempfile.TemporaryDirectory() as d:
+        P.save_project(res, model, d)
+        off, feats = F.load_tracks_from_file_native(os.path.join(d, "tracks.txt"))
+        tt = res.tracks
+        assert np.array_equal(off, tt.offsets) and np.array_equal(feats["view_id"], tt.view)
+        assert np.array_equal(feats["global_feature_id"], 32768 * tt.view + tt.feat)
+        # 6 significant digits of a pixel coordinate below 4096: better than 0.005 px
+        assert np.abs(feats["x"] - tt.xy[:, 0]).max() < 5e-3
+        cams = F.import_camera_file_as_matrix_native(os.path.join(d, "cameras.txt"))
+        assert len(cams) == iset.num_views
+        for (name, m), v in zip(cams, res.aligned_views):
+            R = P._cam_rotation(model, res.cam_params[v])
+            assert name == "view_%04d" % v and np.abs(m[:3, :3] - R).max() < 1e-6
+            assert np.abs(m[:3, 3] + 10.0 * R[:, 2]).max() < 1e-5 and m[3].tolist() == [0, 0, 0, 1]
+        ply = open(os.path.join(d, "sparse_cloud.ply")).read().split("\n")
+        n = int(ply[2].split()[-1])
+        assert n == int((tt.has_point & tt.alive_t).sum()) and len(ply) == 10 + n + 1
+        t = F.runtimes_from_txt_native(os.path.join(d, "time_measurements.txt"))
+        assert abs(t["total"] - res.timings.total_s) < 1e-3 * res.timings.total_s + 1e-6
 
 
 def test_incremental_group_builder_matches_the_oracle():
