@@ -104,7 +104,7 @@ def _check_project_files(res, model, iset):
         assert np.array_equal(off, tt.offsets) and np.array_equal(feats["view_id"], tt.view)
         assert np.array_equal(feats["global_feature_id"], 32768 * tt.view + tt.feat)
         # 6 significant digits of a pixel coordinate below 4096: better than 0.005 px
-        assert np.abs(feats["x"] - tt.xy[:, 0]).max() < 5e-3
+        assert np.abs(feats["x"] - tt.xy[:, 0]).max() < 5.1e-3      # half a unit of the 6th digit + float32 rounding
         cams = F.import_camera_file_as_matrix_native(os.path.join(d, "cameras.txt"))
         assert len(cams) == iset.num_views
         for (name, m), v in zip(cams, res.aligned_views):
