@@ -279,6 +279,11 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     qa.num_pairs = num_pairs;
     qa.pair_key = PL.unique.as<uint32_t>(); qa.pair_start = PL.starts.as<int32_t>();
     qa.entries = PL.entries.as<uint64_t>();
+    qa.chunk_start = PL.chunk_start.as<int32_t>(); qa.max_chunks = PL.max_chunks;
+    qa.chunk_pair = PL.chunk_pair.as<int32_t>();
+    qa.chunk_partials = PL.chunk_partials.as<double>();
+    qa.multi_pairs = PL.multi_pairs.as<int32_t>(); qa.num_multi = PL.num_multi;
+    qa.gmax_out = gmax_cam.as<double>();
     qa.vinv = vinv.as<double>(); qa.ge = ge.as<double>(); qa.obsrec = obsrec.as<double>();
     qa.diag_c = diag_c.as<double>(); qa.scale_c_out = D.scale_c.as<double>();
     qa.S = S.as<double>(); qa.ldS = N; qa.rhs = S.as<double>() + (size_t)N * N;
@@ -346,7 +351,6 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
         OSFM_RETURN_IF(tic(1));
         launch_pair_pass(d, qa, s);
         OSFM_RETURN_IF(toc());
-        launch_cam_gradient(d, qa, gmax_cam.as<double>(), s);
         n_lin++;
         return OSFM_OK;
     };

@@ -31,6 +31,9 @@ struct PointPassArgs {
     double *obsrec;           // [O][kObsRec]: per-observation blocks of this linearisation
 };
 
+constexpr int kPairChunk = 512;   // entries of a camera pair's list per wave (pair pass, camera gradient)
+constexpr int kPairSums = 54;     // sums a pair-pass wave leaves per chunk: 6x6 block, 6 diagonal, 6 rhs, 6 gradient
+
 struct PairPassArgs {
     int mode, update_diag, want_gradient;
     double radius, min_diag, max_diag;
@@ -38,6 +41,13 @@ struct PairPassArgs {
     const uint32_t *pair_key;        // [num_pairs] c1 * C + c2, c1 >= c2
     const int32_t *pair_start;       // [num_pairs + 1]
     const uint64_t *entries;         // (obs a << 32) | obs b, grouped by pair, track order inside
+    const int32_t *chunk_start;      // [num_pairs + 1] first chunk (= wave) of each pair
+    const int32_t *chunk_pair;       // [chunk_start[num_pairs]] pair of each chunk
+    int max_chunks;                  // waves to launch (upper bound of chunk_start[num_pairs])
+    double *chunk_partials;          // [max_chunks][kPairSums] sums of the chunks of multi-chunk pairs
+    const int32_t *multi_pairs;      // [num_multi] pairs with more than one chunk (finished by the join launch)
+    int num_multi;
+    double *gmax_out;                // [C] camera gradient norms (diagonal pairs; may be null)
     const double *vinv, *ge;
     const double *obsrec;     // [O][kObsRec]
     double *diag_c;           // [nc]
@@ -79,7 +89,6 @@ void launch_lm_post(LmDev *lm, const LmParams &prm, const LmScratch &sc, int ini
 
 void launch_point_pass(const BaDev &d, const PointPassArgs &a, int blocks, hipStream_t s);
 void launch_pair_pass(const BaDev &d, const PairPassArgs &a, hipStream_t s);
-void launch_cam_gradient(const BaDev &d, const PairPassArgs &a, double *gmax_out, hipStream_t s);
 // cams_out == nullptr (LM solve): the candidate goes to the iterate buffer that is not current
 void launch_cam_update(const BaDev &d, const double *y_c, double *cams_out, double *partials_cam, hipStream_t s);
 void launch_back_pass(const BaDev &d, const BackPassArgs &a, int blocks, hipStream_t s);
@@ -97,11 +106,15 @@ void launch_triangulate(const BaDev &d, double *points_out, uint8_t *valid, hipS
 // camera-pair lists built on the device (ba_pairs.hip)
 struct PairListsDev {
     DeviceBuffer counts, offsets, keys_in, keys, vals_in, entries, unique, runs, starts, scalars, temp;
+    DeviceBuffer chunk_start, chunk_pair, chunk_partials, multi_pairs;
     int num_pairs = 0;
     int num_entries = 0;
+    int max_chunks = 0;
+    int num_multi = 0;
     ~PairListsDev()
     {
-        DeviceBuffer *b[] = {&counts, &offsets, &keys_in, &keys, &vals_in, &entries, &unique, &runs, &starts, &scalars, &temp};
+        DeviceBuffer *b[] = {&counts, &offsets, &keys_in, &keys, &vals_in, &entries, &unique, &runs, &starts, &scalars, &temp,
+                             &chunk_start, &chunk_pair, &chunk_partials, &multi_pairs};
         for (auto *x : b) x->release();
     }
 };

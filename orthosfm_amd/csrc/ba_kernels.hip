@@ -228,29 +228,119 @@ void launch_point_pass(const BaDev &d, const PointPassArgs &a, int blocks, hipSt
 }
 
 // ---------------------------------------------------------------------------
-// pair pass: one wave per camera pair
+// pair pass: one wave per CHUNK of a camera pair's entry list (kPairChunk entries).
+// A pair with one chunk is finished by its wave.  The chunks of a longer list -- the
+// diagonal pair of a camera holds all its observations, and a 3-camera local problem
+// has six pairs with every track in each -- leave their sums in a scratch row each, and
+// a second launch (ba_pair_join_kernel, one wave per such pair) adds the rows in chunk
+// order.  No fences, no atomics: the launches are ordered by the stream.
+// The camera part of the gradient-norm test rides along on the diagonal pairs:
+// g_c = sum_a Jc_a^T r_a (unscaled), |Plus(x, -g) - x|_inf per camera.
 // ---------------------------------------------------------------------------
+struct PairChunk { int pi, e0, e1, chunk, nchunks; };
+
+// wave -> (pair, chunk); false when the wave has no work
+__device__ __forceinline__ bool locate_pair_chunk(const PairPassArgs &a, int wave, PairChunk &w)
+{
+    if (wave >= a.max_chunks || wave >= a.chunk_start[a.num_pairs]) return false;
+    const int pi = a.chunk_pair[wave];
+    w.pi = pi;
+    w.chunk = wave - a.chunk_start[pi];
+    w.nchunks = a.chunk_start[pi + 1] - a.chunk_start[pi];
+    const int p0 = a.pair_start[pi], p1 = a.pair_start[pi + 1];
+    w.e0 = p0 + w.chunk * kPairChunk;
+    w.e1 = min(p1, w.e0 + kPairChunk);
+    return true;
+}
+
+__device__ __forceinline__ double lane_value(double v, int src)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffu), src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// The sums of a camera pair, complete: block of S, LM diagonal, reduced rhs, and for a
+// diagonal pair the camera's gradient norm.  One lane.
+__device__ __forceinline__ void
+pair_finish(const BaDev &d, const PairPassArgs &a, int c1, int c2, double (&acc)[6][6], const double (&U)[6],
+    const double (&rhs)[6], const double (&g)[6])
+{
+    const int n1 = d.cam_ldim[c1], n2 = d.cam_ldim[c2];
+    const int o1 = d.cam_off[c1], o2 = d.cam_off[c2];
+    const bool diag_pair = c1 == c2;
+    // fully unrolled with predicates: a loop bounded by n1 / n2 would index the
+    // accumulators dynamically and push all 36 of them into scratch memory
+    if (a.mode == kPassScaleInit) {
+        if (diag_pair) {
+#pragma unroll
+            for (int x = 0; x < 6; ++x)
+                if (x < n1) a.scale_c_out[o1 + x] = 1.0 / (1.0 + sqrt(U[x]));
+        }
+        return;
+    }
+    if (diag_pair) {
+#pragma unroll
+        for (int x = 0; x < 6; ++x) {
+            if (x >= n1) continue;
+            if (a.update_diag) a.diag_c[o1 + x] = fmin(fmax(U[x], a.min_diag), a.max_diag);
+            acc[x][x] += a.diag_c[o1 + x] / a.radius;
+            a.rhs[o1 + x] = rhs[x];
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+        for (int y = 0; y < 6; ++y)
+            if (x < n1 && y < n2) a.S[(size_t)(o1 + x) * a.ldS + (o2 + y)] = acc[x][y];
+    if (diag_pair && a.gmax_out && a.want_gradient) {
+        double dl[6];
+#pragma unroll
+        for (int x = 0; x < 6; ++x) dl[x] = x < n1 ? -g[x] / d.scale_c[o1 + x] : 0.0;
+        const double *cam = d.cams + 7 * c1;
+        double out[7];
+        for (int i = 0; i < 7; ++i) out[i] = cam[i];
+        int t = 0;
+        if (d.model == kModelQuat && n1 > 0 && d.cam_colmap[6 * c1] == 0) { quat_plus(cam, dl, out); t = 3; }
+        for (; t < n1; ++t) {
+            const int f = d.cam_colmap[6 * c1 + t];
+            const int slot = d.model == kModelQuat ? f + 1 : f;     // full col 3,4,5 -> slots 4,5,6
+            double dv = 0.0;
+#pragma unroll
+            for (int x = 0; x < 6; ++x) dv = t == x ? dl[x] : dv;
+            out[slot] = cam[slot] + dv;
+        }
+        double gm = 0.0;
+        for (int i = 0; i < 7; ++i) gm = fmax(gm, fabs(cam[i] - out[i]));
+        a.gmax_out[c1] = gm;
+    }
+}
+
 __global__ __launch_bounds__(256) void
 ba_pair_pass_kernel(BaDev d, PairPassArgs a)
 {
     if (!lm_resolve(d)) return;
-    if (d.lm && a.mode == kPassNormal) { a.radius = d.lm->radius; a.update_diag = d.lm->update_diag; }
+    if (d.lm && a.mode == kPassNormal) {
+        a.radius = d.lm->radius; a.update_diag = d.lm->update_diag; a.want_gradient = d.lm->want_gradient;
+    }
     const int lane = threadIdx.x & 63;
-    const int pi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (pi >= a.num_pairs) return;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    PairChunk w;
+    if (!locate_pair_chunk(a, wave, w)) return;
+    const int pi = w.pi;
     const int c1 = (int)(a.pair_key[pi] / (uint32_t)d.C), c2 = (int)(a.pair_key[pi] % (uint32_t)d.C);
-    const int e0 = a.pair_start[pi], e1 = a.pair_start[pi + 1];
-    const int n1 = d.cam_ldim[c1], n2 = d.cam_ldim[c2];
-    const int o1 = d.cam_off[c1], o2 = d.cam_off[c2];
+    const int e0 = w.e0, e1 = w.e1;
     const bool diag_pair = c1 == c2;
     if (a.mode == kPassScaleInit && !diag_pair) return;
 
     double acc[6][6];      // - sum Z_a W_b^T  (+ sum Jc^T Jc on the diagonal pair)
     double U[6];           // diagonal of sum Jc^T Jc (for the LM diagonal)
     double rhs[6];
+    double g[6];           // sum Jc^T r (diagonal pairs: the camera's gradient)
 #pragma unroll
     for (int x = 0; x < 6; ++x) {
-        U[x] = 0.0; rhs[x] = 0.0;
+        U[x] = 0.0; rhs[x] = 0.0; g[x] = 0.0;
 #pragma unroll
         for (int y = 0; y < 6; ++y) acc[x][y] = 0.0;
     }
@@ -270,11 +360,13 @@ ba_pair_pass_kernel(BaDev d, PairPassArgs a)
         for (int x = 0; x < 6; ++x) { Ja[0][x] = ra[kRecJc + x]; Ja[1][x] = ra[kRecJc + 6 + x]; }
         if (ka == kb) {
             double rr0 = ra[kRecR], rr1 = ra[kRecR + 1];
+#pragma unroll
+            for (int x = 0; x < 6; ++x) g[x] += Ja[0][x] * rr0 + Ja[1][x] * rr1;
             if (d.pdim && a.mode != kPassScaleInit) {
                 // rhs = Jc^T (r - Q g):  Z g = Jc^T (Q g)
-                const double *g = a.ge + 3 * d.obs_pt[ka];
-                rr0 -= ra[kRecQ] * g[0] + ra[kRecQ + 1] * g[1] + ra[kRecQ + 2] * g[2];
-                rr1 -= ra[kRecQ + 3] * g[0] + ra[kRecQ + 4] * g[1] + ra[kRecQ + 5] * g[2];
+                const double *gp = a.ge + 3 * d.obs_pt[ka];
+                rr0 -= ra[kRecQ] * gp[0] + ra[kRecQ + 1] * gp[1] + ra[kRecQ + 2] * gp[2];
+                rr1 -= ra[kRecQ + 3] * gp[0] + ra[kRecQ + 4] * gp[1] + ra[kRecQ + 5] * gp[2];
             }
 #pragma unroll
             for (int x = 0; x < 6; ++x) {
@@ -314,92 +406,73 @@ ba_pair_pass_kernel(BaDev d, PairPassArgs a)
     for (int x = 0; x < 6; ++x) {
         U[x] = wave_sum(U[x]);
         rhs[x] = wave_sum(rhs[x]);
+        if (diag_pair) g[x] = wave_sum(g[x]);
 #pragma unroll
         for (int y = 0; y < 6; ++y) acc[x][y] = wave_sum(acc[x][y]);
     }
-    if (lane != 0) return;
-    // fully unrolled with predicates: a loop bounded by n1 / n2 would index the
-    // accumulators dynamically and push all 36 of them into scratch memory
-    if (a.mode == kPassScaleInit) {
-        if (diag_pair) {
-#pragma unroll
-            for (int x = 0; x < 6; ++x)
-                if (x < n1) a.scale_c_out[o1 + x] = 1.0 / (1.0 + sqrt(U[x]));
-        }
-        return;
-    }
-    if (diag_pair) {
+    if (w.nchunks > 1) {
+        // lane v takes sum v (36 block entries, 6 diagonal sums, 6 rhs entries, 6 gradient entries)
+        double mine = 0.0;
 #pragma unroll
         for (int x = 0; x < 6; ++x) {
-            if (x >= n1) continue;
-            if (a.update_diag) a.diag_c[o1 + x] = fmin(fmax(U[x], a.min_diag), a.max_diag);
-            acc[x][x] += a.diag_c[o1 + x] / a.radius;
-            a.rhs[o1 + x] = rhs[x];
+#pragma unroll
+            for (int y = 0; y < 6; ++y) mine = lane == x * 6 + y ? acc[x][y] : mine;
+            mine = lane == 36 + x ? U[x] : mine;
+            mine = lane == 42 + x ? rhs[x] : mine;
+            mine = lane == 48 + x ? g[x] : mine;
         }
+        if (lane < kPairSums) a.chunk_partials[(size_t)wave * kPairSums + lane] = mine;
+        return;
     }
+    if (lane == 0) pair_finish(d, a, c1, c2, acc, U, rhs, g);
+}
+
+// second launch of the pair pass: the pairs with more than one chunk
+__global__ __launch_bounds__(256) void
+ba_pair_join_kernel(BaDev d, PairPassArgs a)
+{
+    if (!lm_resolve(d)) return;
+    if (d.lm && a.mode == kPassNormal) {
+        a.radius = d.lm->radius; a.update_diag = d.lm->update_diag; a.want_gradient = d.lm->want_gradient;
+    }
+    const int lane = threadIdx.x & 63;
+    const int mi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (mi >= a.num_multi) return;
+    const int pi = a.multi_pairs[mi];
+    const int c1 = (int)(a.pair_key[pi] / (uint32_t)d.C), c2 = (int)(a.pair_key[pi] % (uint32_t)d.C);
+    if (a.mode == kPassScaleInit && c1 != c2) return;
+    const int w0 = a.chunk_start[pi], nch = a.chunk_start[pi + 1] - w0;
+    const double *row = a.chunk_partials + (size_t)w0 * kPairSums + lane;
+    double total = 0.0;
+    if (lane < kPairSums) {
+        // four rows per round, loads first (a plain loop is one memory latency per row)
+        int c = 0;
+        for (; c + 4 <= nch; c += 4) {
+            const double v0 = row[(size_t)c * kPairSums], v1 = row[(size_t)(c + 1) * kPairSums];
+            const double v2 = row[(size_t)(c + 2) * kPairSums], v3 = row[(size_t)(c + 3) * kPairSums];
+            total += v0; total += v1; total += v2; total += v3;
+        }
+        for (; c < nch; ++c) total += row[(size_t)c * kPairSums];
+    }
+    double acc[6][6], U[6], rhs[6], g[6];
 #pragma unroll
-    for (int x = 0; x < 6; ++x)
+    for (int x = 0; x < 6; ++x) {
 #pragma unroll
-        for (int y = 0; y < 6; ++y)
-            if (x < n1 && y < n2) a.S[(size_t)(o1 + x) * a.ldS + (o2 + y)] = acc[x][y];
+        for (int y = 0; y < 6; ++y) acc[x][y] = lane_value(total, x * 6 + y);
+        U[x] = lane_value(total, 36 + x);
+        rhs[x] = lane_value(total, 42 + x);
+        g[x] = lane_value(total, 48 + x);
+    }
+    if (lane == 0) pair_finish(d, a, c1, c2, acc, U, rhs, g);
 }
 
 void launch_pair_pass(const BaDev &d, const PairPassArgs &a, hipStream_t s)
 {
     if (a.num_pairs <= 0) return;
-    const int blocks = (a.num_pairs + 3) / 4;
+    const int blocks = (a.max_chunks + 3) / 4;
     hipLaunchKernelGGL(ba_pair_pass_kernel, dim3(blocks), dim3(256), 0, s, d, a);
-}
-
-// Camera part of the gradient-norm test: g_c = sum_a Jc_a^T r_a (unscaled),
-// |Plus(x, -g) - x|_inf per camera.  One wave per camera over its diagonal
-// pair list (entries with a == b).
-__global__ __launch_bounds__(256) void
-ba_cam_gradient_kernel(BaDev d, PairPassArgs a, double *gmax_out)
-{
-    if (!lm_resolve(d)) return;
-    if (d.lm && !d.lm->want_gradient) return;
-    const int lane = threadIdx.x & 63;
-    const int pi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (pi >= a.num_pairs) return;
-    const int c1 = (int)(a.pair_key[pi] / (uint32_t)d.C), c2 = (int)(a.pair_key[pi] % (uint32_t)d.C);
-    if (c1 != c2) return;
-    const int e0 = a.pair_start[pi], e1 = a.pair_start[pi + 1];
-    const int n1 = d.cam_ldim[c1], o1 = d.cam_off[c1];
-    double g[6] = { 0, 0, 0, 0, 0, 0 };
-    for (int e = e0 + lane; e < e1; e += 64) {
-        const uint64_t ent = a.entries[e];
-        const int ka = (int)(ent >> 32);
-        if (ka != (int)(ent & 0xffffffffu)) continue;
-        const double *ra = a.obsrec + (size_t)ka * kObsRec;
-#pragma unroll
-        for (int x = 0; x < 6; ++x) g[x] += ra[kRecJc + x] * ra[kRecR] + ra[kRecJc + 6 + x] * ra[kRecR + 1];
-    }
-#pragma unroll
-    for (int x = 0; x < 6; ++x) g[x] = wave_sum(g[x]);
-    if (lane != 0) return;
-    double dl[6];
-    for (int x = 0; x < 6; ++x) dl[x] = x < n1 ? -g[x] / d.scale_c[o1 + x] : 0.0;
-    const double *cam = d.cams + 7 * c1;
-    double out[7];
-    for (int i = 0; i < 7; ++i) out[i] = cam[i];
-    int t = 0;
-    if (d.model == kModelQuat && n1 > 0 && d.cam_colmap[6 * c1] == 0) { quat_plus(cam, dl, out); t = 3; }
-    for (; t < n1; ++t) {
-        const int f = d.cam_colmap[6 * c1 + t];
-        const int slot = d.model == kModelQuat ? f + 1 : f;     // full col 3,4,5 -> slots 4,5,6
-        out[slot] = cam[slot] + dl[t];
-    }
-    double gm = 0.0;
-    for (int i = 0; i < 7; ++i) gm = fmax(gm, fabs(cam[i] - out[i]));
-    gmax_out[c1] = gm;
-}
-
-void launch_cam_gradient(const BaDev &d, const PairPassArgs &a, double *gmax_out, hipStream_t s)
-{
-    if (a.num_pairs <= 0) return;
-    const int blocks = (a.num_pairs + 3) / 4;
-    hipLaunchKernelGGL(ba_cam_gradient_kernel, dim3(blocks), dim3(256), 0, s, d, a, gmax_out);
+    if (a.num_multi > 0)
+        hipLaunchKernelGGL(ba_pair_join_kernel, dim3((a.num_multi + 3) / 4), dim3(256), 0, s, d, a);
 }
 
 // ---------------------------------------------------------------------------

@@ -55,6 +55,33 @@ pair_fill_kernel(BaDev d, int with_points, const int32_t *offsets, uint32_t *key
     }
 }
 
+// chunks (= pair-pass waves) per camera pair; entry num_pairs is the trailing zero of the scan
+__global__ void
+pair_chunk_count_kernel(const int32_t *runs, int num_pairs, int32_t *chunks)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > num_pairs) return;
+    chunks[i] = i < num_pairs ? (runs[i] + kPairChunk - 1) / kPairChunk : 0;
+}
+
+// chunk (= wave) -> pair, so that a pair-pass wave finds its work with one load
+__global__ void
+pair_chunk_fill_kernel(const int32_t *chunk_start, int num_pairs, int32_t *chunk_pair)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_pairs) return;
+    for (int c = chunk_start[i]; c < chunk_start[i + 1]; ++c) chunk_pair[c] = i;
+}
+
+// the pairs with more than one chunk, in any order (each is finished on its own)
+__global__ void
+pair_multi_list_kernel(const int32_t *chunk_start, int num_pairs, int32_t *multi, int32_t *count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_pairs) return;
+    if (chunk_start[i + 1] - chunk_start[i] > 1) multi[atomicAdd(count, 1)] = i;
+}
+
 int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, PairListsDev *out, hipStream_t s)
 {
     const int M = d.M;
@@ -68,7 +95,7 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
                   "lengths) exceed the supported 2^31 - 1", (long long)max_entries);
         return OSFM_E_RANGE;
     }
-    OSFM_RETURN_IF(out->counts.reserve((size_t)(M + 1) * 4));
+    OSFM_RETURN_IF(out->counts.reserve((size_t)(std::max<int64_t>(M, max_entries) + 1) * 4));   // later: chunk counts per pair
     OSFM_RETURN_IF(out->offsets.reserve((size_t)(M + 1) * 4));
     OSFM_RETURN_IF(out->keys_in.reserve((size_t)max_entries * 4));
     OSFM_RETURN_IF(out->keys.reserve((size_t)max_entries * 4));
@@ -122,6 +149,29 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
     OSFM_HIP_CHECK(hipMemsetAsync(out->runs.as<int32_t>() + h_runs, 0, 4, s));
     OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(out->temp.ptr, tb, out->runs.as<int32_t>(),
         out->starts.as<int32_t>(), h_runs + 1, s));
+    // chunks of the pair pass: chunk_start = exclusive scan of ceil(run / kPairChunk); the number
+    // of waves to launch is bounded without reading anything back
+    out->max_chunks = h_runs + E / kPairChunk;
+    OSFM_RETURN_IF(out->chunk_start.reserve((size_t)(h_runs + 1) * 4));
+    OSFM_RETURN_IF(out->multi_pairs.reserve((size_t)(h_runs + 1) * 4));
+    OSFM_RETURN_IF(out->chunk_partials.reserve((size_t)out->max_chunks * kPairSums * sizeof(double)));
+    // the run lengths are not needed after this: the chunk counts take their place
+    hipLaunchKernelGGL(pair_chunk_count_kernel, dim3((h_runs + 256) / 256), dim3(256), 0, s,
+        out->runs.as<int32_t>(), h_runs, out->counts.as<int32_t>());
+    tb = out->temp.bytes;
+    OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(out->temp.ptr, tb, out->counts.as<int32_t>(),
+        out->chunk_start.as<int32_t>(), h_runs + 1, s));
+    int32_t *multi_count = out->scalars.as<int32_t>() + 4;
+    OSFM_HIP_CHECK(hipMemsetAsync(multi_count, 0, 4, s));
+    OSFM_RETURN_IF(out->chunk_pair.reserve((size_t)(out->max_chunks + 1) * 4));
+    hipLaunchKernelGGL(pair_chunk_fill_kernel, dim3((h_runs + 255) / 256), dim3(256), 0, s,
+        out->chunk_start.as<int32_t>(), h_runs, out->chunk_pair.as<int32_t>());
+    hipLaunchKernelGGL(pair_multi_list_kernel, dim3((h_runs + 255) / 256), dim3(256), 0, s,
+        out->chunk_start.as<int32_t>(), h_runs, out->multi_pairs.as<int32_t>(), multi_count);
+    int32_t h_multi = 0;
+    OSFM_HIP_CHECK(hipMemcpyAsync(&h_multi, multi_count, 4, hipMemcpyDeviceToHost, s));
+    OSFM_HIP_CHECK(hipStreamSynchronize(s));
+    out->num_multi = h_multi;
     return OSFM_OK;
 }
 
