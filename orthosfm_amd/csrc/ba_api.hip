@@ -279,7 +279,7 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     qa.num_pairs = num_pairs;
     qa.pair_key = PL.unique.as<uint32_t>(); qa.pair_start = PL.starts.as<int32_t>();
     qa.entries = PL.entries.as<uint64_t>();
-    qa.chunk_start = PL.chunk_start.as<int32_t>(); qa.max_chunks = PL.max_chunks;
+    qa.chunk_start = PL.chunk_start.as<int32_t>(); qa.max_chunks = PL.max_chunks; qa.chunk = PL.chunk;
     qa.chunk_pair = PL.chunk_pair.as<int32_t>();
     qa.chunk_partials = PL.chunk_partials.as<double>();
     qa.multi_pairs = PL.multi_pairs.as<int32_t>(); qa.num_multi = PL.num_multi;
@@ -320,6 +320,10 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     sc.partA = partA.as<double>(); sc.partB = partB.as<double>(); sc.partC = partC.as<double>();
     sc.part_cam = part_cam.as<double>(); sc.gmax_cam = gmax_cam.as<double>();
     sc.chol_info = info.as<int32_t>(); sc.blocksM = blocksM; sc.C = std::max(C, 1);
+    // one block of unknowns: the solve and the candidate cameras are one launch, and the
+    // decide kernel clears the system for the next linearisation
+    const bool small = nc > 0 && N == 32;
+    sc.reset_S = small ? S.as<double>() : nullptr; sc.reset_n = nc; sc.reset_N = N;
     OSFM_HIP_CHECK(hipMemsetAsync(info.ptr, 0, 16, s));
     OSFM_HIP_CHECK(hipMemsetAsync(part_cam.ptr, 0, (size_t)2 * std::max(C, 1) * 8, s));
 
@@ -341,13 +345,12 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     };
     int n_lin = 0;
 
-    auto linearize = [&]() -> int {
+    auto linearize = [&](bool reset) -> int {
         pa.mode = kPassNormal; qa.mode = kPassNormal;
         OSFM_RETURN_IF(tic(0));
         launch_point_pass(d, pa, blocksM, s);
         OSFM_RETURN_IF(toc());
-        OSFM_HIP_CHECK(hipMemsetAsync(S.ptr, 0, s_elems * 8, s));
-        launch_pad_diag(S.as<double>(), N, nc, N, s);
+        if (reset) launch_reset_system(S.as<double>(), s_elems, N, nc, N, s);
         OSFM_RETURN_IF(tic(1));
         launch_pair_pass(d, qa, s);
         OSFM_RETURN_IF(toc());
@@ -365,8 +368,8 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     }
     d.lm = lm;
     lap("alloc + lists up");
-    OSFM_RETURN_IF(linearize());
-    launch_lm_post(lm, prm, sc, 1, s);
+    OSFM_RETURN_IF(linearize(true));
+    launch_lm_post(lm, prm, sc, 1, nullptr, s);
     OSFM_HIP_CHECK(hipGetLastError());
     lap("first linearize");
     const auto t_loop = std::chrono::steady_clock::now();
@@ -383,26 +386,24 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     for (int it = 0; it < max_slots - 2; ++it) {
         const int slot = it + 1;          // h_state[slot]: the state this iteration leaves
         OSFM_RETURN_IF(tic(2));
-        if (nc > 0) launch_cholesky_solve(S.as<double>(), Lmat.as<double>(), nc, Ldiag.as<double>(), y_c.as<double>(), info.as<int>(), lm, s);
+        if (small) launch_small_solve(S.as<double>(), nc, Ldiag.as<double>(), y_c.as<double>(), info.as<int>(), d, part_cam.as<double>(), s);
+        else if (nc > 0) launch_cholesky_solve(S.as<double>(), Lmat.as<double>(), nc, Ldiag.as<double>(), y_c.as<double>(), info.as<int>(), lm, s);
         OSFM_RETURN_IF(toc());
         OSFM_RETURN_IF(tic(3));
-        launch_cam_update(d, y_c.as<double>(), nullptr, part_cam.as<double>(), s);
+        if (!small) launch_cam_update(d, y_c.as<double>(), nullptr, part_cam.as<double>(), s);
         BackPassArgs ba;
         ba.y_c = y_c.as<double>(); ba.vinv = vinv.as<double>(); ba.ge = ge.as<double>(); ba.obsrec = obsrec.as<double>();
         ba.points_out = nullptr; ba.partials = partB.as<double>();
         launch_back_pass(d, ba, blocksM, s);
         OSFM_RETURN_IF(toc());
         launch_cost_pass(d, nullptr, nullptr, partC.as<double>(), blocksM, s);
-        launch_lm_decide(lm, prm, sc, s);
-        if (!eager) {
-            OSFM_HIP_CHECK(hipMemcpyAsync(&h_state[slot], lm, sizeof(LmDev), hipMemcpyDeviceToHost, s));
-            OSFM_HIP_CHECK(hipEventRecord(evs[slot], s));
-        }
-        OSFM_RETURN_IF(linearize());
-        launch_lm_post(lm, prm, sc, 0, s);
+        // the kernels write the state they leave straight into the host's slot
+        launch_lm_decide(lm, prm, sc, eager ? nullptr : &h_state[slot], s);
+        if (!eager) OSFM_HIP_CHECK(hipEventRecord(evs[slot], s));
+        OSFM_RETURN_IF(linearize(!small));
+        launch_lm_post(lm, prm, sc, 0, eager ? &h_state[slot] : nullptr, s);
         OSFM_HIP_CHECK(hipGetLastError());
         if (eager) {
-            OSFM_HIP_CHECK(hipMemcpyAsync(&h_state[slot], lm, sizeof(LmDev), hipMemcpyDeviceToHost, s));
             OSFM_HIP_CHECK(hipEventRecord(evs[slot], s));
             if (it >= 1) {
                 // what iteration it - 1 left behind (this iteration is already queued after it)

@@ -62,8 +62,12 @@ __device__ __forceinline__ double swap_halves(double v)
 }
 
 __device__ __forceinline__ void
-factor_diag_block(const double *Msrc, int lds_ld, double (*LsT)[NB], int kblock, double *Ldiag, int *info)
+factor_diag_block(const double *Msrc, int lds_ld, double (*LsT)[NB], int kblock, double *Ldiag, int *info,
+    double *linv_lds = nullptr, int linv_ld = 0, int nvalid = NB)
 {
+    // nvalid: rows / columns from there on are identity padding (wave-uniform); their pivot
+    // steps and inverse rows change nothing and are skipped -- the chain is serial, so a
+    // 17-unknown system (three cameras) is done in half the time of a full block
     __shared__ __attribute__((aligned(16))) double colbuf[2][NB];      // [pivot parity][row]
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     double L[NB], dinv[NB];
@@ -72,6 +76,7 @@ factor_diag_block(const double *Msrc, int lds_ld, double (*LsT)[NB], int kblock,
     int bad = 0;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
+        if (j >= nvalid) { dinv[j] = 1.0; continue; }
         double d = readlane_d(L[j], j);
         if (!(d > 0.0)) { d = 1.0; bad = j + 1; }
         const double rinv = rsqrt_newton(d);
@@ -100,6 +105,7 @@ factor_diag_block(const double *Msrc, int lds_ld, double (*LsT)[NB], int kblock,
     double x[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
+        if (i >= nvalid) { x[i] = (i == r) ? 1.0 : 0.0; continue; }
         double acc = 0.0;
 #pragma unroll
         for (int c = 0; c < i; ++c)
@@ -112,6 +118,12 @@ factor_diag_block(const double *Msrc, int lds_ld, double (*LsT)[NB], int kblock,
         double *Lk = Ldiag + (size_t)kblock * NB * NB;                          // [i][j] = inv(L)[i][j]
 #pragma unroll
         for (int i = 0; i < NB; ++i) Lk[i * NB + r] = x[i];
+        // a copy in LDS for a caller that goes on to use it (Msrc itself may be the target:
+        // the block was read into registers at the top)
+        if (linv_lds) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) linv_lds[i * linv_ld + r] = x[i];
+        }
     }
 }
 
@@ -129,6 +141,55 @@ chol_first_kernel(const double *A, int ld, double *Ldiag, int *info, const LmDev
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     factor_diag_block(&M[0][0], NB + 1, LsT, 0, Ldiag, info);
+}
+
+// A system of one block (n <= 32: the three-camera adjustments of the incremental
+// reconstruction) start to finish in one launch of one wave: factor, y = inv(L) b,
+// x = inv(L)^T y, and the candidate cameras Plus(x, -step) that the next kernel needs --
+// four launches of a latency-bound chain in one.  Same operation order as the general
+// path's kernels (chol_rhs_tail / chol_backsolve), so both give the same bits.
+__global__ __launch_bounds__(64, 1) void
+chol_small_kernel(const double *A, int ld, int n, double *Ldiag, double *x, int *info, BaDev d,
+    double *partials_cam)
+{
+    if (!lm_resolve(d)) return;
+    if (d.lm->lin_failed) return;
+    __shared__ __attribute__((aligned(16))) double M[NB][NB + 1];
+    __shared__ __attribute__((aligned(16))) double LsT[NB][NB];
+    __shared__ double ys[NB], xs[NB];
+    const int lane = threadIdx.x, r = lane & 31;
+    double b = 0.0;
+    if (lane < NB) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) M[r][c] = A[(size_t)r * ld + c];
+        b = A[(size_t)NB * ld + r];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    factor_diag_block(&M[0][0], NB + 1, LsT, 0, Ldiag, info, &M[0][0], NB + 1, n);  // M := inv(L)
+    if (lane < NB) ys[lane] = b;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double acc = 0.0;
+    if (lane < NB) {
+        // y_c = sum_{m <= c} b[m] inv(L)[c][m]
+#pragma unroll
+        for (int m = 0; m < NB; ++m) acc = fma(ys[m], m <= lane ? M[lane][m] : 0.0, acc);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < NB) ys[lane] = acc;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < NB) {
+        // x_m = sum_{c >= m} inv(L)[c][m] y[c]
+        double v = 0.0;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) v += (c >= lane) ? M[c][lane] * ys[c] : 0.0;
+        if (lane < n) x[lane] = v;          // the back pass reads it from global memory
+        xs[lane] = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // a failed factorisation is noticed by ba_lm_decide (chol_info); the candidates it then
+    // ignores are written all the same, like the general path does
+    double *cams_out = d.cams2[d.lm->cur ^ 1];
+    for (int c = lane; c < d.C; c += 64) cam_update_one(d, xs, cams_out, partials_cam, c);
 }
 
 // Step k of the right-looking factorisation as ONE launch: tile (i, j), k < j <= i <= nblk
@@ -287,6 +348,12 @@ chol_backsolve_kernel(const double *A, int ld, int nblk, int n, const double *Ld
 }
 
 int cholesky_padded_dim(int n) { return (n + NB - 1) / NB * NB; }
+
+void launch_small_solve(const double *A, int n, double *Ldiag, double *x, int *info, const BaDev &d,
+    double *partials_cam, hipStream_t s)
+{
+    hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(64), 0, s, A, NB, n, Ldiag, x, info, d, partials_cam);
+}
 
 // A: (N + 32) x N row-major, rows/cols >= n padded with identity, rhs in row N.
 // Ldiag: N * 32 doubles of scratch for the inverses of the factored diagonal blocks.

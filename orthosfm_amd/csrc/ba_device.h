@@ -411,4 +411,39 @@ __device__ __forceinline__ bool inv3_spd(const double A[3][3], double inv[3][3])
     return true;
 }
 
+// Candidate of one camera: x+ = Plus(x, scale * step), step = -y, and the camera's share of
+// the step / parameter norms (ambient coordinates of the non-constant blocks).
+__device__ __forceinline__ void
+cam_update_one(const BaDev &d, const double *y_c, double *cams_out, double *partials_cam, int c)
+{
+    const double *cam = d.cams + 7 * c;
+    double out[7];
+    for (int i = 0; i < 7; ++i) out[i] = cam[i];
+    const int n = d.cam_ldim[c], off = d.cam_off[c];
+    double dl[6];
+    for (int t = 0; t < 6; ++t) dl[t] = t < n ? -y_c[off + t] * d.scale_c[off + t] : 0.0;
+    int t = 0;
+    if (d.model == kModelQuat && n > 0 && d.cam_colmap[6 * c] == 0) { quat_plus(cam, dl, out); t = 3; }
+    for (; t < n; ++t) {
+        const int f = d.cam_colmap[6 * c + t];
+        const int slot = d.model == kModelQuat ? f + 1 : f;
+        out[slot] = cam[slot] + dl[t];
+    }
+    // norms over the ambient coordinates of the non-constant blocks
+    double sn = 0.0, xn = 0.0;
+    bool act[7] = { false, false, false, false, false, false, false };
+    for (int tt = 0; tt < n; ++tt) {
+        const int f = d.cam_colmap[6 * c + tt];
+        if (d.model == kModelQuat) {
+            if (f < 3) { act[0] = act[1] = act[2] = act[3] = true; } else act[f + 1] = true;
+        } else act[f] = true;
+    }
+    for (int i = 0; i < 7; ++i) {
+        cams_out[7 * c + i] = out[i];
+        if (act[i]) { sn += (cam[i] - out[i]) * (cam[i] - out[i]); xn += cam[i] * cam[i]; }
+    }
+    partials_cam[2 * c] = sn;
+    partials_cam[2 * c + 1] = xn;
+}
+
 }  // namespace osfm

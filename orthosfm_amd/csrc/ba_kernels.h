@@ -31,7 +31,9 @@ struct PointPassArgs {
     double *obsrec;           // [O][kObsRec]: per-observation blocks of this linearisation
 };
 
-constexpr int kPairChunk = 512;   // entries of a camera pair's list per wave (pair pass, camera gradient)
+constexpr int kPairChunk = 512;   // entries of a camera pair's list per pair-pass wave; kPairChunkSmall below
+constexpr int kPairChunkSmall = 256;       // kPairChunkSmallLimit entries (few cameras: more, shorter waves)
+constexpr int kPairChunkSmallLimit = 1 << 20;
 constexpr int kPairSums = 54;     // sums a pair-pass wave leaves per chunk: 6x6 block, 6 diagonal, 6 rhs, 6 gradient
 
 struct PairPassArgs {
@@ -44,6 +46,7 @@ struct PairPassArgs {
     const int32_t *chunk_start;      // [num_pairs + 1] first chunk (= wave) of each pair
     const int32_t *chunk_pair;       // [chunk_start[num_pairs]] pair of each chunk
     int max_chunks;                  // waves to launch (upper bound of chunk_start[num_pairs])
+    int chunk;                       // entries per chunk
     double *chunk_partials;          // [max_chunks][kPairSums] sums of the chunks of multi-chunk pairs
     const int32_t *multi_pairs;      // [num_multi] pairs with more than one chunk (finished by the join launch)
     int num_multi;
@@ -82,10 +85,13 @@ struct LmScratch {
     const double *gmax_cam;  // [C]           camera gradient norms
     int32_t *chol_info;      // [1]           first non-positive pivot + 1 (reset after reading)
     int32_t blocksM, C;
+    double *reset_S;         // one-block systems: the decide kernel clears S ((reset_N + 32) x reset_N,
+    int32_t reset_n, reset_N;    // identity on the padding diagonal from reset_n on); null otherwise
 };
 
-void launch_lm_decide(LmDev *lm, const LmParams &prm, const LmScratch &sc, hipStream_t s);
-void launch_lm_post(LmDev *lm, const LmParams &prm, const LmScratch &sc, int initial, hipStream_t s);
+// host_out (may be null): page-locked host slot that receives the state the kernel leaves
+void launch_lm_decide(LmDev *lm, const LmParams &prm, const LmScratch &sc, LmDev *host_out, hipStream_t s);
+void launch_lm_post(LmDev *lm, const LmParams &prm, const LmScratch &sc, int initial, LmDev *host_out, hipStream_t s);
 
 void launch_point_pass(const BaDev &d, const PointPassArgs &a, int blocks, hipStream_t s);
 void launch_pair_pass(const BaDev &d, const PairPassArgs &a, hipStream_t s);
@@ -97,7 +103,6 @@ void launch_cost_pass(const BaDev &d, const double *cams, const double *points, 
 void launch_reduce(const double *partials, int n, int num_slots, unsigned max_mask, double *out,
     const double *extra, int extra_n, int extra_stride, int extra_slots, hipStream_t s);
 void launch_max_reduce(const double *v, int n, double *out, hipStream_t s);
-void launch_pad_diag(double *S, int ld, int n, int N, hipStream_t s);
 void launch_fill(double *v, size_t n, double value, hipStream_t s);
 void launch_expand_points(const int32_t *pt_start, int M, int32_t *obs_pt, hipStream_t s);
 void launch_reproj(const BaDev &d, double *err, double *residuals, hipStream_t s);
@@ -110,6 +115,7 @@ struct PairListsDev {
     int num_pairs = 0;
     int num_entries = 0;
     int max_chunks = 0;
+    int chunk = kPairChunk;
     int num_multi = 0;
     ~PairListsDev()
     {
@@ -126,5 +132,10 @@ int cholesky_padded_dim(int n);
 // Lmat: (N + 32) x N scratch for the factor and the solved right-hand side (A keeps the
 // reduced system's trailing updates)
 void launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double *x, int *info, const LmDev *lm, hipStream_t s);
+// n <= 32 (one block): factor, both substitutions and the candidate cameras in one launch
+void launch_small_solve(const double *A, int n, double *Ldiag, double *x, int *info, const BaDev &d,
+    double *partials_cam, hipStream_t s);
+// zeroes the reduced system and puts the identity on its padding diagonal
+void launch_reset_system(double *S, size_t elems, int ld, int n, int N, hipStream_t s);
 
 }  // namespace osfm

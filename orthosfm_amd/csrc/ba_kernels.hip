@@ -228,7 +228,7 @@ void launch_point_pass(const BaDev &d, const PointPassArgs &a, int blocks, hipSt
 }
 
 // ---------------------------------------------------------------------------
-// pair pass: one wave per CHUNK of a camera pair's entry list (kPairChunk entries).
+// pair pass: one wave per CHUNK of a camera pair's entry list (PairPassArgs::chunk entries).
 // A pair with one chunk is finished by its wave.  The chunks of a longer list -- the
 // diagonal pair of a camera holds all its observations, and a 3-camera local problem
 // has six pairs with every track in each -- leave their sums in a scratch row each, and
@@ -248,8 +248,8 @@ __device__ __forceinline__ bool locate_pair_chunk(const PairPassArgs &a, int wav
     w.chunk = wave - a.chunk_start[pi];
     w.nchunks = a.chunk_start[pi + 1] - a.chunk_start[pi];
     const int p0 = a.pair_start[pi], p1 = a.pair_start[pi + 1];
-    w.e0 = p0 + w.chunk * kPairChunk;
-    w.e1 = min(p1, w.e0 + kPairChunk);
+    w.e0 = p0 + w.chunk * a.chunk;
+    w.e1 = min(p1, w.e0 + a.chunk);
     return true;
 }
 
@@ -485,34 +485,7 @@ ba_cam_update_kernel(BaDev d, const double *y_c, double *cams_out, double *parti
     if (d.lm) { if (d.lm->lin_failed) return; cams_out = d.cams2[d.lm->cur ^ 1]; }
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.C) return;
-    const double *cam = d.cams + 7 * c;
-    double out[7];
-    for (int i = 0; i < 7; ++i) out[i] = cam[i];
-    const int n = d.cam_ldim[c], off = d.cam_off[c];
-    double dl[6];
-    for (int t = 0; t < 6; ++t) dl[t] = t < n ? -y_c[off + t] * d.scale_c[off + t] : 0.0;
-    int t = 0;
-    if (d.model == kModelQuat && n > 0 && d.cam_colmap[6 * c] == 0) { quat_plus(cam, dl, out); t = 3; }
-    for (; t < n; ++t) {
-        const int f = d.cam_colmap[6 * c + t];
-        const int slot = d.model == kModelQuat ? f + 1 : f;
-        out[slot] = cam[slot] + dl[t];
-    }
-    // norms over the ambient coordinates of the non-constant blocks
-    double sn = 0.0, xn = 0.0;
-    bool act[7] = { false, false, false, false, false, false, false };
-    for (int tt = 0; tt < n; ++tt) {
-        const int f = d.cam_colmap[6 * c + tt];
-        if (d.model == kModelQuat) {
-            if (f < 3) { act[0] = act[1] = act[2] = act[3] = true; } else act[f + 1] = true;
-        } else act[f] = true;
-    }
-    for (int i = 0; i < 7; ++i) {
-        cams_out[7 * c + i] = out[i];
-        if (act[i]) { sn += (cam[i] - out[i]) * (cam[i] - out[i]); xn += cam[i] * cam[i]; }
-    }
-    partials_cam[2 * c] = sn;
-    partials_cam[2 * c + 1] = xn;
+    cam_update_one(d, y_c, cams_out, partials_cam, c);
 }
 
 void launch_cam_update(const BaDev &d, const double *y_c, double *cams_out, double *partials_cam, hipStream_t s)
@@ -723,20 +696,17 @@ __device__ __forceinline__ double strided_reduce(const double *p, int n, int str
 // After the candidate of an iteration has been evaluated: step validity, the parameter /
 // function tolerance tests, accept or reject, the new radius, and what the linearisation
 // that follows has to do.
-__global__ __launch_bounds__(256) void
-ba_lm_decide_kernel(LmDev *lm, LmParams prm, LmScratch sc)
+// state -> the host's slot for this iteration (page-locked memory the device writes directly:
+// a copy engine transfer per iteration cost 4 us plus a 6 us bubble before the next kernel)
+__device__ __forceinline__ void publish_state(const LmDev *lm, LmDev *host_out)
 {
-    __shared__ double sh[256];
-    if (lm->stop) return;
-    const bool solved = !lm->lin_failed;
-    double mcc = 0.0, sn = 0.0, xn = 0.0, cand = 0.0;
-    if (solved) {
-        mcc = strided_reduce(sc.partB, sc.blocksM, 1, false, sh);
-        sn = strided_reduce(sc.partB + sc.blocksM, sc.blocksM, 1, false, sh) + strided_reduce(sc.part_cam, sc.C, 2, false, sh);
-        xn = strided_reduce(sc.partB + 2 * (size_t)sc.blocksM, sc.blocksM, 1, false, sh) + strided_reduce(sc.part_cam + 1, sc.C, 2, false, sh);
-        cand = strided_reduce(sc.partC, sc.blocksM, 1, false, sh);
-    }
-    if (threadIdx.x != 0) return;
+    if (host_out) *host_out = *lm;
+}
+
+__device__ __forceinline__ void
+lm_decide_logic(LmDev *lm, const LmParams &prm, const LmScratch &sc, bool solved, double mcc, double sn, double xn,
+    double cand)
+{
     const int info = *sc.chol_info;
     *sc.chol_info = 0;
     const double step_norm = sqrt(sn), x_norm = sqrt(xn);
@@ -775,18 +745,38 @@ ba_lm_decide_kernel(LmDev *lm, LmParams prm, LmScratch sc)
     }
 }
 
-// After a linearisation: cost / gradient norm of a new iterate, the not-positive-definite
-// flag, then FinalizeIterationAndCheckIfMinimizerCanContinue for the iteration that follows.
 __global__ __launch_bounds__(256) void
-ba_lm_post_kernel(LmDev *lm, LmParams prm, LmScratch sc, int initial)
+ba_lm_decide_kernel(LmDev *lm, LmParams prm, LmScratch sc, LmDev *host_out)
 {
     __shared__ double sh[256];
-    if (lm->stop) return;
-    const double cost = strided_reduce(sc.partA, sc.blocksM, 1, false, sh);
-    const double gp = strided_reduce(sc.partA + sc.blocksM, sc.blocksM, 1, true, sh);
-    const double bad = strided_reduce(sc.partA + 2 * (size_t)sc.blocksM, sc.blocksM, 1, true, sh);
-    const double gc = strided_reduce(sc.gmax_cam, sc.C, 1, true, sh);
+    if (lm->stop) { if (threadIdx.x == 0) publish_state(lm, host_out); return; }
+    const bool solved = !lm->lin_failed;
+    double mcc = 0.0, sn = 0.0, xn = 0.0, cand = 0.0;
+    if (solved) {
+        mcc = strided_reduce(sc.partB, sc.blocksM, 1, false, sh);
+        sn = strided_reduce(sc.partB + sc.blocksM, sc.blocksM, 1, false, sh) + strided_reduce(sc.part_cam, sc.C, 2, false, sh);
+        xn = strided_reduce(sc.partB + 2 * (size_t)sc.blocksM, sc.blocksM, 1, false, sh) + strided_reduce(sc.part_cam + 1, sc.C, 2, false, sh);
+        cand = strided_reduce(sc.partC, sc.blocksM, 1, false, sh);
+    }
+    // a one-block system was consumed by the solve at the head of this iteration: clear it
+    // for the linearisation that follows (saves that launch its own reset kernel)
+    if (sc.reset_S) {
+        const int N = sc.reset_N, n = sc.reset_n;
+        for (int i = threadIdx.x; i < (N + 32) * N; i += blockDim.x) {
+            const int row = i / N, col = i - row * N;
+            sc.reset_S[i] = (row == col && row >= n && row < N) ? 1.0 : 0.0;
+        }
+    }
     if (threadIdx.x != 0) return;
+    lm_decide_logic(lm, prm, sc, solved, mcc, sn, xn, cand);
+    publish_state(lm, host_out);
+}
+
+// After a linearisation: cost / gradient norm of a new iterate, the not-positive-definite
+// flag, then FinalizeIterationAndCheckIfMinimizerCanContinue for the iteration that follows.
+__device__ __forceinline__ void
+lm_post_logic(LmDev *lm, const LmParams &prm, int initial, double cost, double gp, double bad, double gc)
+{
     if (lm->want_gradient) { lm->x_cost = cost; lm->grad_max = fmax(gp, gc); }
     lm->lin_failed = bad != 0.0 ? 1 : 0;
     if (initial) {
@@ -803,27 +793,52 @@ ba_lm_post_kernel(LmDev *lm, LmParams prm, LmScratch sc, int initial)
     lm->last_successful = 0;
 }
 
-void launch_lm_decide(LmDev *lm, const LmParams &prm, const LmScratch &sc, hipStream_t s)
+__global__ __launch_bounds__(256) void
+ba_lm_post_kernel(LmDev *lm, LmParams prm, LmScratch sc, int initial, LmDev *host_out)
 {
-    hipLaunchKernelGGL(ba_lm_decide_kernel, dim3(1), dim3(256), 0, s, lm, prm, sc);
+    __shared__ double sh[256];
+    if (lm->stop) { if (threadIdx.x == 0) publish_state(lm, host_out); return; }
+    const double cost = strided_reduce(sc.partA, sc.blocksM, 1, false, sh);
+    const double gp = strided_reduce(sc.partA + sc.blocksM, sc.blocksM, 1, true, sh);
+    const double bad = strided_reduce(sc.partA + 2 * (size_t)sc.blocksM, sc.blocksM, 1, true, sh);
+    const double gc = strided_reduce(sc.gmax_cam, sc.C, 1, true, sh);
+    if (threadIdx.x != 0) return;
+    lm_post_logic(lm, prm, initial, cost, gp, bad, gc);
+    publish_state(lm, host_out);
 }
 
-void launch_lm_post(LmDev *lm, const LmParams &prm, const LmScratch &sc, int initial, hipStream_t s)
+void launch_lm_decide(LmDev *lm, const LmParams &prm, const LmScratch &sc, LmDev *host_out, hipStream_t s)
 {
-    hipLaunchKernelGGL(ba_lm_post_kernel, dim3(1), dim3(256), 0, s, lm, prm, sc, initial);
+    hipLaunchKernelGGL(ba_lm_decide_kernel, dim3(1), dim3(256), 0, s, lm, prm, sc, host_out);
 }
 
-// identity on the padding diagonal of the (zeroed) reduced system
-__global__ void
-ba_pad_diag_kernel(double *S, int ld, int n, int N)
+void launch_lm_post(LmDev *lm, const LmParams &prm, const LmScratch &sc, int initial, LmDev *host_out, hipStream_t s)
 {
-    const int i = n + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) S[(size_t)i * ld + i] = 1.0;
+    hipLaunchKernelGGL(ba_lm_post_kernel, dim3(1), dim3(256), 0, s, lm, prm, sc, initial, host_out);
 }
 
-void launch_pad_diag(double *S, int ld, int n, int N, hipStream_t s)
+// zero, with the identity on the padding diagonal
+__global__ __launch_bounds__(256) void
+ba_reset_system_kernel(double2 *S2, size_t pairs, double *S, int ld, int n, int N)
 {
-    if (N > n) hipLaunchKernelGGL(ba_pad_diag_kernel, dim3(1), dim3(64), 0, s, S, ld, n, N);
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // element (r, r) of the padding diagonal, r in [n, N): 1, everything else 0
+    if (i < pairs) {
+        double2 v = {0.0, 0.0};
+        const size_t e = 2 * i, row = e / (size_t)ld, col = e - row * (size_t)ld;     // ld is even (a multiple of 32)
+        if (row >= (size_t)n && row < (size_t)N) {
+            if (col == row) v.x = 1.0;
+            if (col + 1 == row) v.y = 1.0;
+        }
+        S2[i] = v;
+    }
+}
+
+void launch_reset_system(double *S, size_t elems, int ld, int n, int N, hipStream_t s)
+{
+    const size_t pairs = elems / 2;
+    hipLaunchKernelGGL(ba_reset_system_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s,
+        reinterpret_cast<double2 *>(S), pairs, S, ld, n, N);
 }
 
 // v[i] = value (the unit Jacobi scales before their first estimate)

@@ -57,11 +57,11 @@ pair_fill_kernel(BaDev d, int with_points, const int32_t *offsets, uint32_t *key
 
 // chunks (= pair-pass waves) per camera pair; entry num_pairs is the trailing zero of the scan
 __global__ void
-pair_chunk_count_kernel(const int32_t *runs, int num_pairs, int32_t *chunks)
+pair_chunk_count_kernel(const int32_t *runs, int num_pairs, int chunk, int32_t *chunks)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > num_pairs) return;
-    chunks[i] = i < num_pairs ? (runs[i] + kPairChunk - 1) / kPairChunk : 0;
+    chunks[i] = i < num_pairs ? (runs[i] + chunk - 1) / chunk : 0;
 }
 
 // chunk (= wave) -> pair, so that a pair-pass wave finds its work with one load
@@ -151,13 +151,14 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
         out->starts.as<int32_t>(), h_runs + 1, s));
     // chunks of the pair pass: chunk_start = exclusive scan of ceil(run / kPairChunk); the number
     // of waves to launch is bounded without reading anything back
-    out->max_chunks = h_runs + E / kPairChunk;
+    out->chunk = E < kPairChunkSmallLimit ? kPairChunkSmall : kPairChunk;
+    out->max_chunks = h_runs + E / out->chunk;
     OSFM_RETURN_IF(out->chunk_start.reserve((size_t)(h_runs + 1) * 4));
     OSFM_RETURN_IF(out->multi_pairs.reserve((size_t)(h_runs + 1) * 4));
     OSFM_RETURN_IF(out->chunk_partials.reserve((size_t)out->max_chunks * kPairSums * sizeof(double)));
     // the run lengths are not needed after this: the chunk counts take their place
     hipLaunchKernelGGL(pair_chunk_count_kernel, dim3((h_runs + 256) / 256), dim3(256), 0, s,
-        out->runs.as<int32_t>(), h_runs, out->counts.as<int32_t>());
+        out->runs.as<int32_t>(), h_runs, out->chunk, out->counts.as<int32_t>());
     tb = out->temp.bytes;
     OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(out->temp.ptr, tb, out->counts.as<int32_t>(),
         out->chunk_start.as<int32_t>(), h_runs + 1, s));

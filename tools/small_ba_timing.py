@@ -8,7 +8,10 @@ import numpy as np
 from orthosfm_amd import ba, synth
 
 out = []
-for cams, pts in ((3, 300), (3, 3000), (3, 20000), (6, 3000), (12, 5000)):
+cases = ((3, 300), (3, 3000), (3, 20000), (6, 3000), (12, 5000))
+if len(sys.argv) > 2:
+    cases = ((int(sys.argv[1]), int(sys.argv[2])),)
+for cams, pts in cases:
     sc = synth.make_ba_scene(synth.MODEL_QUATERNION, cams, pts, config_id=1)
     ba.solve(ba.FlatProblem.from_scene(sc), max_num_iterations=2)
     wall, loop, its = [], [], []
