@@ -189,6 +189,22 @@ def ba_cpu_baseline(iterations=2):
                       "(residual/Jacobian evaluation and the dense Cholesky trailing updates OpenMP-parallel, Schur accumulation serial)"}
 
 
+def local_ba_cpu_baseline(gpu):
+    """The BA oracle on the same 3-camera problem, whole solve (it is small enough)."""
+    import oracle_lib
+    from orthosfm_amd import synth
+    sc = synth.make_ba_scene(synth.MODEL_QUATERNION, 3, 3000, config_id=1)
+    t0 = time.perf_counter()
+    s = oracle_lib.oracle_ba_solve(sc, max_num_iterations=50)
+    dt = time.perf_counter() - t0
+    return {"value": 1e6 * dt / max(s.num_iterations, 1), "unit": "us per LM iteration",
+            "call_ms": dt * 1e3, "iterations": int(s.num_iterations),
+            "cores": int(oracle_lib.oracle().oracle_num_threads()), "kind": "port",
+            "sample": "the whole solve of the same problem",
+            "iterations_equal_gpu": bool(s.num_iterations == gpu["iterations"]),
+            "final_cost_rel_diff": abs(s.final_cost - gpu["final_cost"]) / max(abs(s.final_cost), 1e-300)}
+
+
 def ba_roofline(ba):
     """Q_B = 2*24*O + 96*M + 2*8*(dC)^2 algorithmic bytes per LM iteration
     (observations read for linearisation and trial cost, points read twice and written,
@@ -684,6 +700,14 @@ def main():
 
     if ba is not None and "error" not in ba and not args.no_cpu_baseline and rank == 0:
         ba["cpu_baseline"] = ba_cpu_baseline()
+
+    if ba is not None and "error" not in ba and rank == 0:
+        try:
+            ba["local_ba"] = ba_mod.bench_local_ba()
+            if not args.no_cpu_baseline:
+                ba["local_ba"]["cpu_baseline"] = local_ba_cpu_baseline(ba["local_ba"])
+        except Exception as e:
+            ba["local_ba"] = {"error": str(e)}
 
     if ba is not None and "error" not in ba and rank == 0:
         try:

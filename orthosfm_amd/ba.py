@@ -299,3 +299,28 @@ def bench_global_ba(num_cameras=200, num_points=100000, max_iterations=25, devic
             "observations": int(fp.obs_camera.size), "points": int(num_points),
             # tangent size of the free camera blocks: 3 per free rotation, 1 per free scalar
             "camera_unknowns": int(sum((0 if c[0] else 3) + int((c[4:] == 0).sum()) for c in fp.cam_const))}
+
+
+def bench_local_ba(num_points=3000, num_cameras=3, device=0, repeats=5):
+    """BASELINE configs[0] / the per-group call of the incremental reconstruction
+    (reconstruct.cpp:219): a 3-camera quaternion BA.  Latency of one call and of one LM
+    iteration inside it (best of `repeats`)."""
+    import time
+    from . import synth
+    sc = synth.make_ba_scene(synth.MODEL_QUATERNION, num_cameras, num_points, config_id=1)
+    solve(FlatProblem.from_scene(sc), max_num_iterations=2, device=device)
+    best = None
+    for _ in range(repeats):
+        fp = FlatProblem.from_scene(sc)
+        t0 = time.perf_counter()
+        s = solve(fp, max_num_iterations=50, device=device)
+        call_ms = (time.perf_counter() - t0) * 1e3
+        if best is None or call_ms < best[0]:
+            best = (call_ms, s)
+    call_ms, s = best
+    return {"workload": f"{num_cameras} quaternion cameras, {num_points} tracks, {fp.obs_camera.size} observations "
+                        "(the local adjustment of one camera group)",
+            "iterations": int(s.num_iterations), "call_ms": call_ms, "lm_loop_ms": s.lm_loop_ms,
+            "us_per_iteration": 1e3 * s.lm_loop_ms / max(s.num_iterations, 1),
+            "iterations_per_s": s.num_iterations / max(s.lm_loop_ms * 1e-3, 1e-9),
+            "final_cost": s.final_cost, "termination": TERMINATION.get(s.termination, "?")}

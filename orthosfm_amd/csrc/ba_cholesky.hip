@@ -68,61 +68,69 @@ factor_diag_block(const double *Msrc, int lds_ld, double (*LsT)[NB], int kblock,
     // nvalid: rows / columns from there on are identity padding (wave-uniform); their pivot
     // steps and inverse rows change nothing and are skipped -- the chain is serial, so a
     // 17-unknown system (three cameras) is done in half the time of a full block
-    __shared__ __attribute__((aligned(16))) double colbuf[2][NB];      // [pivot parity][row]
+    __shared__ __attribute__((aligned(16))) double colbuf[2][2 * NB];  // [pivot parity][lane]: column j of L in [0, NB)
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    double L[NB], dinv[NB];
+    // Lanes 0..31: row r of the block, turning into row r of L.  Lanes 32..63: e_r, turning
+    // into column r of inv(L) (L x = e_r, column-oriented: once x[j] is final every later
+    // entry takes L[i][j] x[j]).  Both are the SAME instructions -- v[j] *= 1/L[j][j], then
+    // v[c] -= v[j] * L[c][j] for c > j -- so the inverse costs nothing beyond the lanes that
+    // used to mirror the factorisation, and its chain hangs off the pivot chain instead of
+    // forming a second one of 32 links behind it.
+    double v[NB];
 #pragma unroll
-    for (int c = 0; c < NB; ++c) L[c] = Msrc[r * lds_ld + c];
+    for (int c = 0; c < NB; ++c) v[c] = h == 0 ? Msrc[r * lds_ld + c] : (c == r ? 1.0 : 0.0);
     int bad = 0;
+    // Pivot j: only column j + 1 has to be final before pivot j + 1 can start, so that
+    // column takes its multiplier L[j+1][j] by v_readlane right away and the next pivot's
+    // reciprocal square root (the longest link of the chain) is started at once; the other
+    // columns take their multipliers from LDS (broadcast ds_read_b128, two each) -- a round
+    // trip of > 100 cycles -- with the reads issued in front of that chain and consumed
+    // behind it.
+    double d = nvalid > 0 ? readlane_d(v[0], 0) : 1.0;
+    if (!(d > 0.0)) { d = 1.0; bad = 1; }
+    double rinv = rsqrt_newton(d);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        if (j >= nvalid) { dinv[j] = 1.0; continue; }
-        double d = readlane_d(L[j], j);
-        if (!(d > 0.0)) { d = 1.0; bad = j + 1; }
-        const double rinv = rsqrt_newton(d);
-        dinv[j] = rinv;
-        const double lj = (r == j && bad == j + 1) ? 1.0 : L[j] * rinv;   // lane j: d / sqrt(d) = sqrt(d)
-        L[j] = lj;
+        if (j >= nvalid) continue;          // identity rows: nothing to eliminate, x[j] stays e_r[j]
+        const double vj = (lane == j && bad == j + 1) ? 1.0 : v[j] * rinv;   // lane j: d / sqrt(d) = sqrt(d)
+        v[j] = vj;
         if (j + 1 < NB) {
-            colbuf[j & 1][r] = lj;          // both twins store the same value
+            colbuf[j & 1][lane] = vj;           // lanes 0..31: column j of L (the rest is not read)
             // The LDS executes one wave's operations in order, so no wait is needed -- but the
             // COMPILER must be told that other lanes wrote what this lane is about to read
             // (without the fence it re-used values a lane had loaded two pivots earlier)
             asm volatile("" ::: "memory");
+            double col[NB];
 #pragma unroll
-            for (int c = j + 1; c < NB; ++c) L[c] = fma(-lj, colbuf[j & 1][c], L[c]);   // meaningful for r >= c
+            for (int c = j + 2; c < NB; ++c) col[c] = colbuf[j & 1][c];
+            __builtin_amdgcn_sched_barrier(0);
+            v[j + 1] = fma(-vj, readlane_d(vj, j + 1), v[j + 1]);
+            if (j + 1 < nvalid) {
+                d = readlane_d(v[j + 1], j + 1);
+                if (!(d > 0.0)) { d = 1.0; bad = j + 2; }
+                rinv = rsqrt_newton(d);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = j + 2; c < NB; ++c) v[c] = fma(-vj, col[c], v[c]);    // L: meaningful for r >= c
         }
     }
     if (bad && lane == 0) atomicMax(info, kblock * NB + bad);
-    // L, row-major, for the inverse: LsT[i][c] = L[i][c] (zero above the diagonal)
-    if (h == 0) {
+    // L itself, transposed (LsT[c][i] = L[i][c], zero above the diagonal), for a caller that
+    // wants to look at it: lane r writes element r of every row, consecutive addresses
+    if (LsT && h == 0) {
 #pragma unroll
-        for (int c = 0; c < NB; ++c) LsT[r][c] = c <= r ? L[c] : 0.0;
+        for (int c = 0; c < NB; ++c) LsT[c][r] = c <= r ? v[c] : 0.0;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // one wave: its LDS writes land in order
-    // inv(L): lane (j, h) solves L x = e_j, the two halves sharing every dot product
-    // (columns c of parity h each, folded with one swap)
-    double x[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        if (i >= nvalid) { x[i] = (i == r) ? 1.0 : 0.0; continue; }
-        double acc = 0.0;
-#pragma unroll
-        for (int c = 0; c < i; ++c)
-            if ((c & 1) == 0) { if (h == 0) acc = fma(-LsT[i][c], x[c], acc); }
-            else { if (h == 1) acc = fma(-LsT[i][c], x[c], acc); }
-        acc += swap_halves(acc);
-        x[i] = (acc + ((i == r) ? 1.0 : 0.0)) * dinv[i];
-    }
-    if (h == 0) {
+    if (h == 1) {
         double *Lk = Ldiag + (size_t)kblock * NB * NB;                          // [i][j] = inv(L)[i][j]
 #pragma unroll
-        for (int i = 0; i < NB; ++i) Lk[i * NB + r] = x[i];
+        for (int i = 0; i < NB; ++i) Lk[i * NB + r] = v[i];
         // a copy in LDS for a caller that goes on to use it (Msrc itself may be the target:
         // the block was read into registers at the top)
         if (linv_lds) {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) linv_lds[i * linv_ld + r] = x[i];
+            for (int i = 0; i < NB; ++i) linv_lds[i * linv_ld + r] = v[i];
         }
     }
 }
@@ -133,21 +141,19 @@ chol_first_kernel(const double *A, int ld, double *Ldiag, int *info, const LmDev
 {
     if (lm && (lm->stop || lm->lin_failed)) return;
     __shared__ __attribute__((aligned(16))) double M[NB][NB + 1];
-    __shared__ __attribute__((aligned(16))) double LsT[NB][NB];
     const int lane = threadIdx.x, r = lane & 31;
     if (lane < NB) {
 #pragma unroll
         for (int c = 0; c < NB; ++c) M[r][c] = A[(size_t)r * ld + c];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    factor_diag_block(&M[0][0], NB + 1, LsT, 0, Ldiag, info);
+    factor_diag_block(&M[0][0], NB + 1, nullptr, 0, Ldiag, info);
 }
 
 // A system of one block (n <= 32: the three-camera adjustments of the incremental
 // reconstruction) start to finish in one launch of one wave: factor, y = inv(L) b,
 // x = inv(L)^T y, and the candidate cameras Plus(x, -step) that the next kernel needs --
-// four launches of a latency-bound chain in one.  Same operation order as the general
-// path's kernels (chol_rhs_tail / chol_backsolve), so both give the same bits.
+// four launches of a latency-bound chain in one.
 __global__ __launch_bounds__(64, 1) void
 chol_small_kernel(const double *A, int ld, int n, double *Ldiag, double *x, int *info, BaDev d,
     double *partials_cam)
@@ -155,7 +161,6 @@ chol_small_kernel(const double *A, int ld, int n, double *Ldiag, double *x, int 
     if (!lm_resolve(d)) return;
     if (d.lm->lin_failed) return;
     __shared__ __attribute__((aligned(16))) double M[NB][NB + 1];
-    __shared__ __attribute__((aligned(16))) double LsT[NB][NB];
     __shared__ double ys[NB], xs[NB];
     const int lane = threadIdx.x, r = lane & 31;
     double b = 0.0;
@@ -165,7 +170,7 @@ chol_small_kernel(const double *A, int ld, int n, double *Ldiag, double *x, int 
         b = A[(size_t)NB * ld + r];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    factor_diag_block(&M[0][0], NB + 1, LsT, 0, Ldiag, info, &M[0][0], NB + 1, n);  // M := inv(L)
+    factor_diag_block(&M[0][0], NB + 1, nullptr, 0, Ldiag, info, &M[0][0], NB + 1, n);  // M := inv(L)
     if (lane < NB) ys[lane] = b;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     double acc = 0.0;
@@ -212,7 +217,6 @@ chol_step_kernel(double *A, double *Lout, int ld, int nblk, int k, double *Ldiag
     __shared__ __attribute__((aligned(16))) double Aj[NB][NB + 1];      // A_jk
     __shared__ __attribute__((aligned(16))) double Xi[NB][NB + 1];      // L_ik
     __shared__ __attribute__((aligned(16))) double Xj[NB][NB + 1];      // L_jk
-    __shared__ __attribute__((aligned(16))) double LsT[NB][NB];
     const int tid = threadIdx.x;
     const int r = tid >> 3, c0 = (tid & 7) * 4;
     const double *Lk = Ldiag + (size_t)k * NB * NB;
@@ -264,7 +268,7 @@ chol_step_kernel(double *A, double *Lout, int ld, int nblk, int k, double *Ldiag
     }
     if (!next_diag) return;
     __syncthreads();
-    if (tid < 64) factor_diag_block(&Ai[0][0], NB + 1, LsT, k + 1, Ldiag, info);
+    if (tid < 64) factor_diag_block(&Ai[0][0], NB + 1, nullptr, k + 1, Ldiag, info);
 }
 
 // The right-hand side's last block: y_k = b_k inv(L_kk)^T for k = nblk - 1 (every earlier

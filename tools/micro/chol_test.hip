@@ -16,7 +16,7 @@ __global__ void dbg_factor(const double *A, int ld, double *Ldiag, int *info, do
     __syncthreads();
     factor_diag_block(&M[0][0], NB + 1, LsT, 0, Ldiag, info);
     __syncthreads();
-    if (lane < NB) for (int c = 0; c < NB; ++c) Lout[r * NB + c] = LsT[r][c];
+    if (lane < NB) for (int c = 0; c < NB; ++c) Lout[r * NB + c] = LsT[c][r];
 }
 int main()
 {
