@@ -42,6 +42,13 @@ OSFM_API int osfm_device_count(void);
  * batches and check that handles give their memory back. */
 OSFM_API int osfm_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 
+/* The work arrays of the bundle-adjustment / triangulation / filter calls come from a
+ * per-device cache of device memory (hipMalloc and hipFree cost 50-100 us apiece, dozens per
+ * call, hundreds of calls per reconstruction); at most 8 GiB per device are kept.  This
+ * hands what is cached on `device` (-1: all devices) back to the driver; *released_bytes
+ * (may be NULL) reports how much that was. */
+OSFM_API int osfm_trim_device_memory(int device, uint64_t *released_bytes);
+
 /* ====================================================================== */
 /* (A) Matching                                                            */
 /* ====================================================================== */

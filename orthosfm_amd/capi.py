@@ -113,7 +113,7 @@ class BaSummary(C.Structure):
 
 # every symbol include/osfm_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = [
-    "osfm_last_error", "osfm_version", "osfm_device_count", "osfm_device_memory",
+    "osfm_last_error", "osfm_version", "osfm_device_count", "osfm_device_memory", "osfm_trim_device_memory",
     "osfm_match_options_default", "osfm_match_create", "osfm_match_destroy",
     "osfm_quantize_sift", "osfm_quantize_surf",
     "osfm_match_set_view", "osfm_match_set_view_float", "osfm_match_view_size", "osfm_match_set_positions",
@@ -153,6 +153,13 @@ def _ptr(a, ctype):
 
 def device_count() -> int:
     return lib.osfm_device_count()
+
+
+def trim_device_memory(device: int = -1) -> int:
+    """Hands the cached work-array memory back to the driver; returns the bytes released."""
+    b = C.c_uint64()
+    check(lib.osfm_trim_device_memory(C.c_int(device), C.byref(b)))
+    return b.value
 
 
 def device_memory(device: int = 0):

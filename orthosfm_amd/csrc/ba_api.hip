@@ -21,14 +21,14 @@ using namespace osfm;
 
 namespace {
 
+// a work array of one call, from the pool of osfm_common.h
 struct DevArray {
     void *ptr = nullptr;
-    ~DevArray() { if (ptr) (void)hipFree(ptr); }
+    ~DevArray() { if (ptr) pool_release(ptr); }
     int alloc(size_t bytes)
     {
-        if (ptr) { (void)hipFree(ptr); ptr = nullptr; }
-        OSFM_HIP_CHECK(hipMalloc(&ptr, std::max<size_t>(bytes, 16)));
-        return OSFM_OK;
+        if (ptr) { pool_release(ptr); ptr = nullptr; }
+        return g_device_pool.alloc(&ptr, std::max<size_t>(bytes, 16));
     }
     template <typename T> T *as() const { return static_cast<T *>(ptr); }
 };

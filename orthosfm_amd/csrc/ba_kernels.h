@@ -110,8 +110,8 @@ void launch_triangulate(const BaDev &d, double *points_out, uint8_t *valid, hipS
 
 // camera-pair lists built on the device (ba_pairs.hip)
 struct PairListsDev {
-    DeviceBuffer counts, offsets, keys_in, keys, vals_in, entries, unique, runs, starts, scalars, temp;
-    DeviceBuffer chunk_start, chunk_pair, chunk_partials, multi_pairs;
+    PooledBuffer counts, offsets, keys_in, keys, vals_in, entries, unique, runs, starts, scalars, temp;
+    PooledBuffer chunk_start, chunk_pair, chunk_partials, multi_pairs;
     int num_pairs = 0;
     int num_entries = 0;
     int max_chunks = 0;
@@ -119,7 +119,7 @@ struct PairListsDev {
     int num_multi = 0;
     ~PairListsDev()
     {
-        DeviceBuffer *b[] = {&counts, &offsets, &keys_in, &keys, &vals_in, &entries, &unique, &runs, &starts, &scalars, &temp,
+        PooledBuffer *b[] = {&counts, &offsets, &keys_in, &keys, &vals_in, &entries, &unique, &runs, &starts, &scalars, &temp,
                              &chunk_start, &chunk_pair, &chunk_partials, &multi_pairs};
         for (auto *x : b) x->release();
     }

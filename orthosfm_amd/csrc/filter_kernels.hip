@@ -61,7 +61,7 @@ int nn_distances_device(int device, const double *points, int n, double *nn_out)
     StreamLease lease;                       // pooled: creating a stream costs ~1 ms
     OSFM_RETURN_IF(lease.acquire());
     hipStream_t s = lease.s;
-    DeviceBuffer d_pts, d_nn;
+    PooledBuffer d_pts, d_nn;
     int rc = d_pts.reserve((size_t)n * 32);
     if (rc == OSFM_OK) rc = d_nn.reserve((size_t)n * 8);
     if (rc == OSFM_OK) {

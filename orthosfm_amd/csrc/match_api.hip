@@ -545,6 +545,19 @@ int osfm_device_count(void)
     return n;
 }
 
+int osfm_trim_device_memory(int device, uint64_t *released_bytes)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("trim_device_memory: no HIP device available");
+        return OSFM_E_DEVICE;
+    }
+    if (device < -1 || device >= ndev) { set_error("trim_device_memory: device %d out of range [-1,%d)", device, ndev); return OSFM_E_ARG; }
+    const size_t b = g_device_pool.trim(device);
+    if (released_bytes) *released_bytes = b;
+    return OSFM_OK;
+}
+
 int osfm_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes)
 {
     int ndev = 0;

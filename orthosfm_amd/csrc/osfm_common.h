@@ -3,8 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <map>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/osfm_hip.h"
@@ -61,6 +63,128 @@ struct DeviceBuffer {
     template <typename T> T *as() const { return static_cast<T *>(ptr); }
 };
 
+// Device memory of the short-lived work arrays of a call (bundle adjustment, triangulation,
+// the filters: dozens of arrays per call, hundreds of calls per reconstruction).  hipMalloc /
+// hipFree cost 50-100 us apiece -- hipFree also synchronises the device -- which was two
+// thirds of a global-adjustment call inside the incremental reconstruction.  Blocks handed
+// back are kept, by size class (steps of 1/8 of a power of two, at most 12.5 % slack), and
+// given out again; osfm_trim_device_memory() returns them to the driver.  What is kept is
+// bounded (kPoolKeepBytes per device); beyond it a block is freed at once.
+struct DevicePool {
+    static constexpr size_t kPoolKeepBytes = (size_t)8 << 30;
+    struct Block { void *ptr; size_t bytes; };
+    std::mutex mutex;
+    std::unordered_map<int, std::multimap<size_t, void *>> free_blocks;    // device -> size class -> blocks
+    std::unordered_map<void *, std::pair<int, size_t>> live;               // block -> (device, size class)
+    std::unordered_map<int, size_t> kept;                                   // bytes in free_blocks per device
+    static size_t size_class(size_t bytes)
+    {
+        size_t b = bytes < 256 ? 256 : bytes;
+        size_t p = 256;
+        while (p < b) p <<= 1;                 // smallest power of two >= b
+        const size_t step = p >> 4;             // sixteenths of it = eighths of the power below
+        return step ? (b + step - 1) / step * step : p;
+    }
+    int alloc(void **out, size_t bytes)
+    {
+        int device = 0;
+        OSFM_HIP_CHECK(hipGetDevice(&device));
+        const size_t cls = size_class(bytes);
+        {
+            std::lock_guard<std::mutex> lock(mutex);
+            auto &fb = free_blocks[device];
+            auto it = fb.find(cls);
+            if (it != fb.end()) {
+                *out = it->second;
+                fb.erase(it);
+                kept[device] -= cls;
+                live[*out] = {device, cls};
+                return OSFM_OK;
+            }
+        }
+        hipError_t e = hipMalloc(out, cls);
+        if (e != hipSuccess) {
+            // out of memory with blocks of other sizes lying idle: hand them back and retry once
+            (void)hipGetLastError();
+            trim(device);
+            e = hipMalloc(out, cls);
+        }
+        OSFM_HIP_CHECK(e);
+        std::lock_guard<std::mutex> lock(mutex);
+        live[*out] = {device, cls};
+        return OSFM_OK;
+    }
+    void free(void *ptr)
+    {
+        if (!ptr) return;
+        int device = -1;
+        size_t cls = 0;
+        {
+            std::lock_guard<std::mutex> lock(mutex);
+            auto it = live.find(ptr);
+            if (it != live.end()) {
+                device = it->second.first; cls = it->second.second;
+                live.erase(it);
+                if (kept[device] + cls <= kPoolKeepBytes) {
+                    free_blocks[device].emplace(cls, ptr);
+                    kept[device] += cls;
+                    return;
+                }
+            }
+        }
+        (void)hipFree(ptr);
+    }
+    // frees what is kept for `device` (-1: every device); returns the bytes released
+    size_t trim(int device)
+    {
+        std::vector<void *> victims;
+        size_t bytes = 0;
+        {
+            std::lock_guard<std::mutex> lock(mutex);
+            for (auto &dev : free_blocks) {
+                if (device >= 0 && dev.first != device) continue;
+                for (auto &b : dev.second) { victims.push_back(b.second); bytes += b.first; }
+                dev.second.clear();
+                kept[dev.first] = 0;
+            }
+        }
+        for (void *p : victims) (void)hipFree(p);
+        return bytes;
+    }
+};
+inline DevicePool g_device_pool;
+
+// Blocks released while a stream lease is active on this thread may still be in use by
+// work queued on that stream (an error path returns with kernels in flight); they go back
+// to the pool only after the lease has drained its stream (StreamLease::~StreamLease).
+struct StreamLease;
+inline thread_local StreamLease *g_active_lease = nullptr;
+inline void pool_release(void *ptr);
+
+// DeviceBuffer's interface on pooled memory (grow-only, contents not preserved on growth)
+struct PooledBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    PooledBuffer() = default;
+    PooledBuffer(const PooledBuffer &) = delete;
+    PooledBuffer &operator=(const PooledBuffer &) = delete;
+    ~PooledBuffer() { release(); }
+    int reserve(size_t need)
+    {
+        if (need <= bytes) return OSFM_OK;
+        release();
+        OSFM_RETURN_IF(g_device_pool.alloc(&ptr, need));
+        bytes = DevicePool::size_class(need);
+        return OSFM_OK;
+    }
+    void release()
+    {
+        if (ptr) pool_release(ptr);
+        ptr = nullptr; bytes = 0;
+    }
+    template <typename T> T *as() const { return static_cast<T *>(ptr); }
+};
+
 // A stream and its timing events, leased for the duration of one call.  Creating a
 // stream costs about a millisecond -- a real share of a 15 ms solve that the
 // incremental reconstruction repeats for every camera group -- so the sets live in
@@ -101,8 +225,12 @@ struct StreamLease {
     hipStream_t s = nullptr;
     EventPair *ev = nullptr;
     StreamSet *set = nullptr;
+    StreamLease *outer = nullptr;            // the lease this one nests in (same thread)
+    std::vector<void *> pending_free;        // pool blocks released while this lease was active
+    bool active = false;
     int acquire()
     {
+        outer = g_active_lease; g_active_lease = this; active = true;
         int device = 0;
         OSFM_HIP_CHECK(hipGetDevice(&device));
         {
@@ -135,12 +263,20 @@ struct StreamLease {
     }
     ~StreamLease()
     {
+        if (set) (void)hipStreamSynchronize(set->s);  // nothing of this call may still run when the next one reuses it
+        if (active) g_active_lease = outer;
+        for (void *p : pending_free) g_device_pool.free(p);
         if (!set) return;
-        (void)hipStreamSynchronize(set->s);       // nothing of this call may still run when the next one reuses it
         std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
         g_stream_pool.push_back(set);
     }
 };
+
+inline void pool_release(void *ptr)
+{
+    if (g_active_lease) g_active_lease->pending_free.push_back(ptr);
+    else g_device_pool.free(ptr);
+}
 
 
 }  // namespace osfm

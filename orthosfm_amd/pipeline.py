@@ -332,7 +332,7 @@ def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, ti
 
 def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2.0, off_perturb=0.01,
                         seed=7, timings=None, capture=(), max_groups=None, verbose=False, view_ids=None,
-                        euler_dof=4):
+                        euler_dof=4, check_incremental=False):
     """runPoseEstimation (reconstruct.cpp:174-295) on the track table."""
     tm = timings if timings is not None else Timings()
     V = iset.num_views
@@ -388,22 +388,53 @@ def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2
                             int(s.num_iterations), dt * 1e3, s.lm_loop_ms))
         return s, dt
 
-    def triangulate_all():
+    # A track's intersection depends on its alive features under the aligned cameras and on
+    # those cameras alone.  While the cameras already aligned stay as they are (every step but
+    # a global adjustment, which also overwrites the points), adding views changes only the
+    # tracks those views see: the full pass of the reference then recomputes everything else
+    # to the same bits, and is skipped here.
+    tri = {"full": True}
+
+    def _triangulate(tracks_subset):
+        cam_of = np.full(V, -1, dtype=np.int32)
+        cam_of[aligned] = np.arange(len(aligned), dtype=np.int32)
+        if tracks_subset is None:
+            fsel = np.nonzero((cam_of[tt.view] >= 0) & tt.alive_f & tt.alive_t[tt.track_of])[0]
+        else:
+            lo, hi = tt.offsets[tracks_subset], tt.offsets[tracks_subset + 1]
+            n = hi - lo
+            fsel = np.repeat(lo - np.concatenate([[0], np.cumsum(n)[:-1]]), n) + np.arange(int(n.sum()))
+            fsel = fsel[(cam_of[tt.view[fsel]] >= 0) & tt.alive_f[fsel]]
+        uniq, _, _, run = _runs(tt.track_of[fsel])              # fsel is in track order
+        prob = _problem(model, cams[aligned], const[aligned], W, H, np.tile([0.0, 0, 0, 1], (uniq.size, 1)),
+                        tt.xy[fsel], cam_of[tt.view[fsel]], run.astype(np.int32))
+        valid = (B.triangulate(prob, device) if uniq.size else np.zeros(0, np.uint8)).astype(bool)
+        return uniq, valid, prob.points
+
+    def triangulate_all(new_views=None):
         """algorithm->triangulateTracks(alignedCameras, tracks, true): every track with two
         or more rays under the aligned cameras gets its intersection, the others lose their
         point (triangulation.cpp:76-91)."""
         t0 = time.perf_counter()
-        cam_of = np.full(V, -1, dtype=np.int32)
-        cam_of[aligned] = np.arange(len(aligned), dtype=np.int32)
-        fsel = np.nonzero((cam_of[tt.view] >= 0) & tt.alive_f & tt.alive_t[tt.track_of])[0]
-        uniq, _, _, run = _runs(tt.track_of[fsel])              # fsel is in track order
-        prob = _problem(model, cams[aligned], const[aligned], W, H, np.tile([0.0, 0, 0, 1], (uniq.size, 1)),
-                        tt.xy[fsel], cam_of[tt.view[fsel]], run.astype(np.int32))
-        valid = B.triangulate(prob, device) if uniq.size else np.zeros(0, np.uint8)
-        tt.has_point[:] = False
-        ok = uniq[valid.astype(bool)]
+        subset = None
+        if not tri["full"] and new_views is not None:
+            idx = tt.features_of_views(new_views)
+            subset = np.unique(tt.track_of[idx]).astype(np.int64)
+        uniq, valid, pts = _triangulate(subset)
+        if subset is None:
+            tt.has_point[:] = False
+        else:
+            tt.has_point[subset] = False
+        ok = uniq[valid]
         tt.has_point[ok] = True
-        tt.point[ok] = prob.points[valid.astype(bool)]
+        tt.point[ok] = pts[valid]
+        if check_incremental and subset is not None:
+            hp, pt = tt.has_point.copy(), tt.point.copy()
+            uniq, valid, pts = _triangulate(None)
+            full_hp = np.zeros_like(hp)
+            full_hp[uniq[valid]] = True
+            assert np.array_equal(full_hp, hp) and np.array_equal(pts[valid], pt[uniq[valid]]), "incremental triangulation"
+        tri["full"] = False
         tm.triangulate_s += time.perf_counter() - t0
 
     def reprojection_filter(view_list, cam_p, cam_c, permanent):
@@ -475,13 +506,15 @@ def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2
             triangulate_all()
         else:
             align_to_global(model, lp, [cams[v] if is_aligned[v] else None for v in ids])
+            new_views = []
             for k, v in enumerate(ids):                             # mergeIntoGlobal: only the new cameras
                 if not is_aligned[v]:
                     cams[v] = lp[k]; const[v] = default_const_mask(model, euler_dof=euler_dof)
-                    aligned.append(v); is_aligned[v] = True
-            triangulate_all()
+                    aligned.append(v); is_aligned[v] = True; new_views.append(v)
+            triangulate_all(new_views)
             if processed % GLOBAL_BA_INTERVAL == 0:
                 _global_ba(tt, model, cams, const, aligned, W, H, V, solve, "global", opt, tm)
+                tri["full"] = True                      # old cameras moved, points overwritten
                 # filterOutlierTracks + filterTracksWithReprojectionError (:264-265)
                 t0 = time.perf_counter()
                 at = np.nonzero(tt.alive_t)[0]
@@ -525,7 +558,8 @@ def _global_ba(tt, model, cams, const, aligned, W, H, V, solve, kind, opt, tm):
 
 
 def reconstruct(iset, solver=0, matcher="exhaustive", device=0, verify=True, rot_perturb_deg=2.0,
-                off_perturb=0.01, seed=7, capture=(), max_groups=None, verbose=False) -> Result:
+                off_perturb=0.01, seed=7, capture=(), max_groups=None, verbose=False,
+                check_incremental=False) -> Result:
     """orthosfm::reconstruct from the views' descriptors on: one wall clock over matching,
     track building, group ordering and the incremental pose estimation.
     solver 0: quaternion cameras (ORTHO_QUATERNION); 1..3: Euler cameras with that many
@@ -536,7 +570,7 @@ def reconstruct(iset, solver=0, matcher="exhaustive", device=0, verify=True, rot
     model = B.MODEL_QUATERNION if solver == 0 else B.MODEL_EULER
     cams, aligned, groups, calls, captured = run_pose_estimation(
         tt, iset, model, device, rot_perturb_deg, off_perturb, seed, tm, capture, max_groups, verbose,
-        euler_dof=euler_dof_of_solver(solver))
+        euler_dof=euler_dof_of_solver(solver), check_incremental=check_incremental)
     tm.total_s = time.perf_counter() - t_all
     return Result(cams, aligned, tt, groups, tm, calls, captured=captured, **info)
 

@@ -268,3 +268,27 @@ def test_cpp_adapter_equals_python_mirror(ba, model, retri, tmp_path):
         if t.has_point:           # a track without a point has no value to compare (the double holds zeros)
             assert np.array_equal(np.asarray(t.point, dtype=np.float64), np.array(row[1:], dtype=np.float64))
     assert "Average point change" in out.stdout
+
+
+def test_work_arrays_are_cached_and_can_be_handed_back(ba):
+    """The per-call work arrays come from a per-device cache (osfm_common.h: DevicePool):
+    a second identical solve allocates nothing new, results do not depend on it, and
+    osfm_trim_device_memory returns what is cached to the driver."""
+    from orthosfm_amd import capi
+    sc = synth.make_ba_scene(synth.MODEL_QUATERNION, 12, 4000, config_id=1)
+    capi.trim_device_memory()
+    free0, _ = capi.device_memory(0)
+    a = ba.FlatProblem.from_scene(sc)
+    s1 = ba.solve(a, max_num_iterations=6)
+    free1, _ = capi.device_memory(0)
+    b = ba.FlatProblem.from_scene(sc)
+    s2 = ba.solve(b, max_num_iterations=6)
+    free2, _ = capi.device_memory(0)
+    assert free1 < free0                     # the first call's arrays stay cached ...
+    assert free2 == free1                    # ... and serve the second call
+    assert s1.final_cost == s2.final_cost and np.array_equal(a.cam_params, b.cam_params)
+    released = capi.trim_device_memory(0)
+    free3, _ = capi.device_memory(0)
+    # (the driver accounts whole pages, so its numbers and the pool's byte count differ slightly)
+    assert released > 0 and free3 > free1 and free3 >= free0 - (1 << 22)
+    assert capi.trim_device_memory() == 0    # nothing left

@@ -52,7 +52,8 @@ def _cpu_path_tracks(iset):
 @pytest.mark.parametrize("solver", [0, 3])
 def test_reconstruct_small_set(iset, solver):
     from orthosfm_amd import pipeline as P
-    res = P.reconstruct(iset, solver=solver, seed=11)
+    # check_incremental: every partial re-triangulation is repeated in full and compared bit for bit
+    res = P.reconstruct(iset, solver=solver, seed=11, check_incremental=True)
     V = iset.num_views
     # (1) identical track count (and tracks) with the CPU path
     cpu, n_pairs, n_corr = _cpu_path_tracks(iset)
