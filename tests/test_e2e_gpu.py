@@ -155,3 +155,50 @@ def test_config1_three_views_quaternion():
         Rg, Rc = P._cam_rotation(0, gt[v]), P._cam_rotation(0, res.cam_params[v])
         assert np.degrees(np.arccos(np.clip((np.trace(Rg.T @ Rc) - 1) / 2, -1, 1))) < 0.02
     assert int((res.tracks.alive_t & res.tracks.has_point).sum()) > 300
+
+
+def test_config3_200_views_at_stated_size():
+    """BASELINE configs[2] at its stated size on one GPU: 200 views x 20000 SIFT features, all
+    19900 pairs through osfm_match_all with RANSAC-F, then Tracks::compute.  Checked:
+    (1) a sample of pairs spread over the set, recomputed by the CPU oracle chain (low-res
+    gate, exhaustive two-way match + cross-check, RANSAC-F on the same sample streams): the
+    inlier lists are identical; (2) the tracks equal the output of the reference's own
+    bundler_tracks.cc (compiled into oracle/_ref, when it travelled; else the restatement)
+    on the same 127 M matches, element for element."""
+    from orthosfm_amd import capi, tracks as T
+    from orthosfm_amd.matching import HipExhaustiveMatching
+    V, F = 200, 20000
+    iset = synth.make_image_set(V, F, config_id=3)
+    W, H = iset.width, iset.height
+    o = capi.default_match_options()
+    o.geometric_verification = 1
+    m = HipExhaustiveMatching(V, options=o, copy_results=False)
+    norm = []
+    for v in range(V):
+        m.set_view(v, iset.sift[v])
+        norm.append(((iset.pos[v] + 0.5 - np.array([W / 2, H / 2])) / max(W, H)).astype(np.float32))
+        m.set_positions(v, norm[v])
+    pairs = [capi.pair_from_index(i) for i in range(V * (V - 1) // 2)]
+    out = m.compute(pairs, capacity=F * len(pairs))
+    assert len(out) == 19900 and all(tv.status == capi.PAIR_MATCHED for tv in out)
+    # (1) sampled pairs against the oracle chain
+    empty = np.zeros((0, 64), np.int16)
+    for i in np.linspace(0, len(pairs) - 1, 10).astype(int):
+        a, b = pairs[i]
+        assert oracle_lib.oracle_pairwise_match_lowres(iset.sift[a], empty, iset.sift[b], empty, 500) >= 5
+        e12, _ = oracle_lib.oracle_pairwise_match(iset.sift[a], empty, iset.sift[b], empty)
+        idx = np.nonzero(e12 >= 0)[0]
+        corr = np.stack([idx, e12[idx]], 1).astype(np.int32)
+        n, inl, _ = oracle_lib.oracle_ransac(norm[a], norm[b], corr, pair_id=int(i))
+        assert corr.shape[0] == out[i].num_matches and n == out[i].num_inliers, (i, a, b)
+        assert np.array_equal(np.asarray(out[i].matches), corr[inl]), (i, a, b)
+    # (2) tracks
+    sizes = np.full(V, F, dtype=np.int32)
+    parr, offs, corr = T.flatten_matching(out)
+    ids, toff, tfeat, tcol, summary = T.compute_flat(sizes, None, parr, offs, corr)
+    assert summary.num_tracks == 40000 and summary.num_invalid_tracks == 0
+    fn = oracle_lib.ref_tracks_compute if oracle_lib.ref_tracks() is not None else oracle_lib.oracle_tracks
+    ref = fn(sizes, None, np.array(pairs, np.int32), offs, corr)
+    assert np.array_equal(toff, ref["track_offsets"]) and np.array_equal(tfeat, ref["track_features"])
+    assert np.array_equal(ids, ref["track_ids"])
+    m.close()
