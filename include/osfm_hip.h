@@ -49,6 +49,16 @@ OSFM_API int osfm_device_memory(int device, uint64_t *free_bytes, uint64_t *tota
  * (may be NULL) reports how much that was. */
 OSFM_API int osfm_trim_device_memory(int device, uint64_t *released_bytes);
 
+/* Diagnostic of the RANSAC-F scoring loop.  Its Sampson tests are pre-classified in packed
+ * single precision; a test only counts when the float result is out of reach of its error
+ * bound, everything else is redone in the reference's double arithmetic, so the inlier
+ * counts are the double ones (orthosfm_amd/csrc/ransac_kernels.hip).  mode 0: double path
+ * only; 1: pre-classification (default); 2: pre-classification, every decision checked
+ * against the double path on the device.  counters (may be NULL) receives what the
+ * launches since the previous call counted in mode 2: [0] wrong decisions (must be 0),
+ * [1] undecided tests, [2] tests.  Process-wide; not for concurrent use with matching. */
+OSFM_API int osfm_ransac_selfcheck(int mode, uint64_t *counters);
+
 /* ====================================================================== */
 /* (A) Matching                                                            */
 /* ====================================================================== */

@@ -113,7 +113,7 @@ class BaSummary(C.Structure):
 
 # every symbol include/osfm_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = [
-    "osfm_last_error", "osfm_version", "osfm_device_count", "osfm_device_memory", "osfm_trim_device_memory",
+    "osfm_last_error", "osfm_version", "osfm_device_count", "osfm_device_memory", "osfm_trim_device_memory", "osfm_ransac_selfcheck",
     "osfm_match_options_default", "osfm_match_create", "osfm_match_destroy",
     "osfm_quantize_sift", "osfm_quantize_surf",
     "osfm_match_set_view", "osfm_match_set_view_float", "osfm_match_view_size", "osfm_match_set_positions",
@@ -153,6 +153,14 @@ def _ptr(a, ctype):
 
 def device_count() -> int:
     return lib.osfm_device_count()
+
+
+def ransac_selfcheck(mode: int):
+    """Sets the scoring mode of the RANSAC kernel (0 double, 1 pre-classified, 2 checked) and
+    returns (wrong, undecided, tests) counted in mode 2 since the previous call."""
+    c = (C.c_uint64 * 3)()
+    check(lib.osfm_ransac_selfcheck(C.c_int(mode), c))
+    return int(c[0]), int(c[1]), int(c[2])
 
 
 def trim_device_memory(device: int = -1) -> int:

@@ -545,6 +545,20 @@ int osfm_device_count(void)
     return n;
 }
 
+int osfm_ransac_selfcheck(int mode, uint64_t *counters)
+{
+    if (mode < 0 || mode > 2) { set_error("ransac_selfcheck: mode %d", mode); return OSFM_E_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("ransac_selfcheck: no HIP device available");
+        return OSFM_E_DEVICE;
+    }
+    unsigned long long c[3] = {0, 0, 0};
+    OSFM_RETURN_IF(ransac_set_mode(mode, c));
+    if (counters) for (int i = 0; i < 3; ++i) counters[i] = c[i];
+    return OSFM_OK;
+}
+
 int osfm_trim_device_memory(int device, uint64_t *released_bytes)
 {
     int ndev = 0;

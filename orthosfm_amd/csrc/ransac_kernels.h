@@ -25,5 +25,7 @@ constexpr int kRansacSplit = 2;     // workgroups per pair (each takes a share o
 size_t ransac_scratch_bytes(int num_jobs);
 void launch_ransac(const RansacJob *d_jobs, int num_jobs, int max_iterations, double threshold,
     uint64_t seed, void *scratch, hipStream_t s);
+// see osfm_ransac_selfcheck (include/osfm_hip.h)
+int ransac_set_mode(int mode, unsigned long long *counters_out);
 
 }  // namespace osfm

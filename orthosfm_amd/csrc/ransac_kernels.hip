@@ -11,6 +11,7 @@
 // of how pairs are batched or sharded.  All arithmetic is double precision in
 // the operation order of the CPU oracle, so both agree bit for bit.
 #include "ransac_kernels.h"
+#include "osfm_common.h"
 
 #include <algorithm>
 
@@ -160,6 +161,94 @@ eight_point(const double p1[8][2], const double p2[8][2], double F[9])
     return true;
 }
 
+// ---------------------------------------------------------------------------
+// Packed single-precision pre-classification of the scoring loop.
+//
+// 7.8e9 Sampson tests per 1225 pairs are 85 % of this kernel, and the reference's double
+// arithmetic (no FMA, 41 operations per test) runs at the same rate as float here -- but
+// v_pk_fma_f32 does two floats per lane and instruction, and a thread scores two
+// hypotheses, so one packed operation serves both.  The float result only DECIDES when
+// it is out of reach of every error it can carry; the rest (about one test in 10^4) takes
+// the double path above, so the counts are those of the double arithmetic, bit for bit.
+//
+// Bound, for |x1|, |y1|, |x2|, |y2| <= 1 (checked per chunk; a chunk with a larger
+// coordinate is scored in double), u = 2^-24, S = sum |F_ij|, exact quantities unmarked,
+// computed ones with ~ (F rounded to float: one u per entry; every FMA one rounding):
+//   a = x1 F0 + y1 F1 + F2 (b, c, t3, t4 alike):   |a~ - a| <= 4u (|F0| + |F1| + |F2|)
+//   n = x2 a + y2 b + c:                           |n~ - n| <= 4uS + 2u S (1 + 4u) <= 7uS
+//   s = a^2 + b^2 + t3^2 + t4^2:  |s~ - s| <= 2 sqrt(s) 4u 2S + 64 u^2 S^2 + 4u s
+//                                           <= 8u (s + S^2) + 4u s + ...  <= 14u s + 9u S^2
+//     (sqrt(s) <= (s / S + S) / 2)
+// so with N = |n~|, E = 10uS, and m = 1e-5 standing for the roundings of the test itself
+// and of the double reference (1e-15):
+//   (N + E)^2 < thr2 (1 - m) / (1 + 14u) (s~ - 12u S^2)   =>  n^2 < thr2 s      inlier for sure
+//   (max(N - E, 0))^2 > thr2 (1 + m) / (1 - 14u) (s~ + 12u S^2)  =>  n^2 > thr2 s   not one
+// NaN or infinity anywhere fails both comparisons and falls through to the double path.
+// ---------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct PrefilterConst { v2f F[9], E, K1, K2, K3, K4; };
+
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+// next float above |v| (constants of the bound must not be rounded down)
+__device__ __forceinline__ float float_up(double v)
+{
+    float f = (float)v;
+    if ((double)f < v) f = __uint_as_float(__float_as_uint(f) + 1u);
+    return f;
+}
+__device__ __forceinline__ float float_down(double v)
+{
+    float f = (float)v;
+    if ((double)f > v && f > 0.f) f = __uint_as_float(__float_as_uint(f) - 1u);
+    return f;
+}
+
+__device__ __forceinline__ void
+prefilter_setup(const double (&F)[2][9], double thr2, PrefilterConst &pc)
+{
+    const double u = 5.9604644775390625e-08;      // 2^-24
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        double S = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { S += fabs(F[h][i]); pc.F[i][h] = (float)F[h][i]; }
+        const double k1 = thr2 * (1.0 - 1e-5) / (1.0 + 14.0 * u), k3 = thr2 * (1.0 + 1e-5) / (1.0 - 14.0 * u);
+        pc.E[h] = float_up(10.0 * u * S);
+        pc.K1[h] = float_down(k1);
+        pc.K2[h] = float_up(k1 * 12.0 * u * S * S * 1.001);
+        pc.K3[h] = float_up(k3);
+        pc.K4[h] = float_up(k3 * 12.0 * u * S * S * 1.001);
+    }
+}
+
+// bit 0 / 1: hypothesis 0 / 1 certainly below the threshold; bit 2 / 3: certainly not
+__device__ __forceinline__ unsigned
+prefilter_test(const PrefilterConst &pc, float x1, float y1, float x2, float y2)
+{
+    const v2f X1 = {x1, x1}, Y1 = {y1, y1}, X2 = {x2, x2}, Y2 = {y2, y2};
+    const v2f a = pk_fma(X1, pc.F[0], pk_fma(Y1, pc.F[1], pc.F[2]));
+    const v2f b = pk_fma(X1, pc.F[3], pk_fma(Y1, pc.F[4], pc.F[5]));
+    const v2f c = pk_fma(X1, pc.F[6], pk_fma(Y1, pc.F[7], pc.F[8]));
+    const v2f n = pk_fma(X2, a, pk_fma(Y2, b, c));
+    const v2f t3 = pk_fma(X2, pc.F[0], pk_fma(Y2, pc.F[3], pc.F[6]));
+    const v2f t4 = pk_fma(X2, pc.F[1], pk_fma(Y2, pc.F[4], pc.F[7]));
+    const v2f sm = pk_fma(t4, t4, pk_fma(t3, t3, pk_fma(b, b, a * a)));
+    const v2f N = __builtin_elementwise_abs(n);
+    const v2f p = N + pc.E;
+    const v2f zero = {0.f, 0.f};
+    const v2f q = __builtin_elementwise_max(N - pc.E, zero);
+    const v2f lo = pk_fma(pc.K1, sm, -pc.K2), hi = pk_fma(pc.K3, sm, pc.K4);
+    const v2f p2 = p * p, q2 = q * q;
+    unsigned r = 0;
+    r |= p2[0] < lo[0] ? 1u : 0u;
+    r |= p2[1] < lo[1] ? 2u : 0u;
+    r |= q2[0] > hi[0] ? 4u : 0u;
+    r |= q2[1] > hi[1] ? 8u : 0u;
+    return r;
+}
+
 constexpr int kHyp = 2;            // hypotheses per thread and pass
 constexpr int kChunk = 1024;       // matches staged in LDS at a time
 // The hypotheses of a pair are split over kRansacSplit workgroups: one workgroup per pair
@@ -175,9 +264,11 @@ size_t ransac_scratch_bytes(int num_jobs)
 
 __global__ __launch_bounds__(256) void
 ransac_kernel(const RansacJob *__restrict__ jobs, int num_jobs, int max_iterations, double thr2, uint64_t seed,
-    RansacSlot *__restrict__ slots, int32_t *__restrict__ done)
+    RansacSlot *__restrict__ slots, int32_t *__restrict__ done, int prefilter, unsigned long long *check)
 {
     __shared__ double4 mpt[kChunk];           // (x1, y1, x2, y2) of the staged matches, widened once
+    __shared__ float4 mpf[kChunk];            // the same as the floats they are (pre-classification)
+    __shared__ int s_wide;                    // a staged coordinate lies outside [-1, 1]
     __shared__ int s_count[256], s_iter[256];
     __shared__ double s_F[9];
     __shared__ int s_wave[4], s_run, s_last;
@@ -230,23 +321,70 @@ ransac_kernel(const RansacJob *__restrict__ jobs, int num_jobs, int max_iteratio
             }
             valid[h] = eight_point(p1, p2, F[h]);
         }
+        static_assert(kHyp == 2, "the pre-classification packs the two hypotheses of a thread");
+        PrefilterConst pc;
+        prefilter_setup(F, thr2, pc);
         // inlier counts of this thread's hypotheses over all matches
         for (int c0 = 0; c0 < k; c0 += kChunk) {
             __syncthreads();
+            if (tid == 0) s_wide = 0;
+            __syncthreads();
+            bool wide = false;
             for (int i = tid; i < kChunk && c0 + i < k; i += 256) {
                 const int a = job.corr[2 * (c0 + i)], b = job.corr[2 * (c0 + i) + 1];
-                mpt[i] = make_double4(job.pos1[2 * a], job.pos1[2 * a + 1], job.pos2[2 * b], job.pos2[2 * b + 1]);
+                const float4 f = make_float4(job.pos1[2 * a], job.pos1[2 * a + 1], job.pos2[2 * b], job.pos2[2 * b + 1]);
+                mpf[i] = f;
+                mpt[i] = make_double4(f.x, f.y, f.z, f.w);
+                wide |= !(fabsf(f.x) <= 1.f && fabsf(f.y) <= 1.f && fabsf(f.z) <= 1.f && fabsf(f.w) <= 1.f);
             }
+            if (wide) s_wide = 1;
             __syncthreads();
             const int lim = min(kChunk, k - c0);
-            for (int i = 0; i < lim; ++i) {
-                const double4 m = mpt[i];
-                // invalid hypotheses (all-zero F) are evaluated too and discarded below:
-                // no divergence inside the loop
+            if (s_wide || !prefilter) {
+                for (int i = 0; i < lim; ++i) {
+                    const double4 m = mpt[i];
+                    // invalid hypotheses (all-zero F) are evaluated too and discarded below:
+                    // no divergence inside the loop
 #pragma unroll
-                for (int h = 0; h < kHyp; ++h)
-                    cnt[h] += sampson_below(F[h], m.x, m.y, m.z, m.w, thr2, thr_lo, thr_hi) ? 1 : 0;
+                    for (int h = 0; h < kHyp; ++h)
+                        cnt[h] += sampson_below(F[h], m.x, m.y, m.z, m.w, thr2, thr_lo, thr_hi) ? 1 : 0;
+                }
+                continue;
             }
+            // four matches per round: their (broadcast) LDS reads are issued together, the
+            // first use waits once -- one read per round trip left the loop latency-bound
+            const unsigned vmask = (valid[0] ? 1u : 0u) | (valid[1] ? 2u : 0u);
+            auto score = [&](int i, const float4 &f) {
+                const unsigned r = prefilter_test(pc, f.x, f.y, f.z, f.w);
+                cnt[0] += r & 1u;
+                cnt[1] += (r >> 1) & 1u;
+                // undecided (neither bit of a hypothesis set): the double path; counts of an
+                // invalid hypothesis are discarded below, it never goes there
+                const unsigned und = ~(r | (r >> 2)) & vmask;
+                if (und) {
+                    const double4 m = mpt[i];
+                    if (und & 1u) cnt[0] += sampson_below(F[0], m.x, m.y, m.z, m.w, thr2, thr_lo, thr_hi) ? 1 : 0;
+                    if (und & 2u) cnt[1] += sampson_below(F[1], m.x, m.y, m.z, m.w, thr2, thr_lo, thr_hi) ? 1 : 0;
+                }
+                if (check) {
+                    // self-check: every decision the floats took against the double path
+                    const double4 m = mpt[i];
+#pragma unroll
+                    for (int h = 0; h < kHyp; ++h) {
+                        const bool ref = sampson_below(F[h], m.x, m.y, m.z, m.w, thr2, thr_lo, thr_hi);
+                        const bool in = (r >> h) & 1u, out = (r >> (2 + h)) & 1u;
+                        if (valid[h] && ((in && !ref) || (out && ref) || (in && out))) atomicAdd(&check[0], 1ull);
+                        if (valid[h] && !in && !out) atomicAdd(&check[1], 1ull);
+                        if (valid[h]) atomicAdd(&check[2], 1ull);
+                    }
+                }
+            };
+            int i = 0;
+            for (; i + 4 <= lim; i += 4) {
+                const float4 f0 = mpf[i], f1 = mpf[i + 1], f2 = mpf[i + 2], f3 = mpf[i + 3];
+                score(i, f0); score(i + 1, f1); score(i + 2, f2); score(i + 3, f3);
+            }
+            for (; i < lim; ++i) score(i, mpf[i]);
         }
 #pragma unroll
         for (int h = 0; h < kHyp; ++h) {
@@ -326,6 +464,9 @@ ransac_kernel(const RansacJob *__restrict__ jobs, int num_jobs, int max_iteratio
     if (tid == 0) *job.count_out = s_run;
 }
 
+static int g_ransac_prefilter = 1;
+static unsigned long long *g_ransac_check = nullptr;
+
 void launch_ransac(const RansacJob *d_jobs, int num_jobs, int max_iterations, double threshold,
     uint64_t seed, void *scratch, hipStream_t s)
 {
@@ -334,7 +475,25 @@ void launch_ransac(const RansacJob *d_jobs, int num_jobs, int max_iterations, do
     int32_t *done = reinterpret_cast<int32_t *>(static_cast<char *>(scratch) + (size_t)num_jobs * kRansacSplit * sizeof(RansacSlot));
     (void)hipMemsetAsync(done, 0, (size_t)num_jobs * sizeof(int32_t), s);
     hipLaunchKernelGGL(ransac_kernel, dim3(num_jobs * kRansacSplit), dim3(256), 0, s, d_jobs, num_jobs, max_iterations,
-        threshold * threshold, seed, slots, done);
+        threshold * threshold, seed, slots, done, g_ransac_prefilter, g_ransac_check);
+}
+
+// diagnostics (osfm_ransac_selfcheck): mode 0 = double path only, 1 = pre-classification (default),
+// 2 = pre-classification with every decision compared against the double path; counters[3] =
+// wrong decisions, undecided tests, tests
+int ransac_set_mode(int mode, unsigned long long *counters_out)
+{
+    if (counters_out && g_ransac_check) {
+        OSFM_HIP_CHECK(hipDeviceSynchronize());
+        OSFM_HIP_CHECK(hipMemcpy(counters_out, g_ransac_check, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    if (mode == 2 && !g_ransac_check) {
+        OSFM_HIP_CHECK(hipMalloc(&g_ransac_check, 3 * sizeof(unsigned long long)));
+    }
+    if (g_ransac_check) OSFM_HIP_CHECK(hipMemset(g_ransac_check, 0, 3 * sizeof(unsigned long long)));
+    if (mode != 2 && g_ransac_check) { (void)hipFree(g_ransac_check); g_ransac_check = nullptr; }
+    g_ransac_prefilter = mode != 0;
+    return OSFM_OK;
 }
 
 }  // namespace osfm

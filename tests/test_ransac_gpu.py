@@ -94,3 +94,41 @@ def test_match_all_with_geometric_verification(hm):
     assert e.value.status == capi.E_STATE
     m.close()
     m2.close()
+
+
+def test_prefilter_decisions_are_the_double_ones(hm):
+    """The scoring loop pre-classifies its Sampson tests in packed single precision and only
+    lets a float result count when it is out of reach of its error bound.  Mode 2 compares
+    every such decision with the double path on the device: none may differ, on benign scenes
+    and on ones built to sit at the edges of the bound (coordinates at +-1, at 1e-4 scale, a
+    threshold at the noise level, and coordinates above 1, which must switch the chunk to the
+    double path).  Results equal those of the double-only mode, bit for bit."""
+    from orthosfm_amd import capi
+    scenes = []
+    for n, frac, seed in ((3000, 0.3, 21), (800, 0.0, 22), (6000, 0.7, 23)):
+        scenes.append((*two_view_scene(n, frac, seed)[:3], 0.0015, f"scene {seed}"))
+    p1, p2, corr, _ = two_view_scene(2000, 0.2, 24)
+    s = 1.0 / max(np.abs(p1).max(), np.abs(p2).max())
+    scenes.append(((p1 * s).astype(np.float32), (p2 * s).astype(np.float32), corr, 0.0015 * s, "stretched to +-1"))
+    scenes.append(((p1 * 1e-4).astype(np.float32), (p2 * 1e-4).astype(np.float32), corr, 0.0015e-4, "scale 1e-4"))
+    scenes.append((p1, p2, corr, 2e-5, "threshold at the noise level"))
+    scenes.append(((p1 * 3.0).astype(np.float32), (p2 * 3.0).astype(np.float32), corr, 0.0045, "coordinates above 1"))
+    try:
+        for pos1, pos2, c, thr, what in scenes:
+            capi.ransac_selfcheck(0)
+            ref = hm.ransac_fundamental(pos1, pos2, c, seed=5, pair_id=3, threshold=thr)
+            capi.ransac_selfcheck(2)
+            got = hm.ransac_fundamental(pos1, pos2, c, seed=5, pair_id=3, threshold=thr)
+            wrong, undecided, tests = capi.ransac_selfcheck(1)
+            assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), what
+            assert wrong == 0, (what, wrong, tests)
+            if what == "coordinates above 1":
+                assert tests == 0                      # every chunk went the double way
+            elif what == "scale 1e-4":
+                assert tests > 0                       # the bound (built for |x| <= 1) is loose here: mostly undecided
+            else:
+                assert tests > 1000 * 0.5 * len(c) and undecided < 0.02 * tests, (what, undecided, tests)
+            en, einl, eF = oracle_lib.oracle_ransac(pos1, pos2, c, seed=5, pair_id=3, threshold=thr)
+            assert got[0] == en and np.array_equal(got[1], einl) and np.array_equal(got[2], eF), what
+    finally:
+        capi.ransac_selfcheck(1)
