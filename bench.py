@@ -569,9 +569,10 @@ def main():
             m.use_result_buffer(store.slice)
         except D.SharedSegmentUnavailable:
             args.exchange = "rccl"
-    if world > 1 and store is None:
-        # page-locked result buffer: the lists go device -> host -> device (gather) at full PCIe rate
-        m.use_result_buffer(D.pinned_array("local", capacity, tdev))
+    if store is None:
+        # page-locked result buffer (what a host integration hands the matcher): the lists leave the
+        # device at full PCIe rate, at N > 1 on to the gather; pageable memory goes through staging
+        m.use_result_buffer(D.pinned_array("local", capacity, tdev) if world > 1 else capi.pinned_rows(capacity))
     gathered = [None]
 
     def step():

@@ -163,6 +163,25 @@ def ransac_selfcheck(mode: int):
     return int(c[0]), int(c[1]), int(c[2])
 
 
+_pinned_blocks = []
+
+
+def pinned_rows(rows: int):
+    """A (rows, 2) int32 array in page-locked host memory (hipHostMalloc of the HIP runtime the
+    library is linked against), e.g. as the result buffer of HipExhaustiveMatching.compute: the
+    match lists then leave the device at full PCIe rate instead of through pageable staging.
+    Lives as long as the process."""
+    hip = C.CDLL("libamdhip64.so")
+    p = C.c_void_p()
+    nbytes = max(int(rows), 1) * 8
+    rc = hip.hipHostMalloc(C.byref(p), C.c_size_t(nbytes), C.c_uint(0))
+    if rc != 0 or not p.value:
+        raise OsfmError(E_DEVICE, f"hipHostMalloc({nbytes}) failed with {rc}")
+    buf = (C.c_int32 * (max(int(rows), 1) * 2)).from_address(p.value)
+    _pinned_blocks.append(buf)
+    return np.frombuffer(buf, dtype=np.int32).reshape(-1, 2)[:rows]
+
+
 def trim_device_memory(device: int = -1) -> int:
     """Hands the cached work-array memory back to the driver; returns the bytes released."""
     b = C.c_uint64()

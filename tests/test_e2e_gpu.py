@@ -202,3 +202,28 @@ def test_config3_200_views_at_stated_size():
     assert np.array_equal(toff, ref["track_offsets"]) and np.array_equal(tfeat, ref["track_features"])
     assert np.array_equal(ids, ref["track_ids"])
     m.close()
+
+
+def test_config4_500_views_euler_all_dof_at_stated_size():
+    """BASELINE configs[4] at its stated size on one GPU: 500 views x 20000 features, Euler
+    cameras with every angle free (--solver=3), match + RANSAC-F -> tracks -> group order ->
+    the incremental schedule (498 local, 166 global adjustments, the final one).  Checked:
+    every pair matched, the 40000 landmarks come back as 40000 tracks, 498 groups, every
+    camera at the ground truth."""
+    from orthosfm_amd import pipeline as P
+    V = 500
+    iset = synth.make_image_set(V, 20000, config_id=5)
+    res = P.reconstruct(iset, solver=3)
+    assert res.num_pairs == V * (V - 1) // 2 == res.matched_pairs
+    assert res.num_mve_tracks == 40000 and res.invalid_mve_tracks == 0
+    assert len(res.groups) == V - 2 and sorted(res.aligned_views) == list(range(V))
+    kinds = [c.kind for c in res.ba_calls]
+    assert kinds.count("local") == V - 2 and kinds.count("global") == (V - 2) // 3 and kinds[-1] == "final"
+    gt, _ = P.canonical_ground_truth(iset, 1)
+    worst = 0.0
+    for v in range(V):
+        Rg, Rc = P._cam_rotation(1, gt[v]), P._cam_rotation(1, res.cam_params[v])
+        worst = max(worst, float(np.degrees(np.arccos(np.clip((np.trace(Rg.T @ Rc) - 1) / 2, -1, 1)))))
+    assert worst < 1e-3, worst
+    tt = res.tracks
+    assert int((tt.alive_t & tt.has_point).sum()) > 1000
