@@ -68,10 +68,13 @@ class TrackTable:
         self.has_point = np.zeros(T_, dtype=bool)
         self.alive_t = np.ones(T_, dtype=bool)
         self.alive_f = np.ones(self.view.shape[0], dtype=bool)
+        # kept up to date by kill() / align_view(), so that the per-call selections are one pass:
+        self.live_f = np.ones(self.view.shape[0], dtype=bool)        # alive_f & alive_t[track_of]
+        self.cam_f = np.full(self.view.shape[0], -1, dtype=np.int32)  # camera index of the feature's view, -1: not aligned
+        self._lengths = np.diff(self.offsets).astype(np.int64)        # alive features per alive track
         order = np.argsort(self.view, kind="stable").astype(np.int64)      # feature ids grouped by view, ascending inside
         self.by_view = order
         self.view_start = np.searchsorted(self.view[order], np.arange(self.num_views + 1))
-        self._lengths = None
 
     @classmethod
     def from_mve(cls, track_offsets, track_features, norm_positions, image_width, num_views):
@@ -92,24 +95,36 @@ class TrackTable:
     def features_of_views(self, views):
         """Alive features of alive tracks seen by the given views, in track order."""
         idx = np.concatenate([self.by_view[self.view_start[v]:self.view_start[v + 1]] for v in views])
-        idx = idx[self.alive_f[idx] & self.alive_t[self.track_of[idx]]]
+        idx = idx[self.live_f[idx]]
         idx.sort()
         return idx
 
     def alive_lengths(self):
-        """Features left per track (0 for dead tracks); cached until a filter clears flags."""
-        if self._lengths is None:
-            n = np.bincount(self.track_of[self.alive_f], minlength=self.alive_t.shape[0])
-            self._lengths = np.where(self.alive_t, n, 0)
+        """Features left per track (0 for dead tracks)."""
         return self._lengths
+
+    def align_view(self, v, cam_index):
+        """The view got a camera: its features select it from now on."""
+        self.cam_f[self.by_view[self.view_start[v]:self.view_start[v + 1]]] = cam_index
 
     def kill(self, tracks=None, features=None):
         """Clears alive flags (what a filter's smaller output list means here)."""
         if features is not None and len(features):
-            self.alive_f[features] = False
+            f = np.asarray(features)
+            f = f[self.alive_f[f]]
+            self.alive_f[f] = False
+            was_live = self.live_f[f]
+            self.live_f[f] = False
+            np.subtract.at(self._lengths, self.track_of[f[was_live]], 1)
         if tracks is not None and len(tracks):
-            self.alive_t[tracks] = False
-        self._lengths = None
+            t = np.asarray(tracks)
+            t = t[self.alive_t[t]]
+            self.alive_t[t] = False
+            self._lengths[t] = 0
+            lo, n = self.offsets[t], self.offsets[t + 1] - self.offsets[t]
+            if t.size:
+                fid = np.repeat(lo - np.concatenate([[0], np.cumsum(n)[:-1]]), n) + np.arange(int(n.sum()))
+                self.live_f[fid] = False
 
 
 def _runs(sorted_ids):
@@ -396,18 +411,18 @@ def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2
     tri = {"full": True}
 
     def _triangulate(tracks_subset):
-        cam_of = np.full(V, -1, dtype=np.int32)
-        cam_of[aligned] = np.arange(len(aligned), dtype=np.int32)
         if tracks_subset is None:
-            fsel = np.nonzero((cam_of[tt.view] >= 0) & tt.alive_f & tt.alive_t[tt.track_of])[0]
+            fsel = np.flatnonzero(tt.live_f & (tt.cam_f >= 0))
         else:
             lo, hi = tt.offsets[tracks_subset], tt.offsets[tracks_subset + 1]
             n = hi - lo
             fsel = np.repeat(lo - np.concatenate([[0], np.cumsum(n)[:-1]]), n) + np.arange(int(n.sum()))
-            fsel = fsel[(cam_of[tt.view[fsel]] >= 0) & tt.alive_f[fsel]]
+            fsel = fsel[(tt.cam_f[fsel] >= 0) & tt.alive_f[fsel]]
         uniq, _, _, run = _runs(tt.track_of[fsel])              # fsel is in track order
-        prob = _problem(model, cams[aligned], const[aligned], W, H, np.tile([0.0, 0, 0, 1], (uniq.size, 1)),
-                        tt.xy[fsel], cam_of[tt.view[fsel]], run.astype(np.int32))
+        start = np.zeros((uniq.size, 4))
+        start[:, 3] = 1.0
+        prob = _problem(model, cams[aligned], const[aligned], W, H, start,
+                        tt.xy[fsel], tt.cam_f[fsel], run.astype(np.int32))
         valid = (B.triangulate(prob, device) if uniq.size else np.zeros(0, np.uint8)).astype(bool)
         return uniq, valid, prob.points
 
@@ -502,7 +517,7 @@ def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2
             # normalizeScene is the identity here: camera 0 is canonical and fixed
             for k, v in enumerate(ids):
                 cams[v] = lp[k]; const[v] = lc[k]
-                aligned.append(v); is_aligned[v] = True
+                aligned.append(v); is_aligned[v] = True; tt.align_view(v, len(aligned) - 1)
             triangulate_all()
         else:
             align_to_global(model, lp, [cams[v] if is_aligned[v] else None for v in ids])
@@ -510,7 +525,7 @@ def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2
             for k, v in enumerate(ids):                             # mergeIntoGlobal: only the new cameras
                 if not is_aligned[v]:
                     cams[v] = lp[k]; const[v] = default_const_mask(model, euler_dof=euler_dof)
-                    aligned.append(v); is_aligned[v] = True; new_views.append(v)
+                    aligned.append(v); is_aligned[v] = True; new_views.append(v); tt.align_view(v, len(aligned) - 1)
             triangulate_all(new_views)
             if processed % GLOBAL_BA_INTERVAL == 0:
                 _global_ba(tt, model, cams, const, aligned, W, H, V, solve, "global", opt, tm)
@@ -541,12 +556,12 @@ def _global_ba(tt, model, cams, const, aligned, W, H, V, solve, kind, opt, tm):
     with a point is a parameter block, every feature of such a track whose view has a
     camera a residual (bundle_adjustment.cpp:86-123); cameras and points updated in place."""
     t0 = time.perf_counter()
-    cam_of = np.full(V, -1, dtype=np.int32)
-    cam_of[aligned] = np.arange(len(aligned), dtype=np.int32)
-    tsel = np.nonzero(tt.alive_t & tt.has_point)[0]
-    fsel = np.nonzero((cam_of[tt.view] >= 0) & tt.alive_f & (tt.alive_t & tt.has_point)[tt.track_of])[0]
-    prob = _problem(model, cams[aligned], const[aligned], W, H, tt.point[tsel], tt.xy[fsel], cam_of[tt.view[fsel]],
-                    np.searchsorted(tsel, tt.track_of[fsel]).astype(np.int32))
+    with_point = tt.alive_t & tt.has_point
+    tsel = np.flatnonzero(with_point)
+    fsel = np.flatnonzero(tt.live_f & (tt.cam_f >= 0) & with_point[tt.track_of])
+    slot = np.cumsum(with_point) - 1                                     # track -> row of tsel
+    prob = _problem(model, cams[aligned], const[aligned], W, H, tt.point[tsel], tt.xy[fsel], tt.cam_f[fsel],
+                    slot[tt.track_of[fsel]].astype(np.int32))
     tm.pose_host_s += time.perf_counter() - t0
     s, dt = solve(kind, prob, opt)
     tm.global_ba_s += dt

@@ -69,11 +69,17 @@ def test_track_table_indexing():
     tt = P.TrackTable(offs, view, feat, np.zeros((7, 2)), 4)
     assert tt.track_of.tolist() == [0, 0, 1, 1, 1, 2, 2]
     assert tt.features_of_views([2, 3]).tolist() == [1, 3, 4, 6]
-    tt.alive_f[3] = False
+    tt.kill(features=[3])
     assert tt.features_of_views([2, 3]).tolist() == [1, 4, 6]
-    tt.alive_t[2] = False
+    tt.kill(tracks=[2])
     assert tt.features_of_views([0, 3]).tolist() == [0, 4]
     assert tt.alive_lengths().tolist() == [2, 2, 0] and tt.num_tracks == 2
+    # the flags kill() keeps beside the two alive arrays
+    assert tt.live_f.tolist() == [True, True, True, False, True, False, False]
+    tt.kill(features=[3, 4], tracks=[2])                       # killing the dead again changes nothing
+    assert tt.alive_lengths().tolist() == [2, 1, 0]
+    tt.align_view(2, 0); tt.align_view(0, 1)
+    assert tt.cam_f.tolist() == [1, 0, -1, 0, -1, 1, -1]
     norm = [np.array([[0.1, -0.2]] * 7, np.float32)] * 4
     t2 = P.TrackTable.from_mve(offs, np.stack([view, feat], 1), norm, 100, 4)
     assert np.allclose(t2.xy[0], [np.float32(100 * (np.float64(np.float32(0.1)) + 0.5)),
