@@ -94,7 +94,10 @@ __device__ __forceinline__ int med3a(int a, int b, int c)
 // masking instruction.  MASKED = true (low-res / num_features-limited
 // matching, where the rows behind the limit are real descriptors): explicit
 // per-element masks.
-constexpr int kGroupTiles = 8;          // tiles per row-direction group (16 columns per slot)
+constexpr int kGroupTiles = 8;          // tiles per row-direction group (16 columns per slot), keyed kernels
+constexpr int kPipeGroupTiles = 16;     // ... of the correction-free kernel's staggered schedule: every close
+                                        // is 3 vector + 2 LDS operations in a loop where ~1 % of the time hangs
+                                        // on each vector operation per tile; 8-tile groups were 12 per tile
 constexpr int kValNone = -(1 << 28);    // "no candidate" for un-keyed column scores
 
 template <int V> struct IntC { static constexpr int value = V; };
@@ -249,13 +252,13 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
 
     // One phase: reduce the finished accumulators `cur` (row fragment PH) while
     // the MFMAs of the other fragment are issued into `nxt`, one per chunk.
-    // Extras a phase can carry (PIPE): CL >= 0 -- close the groups of slots CL, CL + 1
+    // Extras a phase can carry (PIPE): CL >= 0 -- close the group of slot CL
     // of the OTHER row fragment (its running bests are not touched in this phase)
     // with first tile `tile0`; MG -- merge the four waves' column partials of tile tm.
     // Their LDS operands are fetched in front of the first chunk and used from the
     // third on; everything is straight-line code (a branch would split the block).
-    // RS >= 0 -- slots RS, RS + 1 of THIS fragment were closed by the phase before:
-    // their running best restarts from this tile's scores (no reset needed there).
+    // RS >= 0 -- slot RS of THIS fragment was closed by the phase before:
+    // its running best restarts from this tile's scores (no reset needed there).
     auto phase = [&](auto ph_c, auto cl_c, auto mg_c, auto rs_c, v16i (&cur)[2], v16i (&nxt)[2], int buf_next,
                      int tile0, int tm) {
         constexpr int PH = decltype(ph_c)::value;
@@ -263,12 +266,9 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
         constexpr int RS = decltype(rs_c)::value;
         constexpr bool MG = decltype(mg_c)::value != 0;
         constexpr int OF = PH ^ 1;
-        int sv[2] = {0, 0};
+        int sv = 0;
         ColPart cpm[4];
-        if (CL >= 0) {
-            sv[0] = rsecbuf[(OF * 16 + CL) * 256 + tid];
-            sv[1] = rsecbuf[(OF * 16 + CL + 1) * 256 + tid];
-        }
+        if (CL >= 0) sv = rsecbuf[(OF * 16 + CL) * 256 + tid];
         if (MG) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) cpm[w] = colbuf[((tm & 7) * 4 + w) * 64 + lane];
@@ -295,7 +295,7 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
 #pragma unroll
             for (int r = i * RPC; r < (i + 1) * RPC; ++r) {
                 if (RAW) {
-                    if (RS >= 0 && (r == RS || r == RS + 1)) rcur[PH][r] = max(cur[0][r], cur[1][r]);
+                    if (RS >= 0 && r == RS) rcur[PH][r] = max(cur[0][r], cur[1][r]);
                     else rcur[PH][r] = max(max(rcur[PH][r], cur[0][r]), cur[1][r]);
                 } else {
                     int k0 = (int)(((unsigned)cur[0][r] << 8) + (unsigned)cjt[0]);
@@ -325,10 +325,10 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
                 asm volatile("" : "+v"(gg));
                 g[cf] = gg;
             }
-            if (CL >= 0 && (i == 2 || i == 3)) {
-                const int r = CL + (i - 2);
+            if (CL >= 0 && i == 2) {
+                const int r = CL;
                 const int gk = (int)(((unsigned)rcur[OF][r] << kRawShift) | (unsigned)tile0);
-                rsecbuf[(OF * 16 + r) * 256 + tid] = med3a(rbest[OF][r], sv[i - 2], gk);
+                rsecbuf[(OF * 16 + r) * 256 + tid] = med3a(rbest[OF][r], sv, gk);
                 rbest[OF][r] = max(rbest[OF][r], gk);
                 // no reset: the next phase that touches this slot restarts it (RS)
             }
@@ -443,44 +443,46 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
 
     int t = 0;
     if (PIPE) {
-        // Cycles of eight tiles, fully unrolled: every phase carries a fixed share of
+        // Cycles of sixteen tiles, fully unrolled: every phase carries a fixed share of
         // the work that would otherwise sit between phases, so nothing has to be
         // chosen at run time (a run-time choice between phase bodies costs a
         // register copy of the accumulators at the join).
-        //   phase (u, 0) closes slots 2u, 2u+1 of fragment 1 -- their groups are the
-        //     eight tiles t-8 .. t-1;  phase (u, 1) closes slots 2u, 2u+1 of fragment 0
-        //     -- tiles t-7 .. t.  Group boundaries are staggered by slot; the key
-        //     carries each group's first tile, which is all the finish kernel needs.
-        //   phase (1, 0) and (5, 0) merge the column partials of the four tiles before
-        //     t-1 (for the very first cycle the result of (1, 0) is a throw-away
-        //     that (5, 0) overwrites: same wave, same addresses, program order).
+        //   phase (u, 0) closes slot u of fragment 1 -- its group is the sixteen tiles
+        //     t-16 .. t-1;  phase (u, 1) closes slot u of fragment 0 -- tiles t-15 .. t.
+        //     Group boundaries are staggered by slot; the key carries each group's first
+        //     tile, which is all the finish kernel needs.
+        //   phases (1, 0), (5, 0), (9, 0), (13, 0) merge the column partials of the four
+        //     tiles before t-1 (for the very first cycle the result of (1, 0) is a
+        //     throw-away that (5, 0) overwrites: same wave, same addresses, program order).
         // In the first cycle the closes of not yet started groups fold "nothing"
         // into (best, second): a no-op.
-        static_assert(kGroupTiles == 8, "the staggered schedule assumes 8-tile groups");
+        static_assert(kPipeGroupTiles == 16, "the staggered schedule closes one of 16 slots per phase");
         auto cycle_tile = [&](auto u_c, int t0) {
             constexpr int u = decltype(u_c)::value;
             const int tt = t0 + u;
             tile_top(tt);
             const int bn = (tt & 1) ^ 1;
             const int tm = max(tt - 5, 0) + wave;
-            // restarts: fragment 0 slots closed by phase (u-1, 1), fragment 1 slots by phase (u, 0)
-            phase(IntC<0>(), IntC<2 * u>(), IntC<(u == 1 || u == 5) ? 1 : 0>(), IntC<2 * ((u + 7) & 7)>(), acc0, acc1, bn,
-                max(tt - 8, 0), tm);
-            phase(IntC<1>(), IntC<2 * u>(), IntC<0>(), IntC<2 * u>(), acc1, acc0, bn, max(tt - 7, 0), 0);
+            // restarts: the fragment 0 slot closed by phase (u-1, 1), the fragment 1 slot by phase (u, 0)
+            phase(IntC<0>(), IntC<u>(), IntC<(u & 3) == 1 ? 1 : 0>(), IntC<(u + 15) & 15>(), acc0, acc1, bn,
+                max(tt - 16, 0), tm);
+            phase(IntC<1>(), IntC<u>(), IntC<0>(), IntC<u>(), acc1, acc0, bn, max(tt - 15, 0), 0);
             tile_bottom(tt);
         };
-        for (; t + 8 <= ntiles; t += 8) {
+        for (; t + 16 <= ntiles; t += 16) {
             cycle_tile(IntC<0>(), t); cycle_tile(IntC<1>(), t); cycle_tile(IntC<2>(), t); cycle_tile(IntC<3>(), t);
             cycle_tile(IntC<4>(), t); cycle_tile(IntC<5>(), t); cycle_tile(IntC<6>(), t); cycle_tile(IntC<7>(), t);
+            cycle_tile(IntC<8>(), t); cycle_tile(IntC<9>(), t); cycle_tile(IntC<10>(), t); cycle_tile(IntC<11>(), t);
+            cycle_tile(IntC<12>(), t); cycle_tile(IntC<13>(), t); cycle_tile(IntC<14>(), t); cycle_tile(IntC<15>(), t);
         }
         if (t > 0) {
             merge_tile(t - 4 + wave);            // the batch of the last four tiles of the last cycle
-            rcur[0][14] = kCurNone; rcur[0][15] = kCurNone;   // closed by the last phase, never restarted
+            rcur[0][15] = kCurNone;              // closed by the last phase, never restarted
         }
         // the open groups of all slots (staggered starts), before the remaining tiles
         // start one common group
         const int tc = t;
-        close_all([&](int rf, int r) { return max(tc - (rf ? 8 : 7) + (r >> 1), 0); });
+        close_all([&](int rf, int r) { return max(tc - (rf ? 16 : 15) + r, 0); });
     }
     // tiles outside whole cycles (all tiles of the kernels without the staggered schedule)
     const int t_tail = t;
@@ -658,7 +660,7 @@ rescan_groups(const MatchProblem &pd, const int (&q)[2], const int (&idx1)[2], c
 {
     constexpr int LPC = DIM / 16;       // lanes per candidate (8: SIFT, 4: SURF)
     constexpr int CPL = 64 / LPC;       // candidates per wave-wide load
-    constexpr int NCAND = DIR == 0 ? 2 * kGroupTiles : 32;
+    constexpr int NCAND = DIR == 0 ? 2 * kPipeGroupTiles : 32;   // kind 0 (keyed kernels): the first 2 * kGroupTiles of them
     constexpr int J = NCAND / CPL;      // wave-wide loads per query
     const int c = lane % LPC, k = lane / LPC;
     const int8_t *Q = DIR == 0 ? pd.A : pd.B;
@@ -693,7 +695,7 @@ rescan_groups(const MatchProblem &pd, const int (&q)[2], const int (&idx1)[2], c
             int cd;
             if (DIR == 0) {
                 cd = base0 + (n >> 1) * kTileCols + (n & 1) * 32 + lr;
-                if (cd >= pd.n2) cd = -1;
+                if (cd >= pd.n2 || (!kind[u] && n >= 2 * kGroupTiles)) cd = -1;
             } else {
                 const int r = n & 15;
                 cd = rbase + (n >> 4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
