@@ -215,14 +215,25 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
         const int ch = (q % CH) ^ ((col / RPB) % CH);
         lane_off[c] = (unsigned)(col * D + ch * 16);
     }
+    auto dma_wait = [&]() { if (PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     auto stage_tile = [&](int t, int buf) {
         const int8_t *src = Bbase + (size_t)(col_begin + t * kTileCols) * D;      // uniform
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
             const int q0 = (c * 4 + wave_s) * 64;         // first chunk of this wave-instruction
-            __builtin_amdgcn_global_load_lds(
-                (glb_void *)(src + lane_off[c]),
-                (lds_void *)(uintptr_t)(bbuf + buf * TILE_BYTES + q0 * 16), 16, 0, 0);
+            if (PIPE) {
+                // scalar base + 32-bit lane offset: through the builtin the compiler adds the base
+                // to a 64-bit lane pointer with a vector instruction per DMA (two per tile in a loop
+                // where every vector operation per tile is ~1 % of the time).  The compiler does not
+                // see this memory operation: dma_wait() below stands where its s_waitcnt would.
+                const unsigned lds_at = (unsigned)(uintptr_t)(bbuf + buf * TILE_BYTES + q0 * 16);
+                asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"
+                             :: "v"(lane_off[c]), "s"(src), "s"(lds_at) : "memory");
+            } else {
+                __builtin_amdgcn_global_load_lds(
+                    (glb_void *)(src + lane_off[c]),
+                    (lds_void *)(uintptr_t)(bbuf + buf * TILE_BYTES + q0 * 16), 16, 0, 0);
+            }
         }
         if (!RAW && wave_s == 0)
             __builtin_amdgcn_global_load_lds(
@@ -354,6 +365,7 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
     // --- prologue: tiles 0 and 1 into LDS, fragments of tile 0, first half of tile 0
     stage_tile(0, 0);
     stage_tile(ntiles > 1 ? 1 : 0, 1);
+    dma_wait();
     __syncthreads();
     load_b(0, 0);
     load_b(0, 1);
@@ -400,6 +412,7 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
         cp.key_best = max(x0, x1);
         cp.key_second = min(x0, x1);
         colbuf[((t & 7) * 4 + wave) * 64 + lane] = cp;
+        dma_wait();
         __syncthreads();
     };
     // close the open row-direction group of every slot: fold the group bests into
