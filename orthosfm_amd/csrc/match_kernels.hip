@@ -347,9 +347,9 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
                 // chunk 2: fold the four partials; chunk 3: store (no branch: every tile
                 // merged inside the loop exists, its 64 columns lie below n2stride)
                 if (i == 2) {
-                    int k1 = kKeyNone, k2 = kKeyNone;
+                    int k1 = cpm[0].key_best, k2 = cpm[0].key_second;      // every key is >= kKeyNone
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
+                    for (int w = 1; w < 4; ++w) {
                         k2 = max(max(min(k1, cpm[w].key_best), k2), cpm[w].key_second);
                         k1 = max(k1, cpm[w].key_best);
                     }
@@ -436,12 +436,12 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
     };
     // this wave's share of a batch of four tiles: merge the four waves' partials of tile tm
     auto merge_tile = [&](int tm) {
-        int k1 = kKeyNone, k2 = kKeyNone;
         ColPart cp[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) cp[w] = colbuf[((tm & 7) * 4 + w) * 64 + lane];
+        int k1 = cp[0].key_best, k2 = cp[0].key_second;                          // every key is >= kKeyNone
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 1; w < 4; ++w) {
             k2 = max(max(min(k1, cp[w].key_best), k2), cp[w].key_second);
             k1 = max(k1, cp[w].key_best);
         }
