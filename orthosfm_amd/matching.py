@@ -120,20 +120,28 @@ class HipExhaustiveMatching:
         return MatchResult(m12[:n1].copy(), m21[:n2].copy())
 
     # --- bundler::Matching::compute (pre-RANSAC part), batched ----------------
-    def compute(self, pairs=None, capacity=None):
-        """Matches `pairs` (default: all V(V-1)/2 pairs in the reference's
-        triangular order, view_1 > view_2).  Returns one TwoViewMatching per
-        input pair, in input order."""
+    def compute_arrays(self, pairs=None, capacity=None):
+        """osfm_match_all as it is: returns (records, corr) -- one record per input pair (status,
+        lowres_matches, num_matches, num_inliers, offset: numpy fields of osfm_pair_result) and the
+        (rows, 2) buffer all lists lie in, pair k at corr[offset : offset + count].  `pairs` may be
+        an (n, 2) int32 array; the marshalled form of the last pair list is kept, so a caller that
+        passes the same object again pays nothing for it."""
         if pairs is None:
             pairs = [capi.pair_from_index(i) for i in range(self.num_views * (self.num_views - 1) // 2)]
-        n = len(pairs)
-        arr = (capi.Pair * max(n, 1))()
-        flat = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
-        if n:
-            np.ctypeslib.as_array(C.cast(arr, C.POINTER(C.c_int32)), shape=(n, 2))[:] = flat
-        res = (capi.PairResult * max(n, 1))()
+        cached = getattr(self, "_pairs_cache", None)
+        if cached is not None and cached[0] is pairs:
+            _, arr, flat, res = cached
+        else:
+            n = len(pairs)
+            arr = (capi.Pair * max(n, 1))()
+            flat = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
+            if n:
+                np.ctypeslib.as_array(C.cast(arr, C.POINTER(C.c_int32)), shape=(n, 2))[:] = flat
+            res = (capi.PairResult * max(n, 1))()
+            self._pairs_cache = (pairs, arr, flat, res)
+        n = flat.shape[0]
         if capacity is None:
-            capacity = sum(min(sum(self.view_size(a)), sum(self.view_size(b))) for a, b in pairs)
+            capacity = sum(min(sum(self.view_size(a)), sum(self.view_size(b))) for a, b in flat.tolist())
         # One result buffer per call, taken from a pool the matcher keeps (its pages
         # stay mapped, so the device-to-host copy does not fault them in again);
         # the per-pair lists are views into it.
@@ -144,10 +152,24 @@ class HipExhaustiveMatching:
         corr = corr[:max(int(total.value), 0)].copy() if self._copy_results else corr
         # all lists of the call, concatenated in pair order (what the per-pair views point into)
         self.last_flat = corr[:max(int(total.value), 0)]
+        ra = np.frombuffer(res, dtype=_PAIR_RESULT_DTYPE, count=n)
+        self._last_pairs_flat = flat
+        return ra, corr
+
+    def compute(self, pairs=None, capacity=None):
+        """Matches `pairs` (default: all V(V-1)/2 pairs in the reference's
+        triangular order, view_1 > view_2).  Returns one TwoViewMatching per
+        input pair, in input order."""
+        ra, corr = self.compute_arrays(pairs, capacity)
+        return self.as_objects(ra, corr)
+
+    def as_objects(self, ra, corr):
+        """The TwoViewMatching list of what compute_arrays returned."""
+        flat = self._last_pairs_flat
+        n = flat.shape[0]
         empty = np.zeros((0, 2), np.int32)
         verify = bool(self.opts.geometric_verification)
         # the result records as columns (one pass each) instead of 7 ctypes field reads per pair
-        ra = np.frombuffer(res, dtype=_PAIR_RESULT_DTYPE, count=n)
         status, lowres = ra["status"].tolist(), ra["lowres_matches"].tolist()
         nm, ni, off = ra["num_matches"].tolist(), ra["num_inliers"].tolist(), ra["offset"].tolist()
         v1, v2 = flat[:, 0].tolist(), flat[:, 1].tolist()
