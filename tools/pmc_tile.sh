@@ -13,6 +13,6 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-include-regex "match_tile" --output-format csv -d $R/gpurun_out/pmct_${tag}_$i -- python $R/bench.py --no-ba --no-verify --no-cpu-baseline --no-e2e --steps 1 --warmup 0 > $R/gpurun_out/pmct_${tag}_$i.log 2>&1 || echo "set $i failed"
   f=$(find $R/gpurun_out/pmct_${tag}_$i -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && python $R/tools/pmc_summary.py $f "${KERNEL:-match_tile_pp_kernel<8>}"
+  [ -n "$f" ] && python $R/tools/pmc_summary.py $f "${KERNEL:-match_tile_kernel<8, false, true, true>}"
   rm -rf $R/gpurun_out/pmct_${tag}_$i
 done
