@@ -12,7 +12,9 @@ enum { kPassNormal = 0, kPassScaleInit = 1 };
 //   Jc[2][6] (Huber-corrected, Jacobi-scaled camera block, unused columns 0),
 //   Jp[2][3], Q[2][3] = Jp (V_j + D^2)^-1, r[2]
 constexpr int kObsRec = 26;
-constexpr int kRecJc = 0, kRecJp = 12, kRecQ = 18, kRecR = 24;
+// Jp, Jc, Q, r: [0, 18) is what the b side of a Schur pair and the back pass read, [6, 24) what
+// the a side of an off-diagonal pair reads (18 of the 26 doubles each)
+constexpr int kRecJp = 0, kRecJc = 6, kRecQ = 18, kRecR = 24;
 
 // lanes per track in the per-point kernels (point / back / cost pass): their grids are
 // ceil(M * kPointLanes / 256) workgroups of 256 threads, and so are their partials

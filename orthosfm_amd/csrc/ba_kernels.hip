@@ -347,19 +347,20 @@ ba_pair_pass_kernel(BaDev d, PairPassArgs a)
     for (int e = e0 + lane; e < e1; e += 64) {
         const uint64_t ent = a.entries[e];
         const int ka = (int)(ent >> 32), kb = (int)(ent & 0xffffffffu);
-        // whole records as 16-byte loads (26 doubles = 13 x double2): each lane reads
-        // its own records, so the request count, not the byte count, is what costs
+        // 16-byte loads; of record a only Jc and Q (18 doubles at [kRecJc, kRecR)) -- the residual
+        // is read by the diagonal entries alone, Jp comes with record b
         double ra[kObsRec];
         {
             const double2 *src = reinterpret_cast<const double2 *>(a.obsrec + (size_t)ka * kObsRec);
 #pragma unroll
-            for (int i = 0; i < kObsRec / 2; ++i) { const double2 v = src[i]; ra[2 * i] = v.x; ra[2 * i + 1] = v.y; }
+            for (int i = kRecJc / 2; i < kRecR / 2; ++i) { const double2 v = src[i]; ra[2 * i] = v.x; ra[2 * i + 1] = v.y; }
         }
         double Ja[2][6];
 #pragma unroll
         for (int x = 0; x < 6; ++x) { Ja[0][x] = ra[kRecJc + x]; Ja[1][x] = ra[kRecJc + 6 + x]; }
         if (ka == kb) {
-            double rr0 = ra[kRecR], rr1 = ra[kRecR + 1];
+            const double2 rv = reinterpret_cast<const double2 *>(a.obsrec + (size_t)ka * kObsRec)[kRecR / 2];
+            double rr0 = rv.x, rr1 = rv.y;
 #pragma unroll
             for (int x = 0; x < 6; ++x) g[x] += Ja[0][x] * rr0 + Ja[1][x] * rr1;
             if (d.pdim && a.mode != kPassScaleInit) {
