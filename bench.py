@@ -373,9 +373,48 @@ def per_pair_latency(m, pairs, n=24):
     for a, b in sel:
         m.pairwise_match_lowres(a, b, 500)
     dl = (time.perf_counter() - t0) / len(sel)
-    return {"interface": "MatchingBase::pairwise_match / pairwise_match_lowres, one call per pair (through ctypes)",
-            "pairwise_match_ms": dt * 1e3, "pairwise_match_lowres_ms": dl * 1e3, "pairs_per_s": 1.0 / (dt + dl),
-            "sample": f"{len(sel)} pairs of 20k x 20k features"}
+    # the reference's loop is an OpenMP parallel for over the pairs (bundler_matching.cc:86-88): the
+    # same two calls per pair from `threads` host threads; the library combines whatever calls are
+    # waiting into one batch per kind
+    import threading
+    threads = 16
+    many = [pairs[i] for i in np.linspace(0, len(pairs) - 1, min(len(pairs), 30 * threads)).astype(int)]
+
+    def worker(k):
+        for a, b in many[k::threads]:
+            if m.pairwise_match_lowres(a, b, 500) >= 5:
+                m.pairwise_match(a, b)
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(threads)]
+    t0 = time.perf_counter()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dc = time.perf_counter() - t0
+    out = {"interface": "MatchingBase::pairwise_match / pairwise_match_lowres, one call per pair (through ctypes)",
+           "pairwise_match_ms": dt * 1e3, "pairwise_match_lowres_ms": dl * 1e3, "pairs_per_s": 1.0 / (dt + dl),
+           "sample": f"{len(sel)} pairs of 20k x 20k features",
+           "concurrent": {"threads": threads, "pairs": len(many), "pairs_per_s": len(many) / dc,
+                          "what": "gate + match per pair from 16 Python threads (the interpreter lock serialises "
+                                  "the wrapper around the calls)"}}
+    # the same loop in the reference's language: tests/host/drop_in_bench.cc, an OpenMP parallel for over
+    # the C ABI (a child process with its own matcher: 50 views x 20k features, 1225 pairs)
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "host", "drop_in_bench")
+    if os.path.exists(exe):
+        import subprocess
+        try:
+            r = subprocess.run([exe, "50", "20000", "32"], capture_output=True, text=True, timeout=120)
+            lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode == 0 and len(lines) == 2:
+                out["openmp"] = {"serial_pairs_per_s": lines[0]["pairs_per_s"], "threads": lines[1]["threads"],
+                                 "pairs_per_s": lines[1]["pairs_per_s"], "pairs": lines[1]["pairs"],
+                                 "identical_to_serial": True}
+            else:
+                out["openmp"] = {"error": (r.stderr or r.stdout)[-300:]}
+        except Exception as e:
+            out["openmp"] = {"error": str(e)}
+    return out
 
 
 def schedule_kinds(num_views):

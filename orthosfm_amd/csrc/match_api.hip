@@ -5,6 +5,8 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <vector>
 
@@ -113,6 +115,30 @@ struct osfm_matcher {
     bool cas_dirty = true;
 
     osfm_match_stats stats;
+
+    // Concurrent callers of the per-pair entries (the reference drives MatchingBase from an
+    // OpenMP loop, bundler_matching.cc:86-88) are combined: whoever finds no leader at work
+    // takes every request that is waiting, runs them as ONE batch and hands the results out.
+    // A pair alone costs 0.26 ms of launch and synchronisation latency for 60 us of GPU work.
+    struct Staging { int32_t *ptr = nullptr; size_t ints = 0; int users = 0; };
+    struct PairRequest {
+        int kind;                       // 0: pairwise_match, 1: pairwise_match_lowres
+        int v1, v2, num_features;
+        int32_t *m12, *m21, *len12, *len21, *count;
+        int status = OSFM_OK;
+        bool done = false;
+        std::string error;
+        // where the leader left this request's lists: in a page-locked staging block that the
+        // requester copies from itself (the copies of a batch run in parallel, one per thread)
+        Staging *stage = nullptr;
+        int64_t src12 = 0, src21 = 0;
+        int32_t n12 = 0, n21 = 0;
+    };
+    std::vector<Staging *> comb_staging;      // guarded by comb_mu; blocks live as long as the matcher
+    std::mutex comb_mu;
+    std::condition_variable comb_cv;
+    std::deque<PairRequest *> comb_queue;
+    bool comb_leader = false;
 };
 
 namespace {
@@ -662,6 +688,7 @@ int osfm_match_destroy(osfm_matcher *m)
         for (int j = 0; j < 2; ++j)
             if (m->ev[i][j]) (void)hipEventDestroy(m->ev[i][j]);
     if (m->stream) (void)hipStreamDestroy(m->stream);
+    for (auto *sg : m->comb_staging) { if (sg->ptr) (void)hipHostFree(sg->ptr); delete sg; }
     delete m;       // every DeviceBuffer (views, scratch, cascade-hashing data) frees itself
     return OSFM_OK;
 }
@@ -795,39 +822,133 @@ int osfm_ransac_fundamental(int device, const float *pos1, int n1, const float *
     return OSFM_OK;
 }
 
+namespace {
+
+constexpr size_t kCombineMax = 64;       // requests per combined batch
+
+// One combined batch: requests of one kind (and, for the low-res kind, one feature limit).
+void serve_requests(osfm_matcher *m, const std::vector<osfm_matcher::PairRequest *> &batch)
+{
+    auto fail_all = [&](int status) {
+        const std::string msg = osfm_last_error();
+        for (auto *r : batch) { r->status = status; r->error = msg; }
+    };
+    std::lock_guard<std::mutex> lock(m->mu);
+    if (hipSetDevice(m->device) != hipSuccess) { set_error("match_pair: hipSetDevice failed"); fail_all(OSFM_E_DEVICE); return; }
+    reset_stats(m);
+    std::vector<osfm_pair> pairs(batch.size());
+    for (size_t k = 0; k < batch.size(); ++k) pairs[k] = {batch[k]->v1, batch[k]->v2};
+    BatchResult res;
+    BatchMode mode;
+    if (batch[0]->kind == 1) { mode.limit = batch[0]->num_features; mode.lowres = true; mode.apply = false; }
+    int st = run_batch(m, pairs.data(), (int)pairs.size(), mode, &res);
+    if (st != OSFM_OK) { fail_all(st); return; }
+    if (batch[0]->kind == 1) {
+        for (size_t k = 0; k < batch.size(); ++k) *batch[k]->count = res.counts[k];
+        return;
+    }
+    // all lists of the batch lie back to back in m->out: ONE copy into a page-locked block (two
+    // pageable copies per pair were most of a batch's time); every requester then takes its own
+    osfm_matcher::Staging *stage = nullptr;
+    {
+        std::lock_guard<std::mutex> q(m->comb_mu);
+        for (auto *sg : m->comb_staging)
+            if (sg->users == 0 && (!stage || sg->ints > stage->ints)) stage = sg;
+        if (!stage) { stage = new osfm_matcher::Staging; m->comb_staging.push_back(stage); }
+        stage->users = (int)batch.size();
+    }
+    const size_t need = (size_t)std::max<int64_t>(res.out_ints, 4);
+    hipError_t e = hipSuccess;
+    if (stage->ints < need) {
+        if (stage->ptr) (void)hipHostFree(stage->ptr);
+        stage->ptr = nullptr; stage->ints = 0;
+        e = hipHostMalloc(reinterpret_cast<void **>(&stage->ptr), (need + need / 4) * 4, hipHostMallocDefault);
+        if (e == hipSuccess) stage->ints = need + need / 4;
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(stage->ptr, m->out.ptr, need * 4, hipMemcpyDeviceToHost, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    if (e != hipSuccess) {
+        set_error("match_pair: copy of the lists failed: %s", hipGetErrorString(e));
+        fail_all(OSFM_E_DEVICE);
+        std::lock_guard<std::mutex> q(m->comb_mu);
+        stage->users = 0;
+        return;
+    }
+    for (size_t k = 0; k < batch.size(); ++k) {
+        const PairPlan &pl = res.plans[k];
+        batch[k]->stage = stage;
+        batch[k]->src12 = pl.off12; batch[k]->n12 = pl.len12;
+        batch[k]->src21 = pl.off21; batch[k]->n21 = pl.len21;
+    }
+}
+
+int combine(osfm_matcher *m, osfm_matcher::PairRequest &rq)
+{
+    std::unique_lock<std::mutex> lk(m->comb_mu);
+    m->comb_queue.push_back(&rq);
+    while (!rq.done) {
+        if (m->comb_leader) { m->comb_cv.wait(lk); continue; }
+        m->comb_leader = true;
+        while (!rq.done && !m->comb_queue.empty()) {
+            // everything of the kind at the head of the queue, in arrival order
+            std::vector<osfm_matcher::PairRequest *> batch;
+            const osfm_matcher::PairRequest *head = m->comb_queue.front();
+            for (auto it = m->comb_queue.begin(); it != m->comb_queue.end() && batch.size() < kCombineMax;) {
+                if ((*it)->kind == head->kind && (*it)->num_features == head->num_features) {
+                    batch.push_back(*it);
+                    it = m->comb_queue.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+            lk.unlock();
+            serve_requests(m, batch);
+            lk.lock();
+            for (auto *r : batch) r->done = true;
+            m->comb_cv.notify_all();
+        }
+        m->comb_leader = false;
+        m->comb_cv.notify_all();             // a waiter whose request is still queued takes over
+    }
+    lk.unlock();
+    if (rq.stage) {
+        if (rq.n12) memcpy(rq.m12, rq.stage->ptr + rq.src12, (size_t)rq.n12 * 4);
+        if (rq.n21) memcpy(rq.m21, rq.stage->ptr + rq.src21, (size_t)rq.n21 * 4);
+        if (rq.len12) *rq.len12 = rq.n12;
+        if (rq.len21) *rq.len21 = rq.n21;
+        lk.lock();
+        rq.stage->users--;
+        lk.unlock();
+    }
+    if (rq.status != OSFM_OK) set_error("%s", rq.error.c_str());
+    return rq.status;
+}
+
+}  // namespace
+
 int osfm_match_pair(osfm_matcher *m, int view_1, int view_2, int32_t *m12, int32_t *len12,
     int32_t *m21, int32_t *len21)
 {
     if (!m || !m12 || !m21) { set_error("match_pair: null argument"); return OSFM_E_ARG; }
-    std::lock_guard<std::mutex> lock(m->mu);
-    OSFM_HIP_CHECK(hipSetDevice(m->device));
-    reset_stats(m);
-    osfm_pair pr = {view_1, view_2};
-    BatchResult res;
-    OSFM_RETURN_IF(run_batch(m, &pr, 1, BatchMode(), &res));
-    const PairPlan &pl = res.plans[0];
-    const int32_t *d_out = m->out.as<int32_t>();
-    if (pl.len12) OSFM_HIP_CHECK(hipMemcpy(m12, d_out + pl.off12, (size_t)pl.len12 * 4, hipMemcpyDeviceToHost));
-    if (pl.len21) OSFM_HIP_CHECK(hipMemcpy(m21, d_out + pl.off21, (size_t)pl.len21 * 4, hipMemcpyDeviceToHost));
-    if (len12) *len12 = pl.len12;
-    if (len21) *len21 = pl.len21;
-    return OSFM_OK;
+    // a bad view id fails its own call, not the batch it would have joined
+    OSFM_RETURN_IF(check_view(m, view_1, "match"));
+    OSFM_RETURN_IF(check_view(m, view_2, "match"));
+    osfm_matcher::PairRequest rq;
+    rq.kind = 0; rq.v1 = view_1; rq.v2 = view_2; rq.num_features = 0;
+    rq.m12 = m12; rq.m21 = m21; rq.len12 = len12; rq.len21 = len21; rq.count = nullptr;
+    return combine(m, rq);
 }
 
 int osfm_match_pair_lowres(osfm_matcher *m, int view_1, int view_2, int num_features, int32_t *count)
 {
     if (!m || !count) { set_error("match_pair_lowres: null argument"); return OSFM_E_ARG; }
     if (num_features <= 0) { *count = 0; return OSFM_OK; }
-    std::lock_guard<std::mutex> lock(m->mu);
-    OSFM_HIP_CHECK(hipSetDevice(m->device));
-    reset_stats(m);
-    osfm_pair pr = {view_1, view_2};
-    BatchResult res;
-    BatchMode mode;
-    mode.limit = num_features; mode.lowres = true; mode.apply = false;
-    OSFM_RETURN_IF(run_batch(m, &pr, 1, mode, &res));
-    *count = res.counts[0];
-    return OSFM_OK;
+    OSFM_RETURN_IF(check_view(m, view_1, "match"));
+    OSFM_RETURN_IF(check_view(m, view_2, "match"));
+    osfm_matcher::PairRequest rq;
+    rq.kind = 1; rq.v1 = view_1; rq.v2 = view_2; rq.num_features = num_features;
+    rq.m12 = rq.m21 = rq.len12 = rq.len21 = nullptr; rq.count = count;
+    return combine(m, rq);
 }
 
 int osfm_match_twoway(osfm_matcher *m, int view_1, int view_2, int descriptor_type, int num_features,

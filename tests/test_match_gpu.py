@@ -498,3 +498,52 @@ def test_matcher_handles_give_their_memory_back():
         cycle(HipExhaustiveMatching)
     free1, _ = capi.device_memory(0)
     assert free0 - free1 < (8 << 20), (free0, free1)
+
+
+def test_concurrent_pair_calls_are_combined(hm):
+    """The per-pair entries called from many threads at once (the reference's OpenMP loop,
+    bundler_matching.cc:86-88): whoever finds no leader at work runs everything that is
+    waiting as one batch.  Results equal the serial calls; a call with a bad view id fails
+    alone, the calls that would have shared its batch do not."""
+    import threading
+    from orthosfm_amd import capi
+    V = 7
+    iset = synth.make_image_set(V, 2500, config_id=23)
+    m = hm(V)
+    for v in range(V):
+        m.set_view(v, iset.sift[v])
+    pairs = [capi.pair_from_index(i) for i in range(V * (V - 1) // 2)]
+    serial = {}
+    for a, b in pairs:
+        r = m.pairwise_match(a, b)
+        serial[(a, b)] = (m.pairwise_match_lowres(a, b, 500), r.matches_1_2.copy(), r.matches_2_1.copy())
+    got, errors = {}, []
+
+    def worker(k):
+        try:
+            for rep in range(3):
+                for a, b in pairs[k::12]:
+                    low = m.pairwise_match_lowres(a, b, 500)
+                    r = m.pairwise_match(a, b)
+                    got[(a, b, rep)] = (low, r.matches_1_2.copy(), r.matches_2_1.copy())
+                if k == 0:
+                    try:
+                        m.pairwise_match(0, V + 3)
+                        errors.append("bad view id accepted")
+                    except capi.OsfmError as e:
+                        if e.status != capi.E_ARG:
+                            errors.append(f"bad view id: status {e.status}")
+        except Exception as e:       # noqa: BLE001 -- reported below, a thread must not die silently
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(12)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert len(got) == 3 * len(pairs)
+    for (a, b, _), (low, m12, m21) in got.items():
+        s_low, s12, s21 = serial[(a, b)]
+        assert low == s_low and np.array_equal(m12, s12) and np.array_equal(m21, s21), (a, b)
+    m.close()
