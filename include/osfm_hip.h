@@ -103,7 +103,14 @@ typedef struct osfm_match_options {
      * offset, matching.cc:74-86).  1: the exhaustive matcher's layout (the block of a
      * type view_1 has is always present, -1 filled): consistent combined indices. */
     int32_t cascade_keep_empty_blocks;
-    int32_t reserved;
+    /* SIFT descriptors with a byte > 127 ("special": MVE renormalises after the 0.2 clamp,
+     * sift.cc:830-839, so a descriptor with its energy in a few bins holds bytes of 128-180)
+     * do not fit the raw int8 operand of the correction-free score-tile kernel.  A view with
+     * at most this many of them keeps all its other descriptors on that kernel and the
+     * special ones are scored by a kernel of their own; a view with more takes the slower
+     * per-view operand forms.  0: default (512); negative: always the per-view forms.
+     * Results are identical either way. */
+    int32_t special_kernel_max;
 } osfm_match_options;
 
 OSFM_API int osfm_match_options_default(osfm_match_options *opts);
@@ -230,7 +237,8 @@ typedef struct osfm_match_stats {
     int64_t lowres_mac_count;
     double cashash_kernel_ms;    /* cascade hashing mode: candidate search + NN kernel */
     int32_t cashash_kernel_launches;
-    int32_t reserved1;
+    int32_t special_kernel_launches;
+    double special_kernel_ms;    /* special descriptors (a byte > 127) against the other view */
 } osfm_match_stats;
 OSFM_API int osfm_match_get_stats(const osfm_matcher *m, osfm_match_stats *out);
 

@@ -43,7 +43,7 @@ class MatchOptions(C.Structure):
                 ("geometric_verification", C.c_int32), ("ransac_max_iterations", C.c_int32),
                 ("ransac_threshold", C.c_double), ("min_matching_inliers", C.c_int32),
                 ("matcher_type", C.c_int32), ("ransac_seed", C.c_uint64),
-                ("cascade_keep_empty_blocks", C.c_int32), ("reserved", C.c_int32)]
+                ("cascade_keep_empty_blocks", C.c_int32), ("special_kernel_max", C.c_int32)]
 
 
 class RansacOptions(C.Structure):
@@ -66,7 +66,8 @@ class MatchStats(C.Structure):
                 ("algorithmic_bytes", C.c_int64), ("lowres_kernel_ms", C.c_double),
                 ("lowres_kernel_launches", C.c_int32), ("reserved", C.c_int32),
                 ("lowres_mac_count", C.c_int64), ("cashash_kernel_ms", C.c_double),
-                ("cashash_kernel_launches", C.c_int32), ("reserved1", C.c_int32)]
+                ("cashash_kernel_launches", C.c_int32), ("special_kernel_launches", C.c_int32),
+                ("special_kernel_ms", C.c_double)]
 
 
 class BaProblem(C.Structure):

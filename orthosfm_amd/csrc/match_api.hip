@@ -105,9 +105,12 @@ struct osfm_matcher {
     // scratch (grow-only)
     DeviceBuffer d_problems[2], rowparts, colparts, out, keep, mark_off[2], counts[2];
     DeviceBuffer exact_items, exact_count, stage_in, flags;
+    DeviceBuffer sp_parts, d_spjobs;      // match_special_kernel: results, job list
+    int special_max = 512;                // views with more special descriptors take the per-view operand forms
     DeviceBuffer d_m12_off, d_len12, d_corr_off, d_keep_pair, d_corr;
     DeviceBuffer d_jobs, d_inl, d_inl_count, d_corr2, d_gather_off;
     hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipEvent_t ev_sp[2] = {nullptr, nullptr};
 
     // cascade hashing: projection matrices (transposed), running sums, average; the
     // hashes depend on the average over ALL views, hence the dirty flag
@@ -196,6 +199,8 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
     res->plans.assign(num_pairs, PairPlan());
     res->counts.assign(num_pairs, 0);
     std::vector<MatchProblem> probs[2];
+    std::vector<SpecialJob> spjobs;
+    int64_t sp_recs = 0;
     std::vector<int64_t> mark_off[2];
     int64_t out_ints = 0, rowpart_recs = 0, colpart_recs = 0, keep_bytes = 0, total_queries = 0;
     int total_blocks[2] = {0, 0}, max_n[2] = {0, 0};
@@ -257,14 +262,36 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
             pr.special_slot = n_special > 0 ? a.special_slot.as<int32_t>() : nullptr;
             const bool empty = pr.n1 == 0 || pr.n2 == 0;
             if (limited) needs_mask[type] = true;
-            if (!empty && n_special > 0) any_special[type] = true;
             // correction-free column operand: SURF bytes are the values; SIFT views
             // without a value > 127 (the raw copy then holds every descriptor)
             pr.B_raw = (type == 0 ? b.sift_raw : b.surf).as<int8_t>();
             pr.c0 = (type == 1 || b.n_special == 0) ? 1 : 0;
+            // Few special descriptors on either side (the case real SIFT data produces,
+            // sift.cc:830-839): they go through match_special_kernel and every other
+            // descriptor of both views stays on the correction-free form.
+            if (type == 0 && !limited && !cascade && !empty && (a.n_special > 0 || b.n_special > 0) &&
+                a.n_special <= m->special_max && b.n_special <= m->special_max) {
+                pr.sp = 1; pr.c0 = 1;
+                pr.nsA = a.n_special; pr.nsB = b.n_special;
+                pr.n_special = 0;                          // no special row blocks in the tile launch
+                pr.special_slot = a.n_special > 0 ? a.special_slot.as<int32_t>() : nullptr;
+                pr.B_special = b.special.as<int8_t>();
+                pr.corrB_special = b.special_corr.as<int32_t>();
+                pr.special_map_B = b.special_map.as<int32_t>();
+                pr.special_slot_B = b.n_special > 0 ? b.special_slot.as<int32_t>() : nullptr;
+                for (int side = 0; side < 2; ++side) {
+                    const int ns = side == 0 ? pr.nsA : pr.nsB, no = side == 0 ? pr.n2 : pr.n1;
+                    if (ns == 0) continue;
+                    const int nchunk = (no + kSpChunk - 1) / kSpChunk;
+                    pr.sp_row_off[side] = sp_recs; sp_recs += (int64_t)nchunk * round_up(ns, 32);
+                    pr.sp_col_off[side] = sp_recs; sp_recs += round_up(no, 32);
+                    for (int c = 0; c < nchunk; ++c) spjobs.push_back({(int)probs[type].size(), side, c, 0});
+                }
+            }
             if (!empty && !limited) (pr.c0 ? any_c0 : any_corrected)[type] = true;
+            if (!empty && pr.n_special > 0) any_special[type] = true;
             pr.nrb_main = empty ? 0 : (pr.n1 + kRowsPerBlock - 1) / kRowsPerBlock;
-            pr.nrb = pr.nrb_main + (empty ? 0 : (n_special + kRowsPerBlock - 1) / kRowsPerBlock);
+            pr.nrb = pr.nrb_main + (empty ? 0 : (pr.n_special + kRowsPerBlock - 1) / kRowsPerBlock);
             pr.nseg = empty ? 0 : (pr.n2 + kSegCols - 1) / kSegCols;
             pr.n2stride = round_up(pr.n2, 64);
             pr.block_start = total_blocks[type];
@@ -319,7 +346,12 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
     OSFM_RETURN_IF(m->keep.reserve((size_t)std::max<int64_t>(keep_bytes, 16)));
     OSFM_RETURN_IF(m->exact_items.reserve((size_t)std::max<int64_t>(total_queries, 1) * sizeof(ExactItem)));
     OSFM_RETURN_IF(m->exact_count.reserve(16));
+    OSFM_RETURN_IF(m->sp_parts.reserve((size_t)std::max<int64_t>(sp_recs, 1) * sizeof(RowPart)));
+    OSFM_RETURN_IF(m->d_spjobs.reserve(std::max<size_t>(spjobs.size(), 1) * sizeof(SpecialJob)));
     hipStream_t s = m->stream;
+    if (!spjobs.empty())
+        OSFM_HIP_CHECK(hipMemcpyAsync(m->d_spjobs.ptr, spjobs.data(), spjobs.size() * sizeof(SpecialJob),
+            hipMemcpyHostToDevice, s));
     int32_t *d_out = m->out.as<int32_t>();
     OSFM_HIP_CHECK(hipMemsetAsync(d_out, 0xff, (size_t)std::max<int64_t>(out_ints, 4) * 4, s));
 
@@ -357,8 +389,13 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
                 any_corrected[type], dp, np, total_blocks[type],
                 m->rowparts.as<RowPart>(), m->colparts.as<ColPart>(), s);
             if (timed[type]) OSFM_HIP_CHECK(hipEventRecord(m->ev[type][1], s));
+            if (type == 0 && !spjobs.empty()) {
+                OSFM_HIP_CHECK(hipEventRecord(m->ev_sp[0], s));
+                launch_match_special(dp, m->d_spjobs.as<SpecialJob>(), (int)spjobs.size(), m->sp_parts.as<RowPart>(), s);
+                OSFM_HIP_CHECK(hipEventRecord(m->ev_sp[1], s));
+            }
             launch_match_finish(dp, np, max_n[type], m->rowparts.as<RowPart>(),
-                m->colparts.as<ColPart>(), tab, 0, m->exact_items.as<ExactItem>(), ecount, ecap, s);
+                m->colparts.as<ColPart>(), m->sp_parts.as<RowPart>(), tab, 0, m->exact_items.as<ExactItem>(), ecount, ecap, s);
             launch_exact_scan(type == 0 ? 128 : 64, dp, m->exact_items.as<ExactItem>(), ecount, ecap,
                 tab, s);
         }
@@ -401,6 +438,12 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
             m->stats.tile_kernel_ms += ms;
             m->stats.tile_kernel_launches += 1;
         }
+    }
+    if (!spjobs.empty()) {
+        float ms = 0.f;
+        OSFM_HIP_CHECK(hipEventElapsedTime(&ms, m->ev_sp[0], m->ev_sp[1]));
+        m->stats.special_kernel_ms += ms;
+        m->stats.special_kernel_launches += 1;
     }
     m->stats.exact_scan_queries += hexact[0] + hexact[1];
     if (cascade) {
@@ -633,7 +676,7 @@ int osfm_match_options_default(osfm_match_options *o)
     o->matcher_type = OSFM_MATCHER_EXHAUSTIVE;
     o->ransac_seed = 0;
     o->cascade_keep_empty_blocks = 0;
-    o->reserved = 0;
+    o->special_kernel_max = 0;
     return OSFM_OK;
 }
 
@@ -661,6 +704,8 @@ int osfm_match_create(int device, int num_views, const osfm_match_options *opts,
     OSFM_HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2; ++j) OSFM_HIP_CHECK(hipEventCreate(&m->ev[i][j]));
+    for (int j = 0; j < 2; ++j) OSFM_HIP_CHECK(hipEventCreate(&m->ev_sp[j]));
+    if (m->opts.special_kernel_max != 0) m->special_max = std::max(m->opts.special_kernel_max, 0);
     std::vector<int32_t> t;
     build_lowe_table(m->opts.sift_lowe_ratio, false, &t);
     OSFM_RETURN_IF(m->lowe_sift.reserve(t.size() * 4));
@@ -687,6 +732,8 @@ int osfm_match_destroy(osfm_matcher *m)
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2; ++j)
             if (m->ev[i][j]) (void)hipEventDestroy(m->ev[i][j]);
+    for (int j = 0; j < 2; ++j)
+        if (m->ev_sp[j]) (void)hipEventDestroy(m->ev_sp[j]);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     for (auto *sg : m->comb_staging) { if (sg->ptr) (void)hipHostFree(sg->ptr); delete sg; }
     delete m;       // every DeviceBuffer (views, scratch, cascade-hashing data) frees itself

@@ -47,6 +47,25 @@ struct MatchProblem {
     // ip = sum(a * b) needs no correction at all and the MFMA C operand is 0.
     int32_t c0;
     const int8_t *B_raw;
+    // sp != 0 (SIFT, both views with few special descriptors): the tile kernel runs the
+    // correction-free form on A_raw x B_raw for EVERY pair -- special descriptors are blank
+    // (zero) rows / columns there, which score 0 and change nothing (the reference's state
+    // starts at (0, 0)) -- and match_special_kernel scores the special descriptors of either
+    // view against all descriptors of the other one exactly:
+    //   side 0: special rows of set 1 (A_special) x all of set 2;  side 1: special rows of
+    //   set 2 (B_special) x all of set 1.
+    // sp_row_off[side]: RowPart[chunks of the other set][ns rounded up to 32] -- the complete
+    //   (best, second, index) of every special descriptor per 4096-candidate chunk;
+    // sp_col_off[side]: RowPart[n of the other set] -- for every descriptor of the other set
+    //   its exact (best, second, index) over the special descriptors of this side.
+    int32_t sp;
+    int32_t nsA, nsB;                  // special descriptors of set 1 / set 2
+    const int8_t *B_special;           // [nsB padded to 256][128], value - 128 form
+    const int32_t *corrB_special;
+    const int32_t *special_map_B;      // [nsB] original column of a special slot
+    const int32_t *special_slot_B;     // [n2] slot of a column or -1
+    int64_t sp_row_off[2];
+    int64_t sp_col_off[2];
     // cascade hashing mode (cashash_kernels.h): hash data of set 1 / set 2
     const void *cas_rec[2];          // CasRecord[n]: hash words + packed bucket ids
     const int32_t *cas_start[2];
@@ -78,6 +97,13 @@ struct LoweTable {
 // wrap-around arithmetic (nearest_neighbor.cc:75-84 and the T-typed state).
 struct ExactItem { int32_t problem; int32_t dir; int32_t query; };
 
+// One workgroup of match_special_kernel: the special descriptors of one side of a problem
+// against one chunk of kSpChunk descriptors of the other set.
+constexpr int kSpChunk = 4096;
+struct SpecialJob { int32_t problem, side, chunk, pad; };
+void launch_match_special(const MatchProblem *d_problems, const SpecialJob *d_jobs, int num_jobs,
+    RowPart *sp_parts, hipStream_t s);
+
 // any_special: some problem has row blocks behind nrb_main (gathered special rows);
 // any_c0 / any_corrected: some problem has / lacks the correction-free column operand
 void launch_match_tiles(int ch, bool masked, bool any_special, bool any_c0, bool any_corrected,
@@ -85,7 +111,7 @@ void launch_match_tiles(int ch, bool masked, bool any_special, bool any_c0, bool
     int num_problems, int total_blocks, RowPart *rowparts, ColPart *colparts, hipStream_t s);
 
 void launch_match_finish(const MatchProblem *d_problems, int num_problems,
-    int max_n, const RowPart *rowparts, const ColPart *colparts, LoweTable tab,
+    int max_n, const RowPart *rowparts, const ColPart *colparts, const RowPart *sp_parts, LoweTable tab,
     int force_exact, ExactItem *exact_items, int32_t *exact_count, int exact_cap,
     hipStream_t s);
 

@@ -226,6 +226,12 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
                 // to a 64-bit lane pointer with a vector instruction per DMA (two per tile in a loop
                 // where every vector operation per tile is ~1 % of the time).  The compiler does not
                 // see this memory operation: dma_wait() below stands where its s_waitcnt would.
+                // m0 is written here behind the compiler's back (hipcc rejects it as a clobber: a
+                // reserved register).  That is safe only because NOTHING else in this instantiation
+                // uses m0: PIPE implies RAW, so the builtin DMA of the column corrections below does
+                // not exist in it (static_assert), and gfx950 LDS / readlane instructions do not read
+                // m0.  tools/check_m0.sh greps the ISA of the PIPE kernels for any other m0 use.
+                static_assert(!PIPE || RAW, "the PIPE schedule must not contain compiler-managed m0 users");
                 const unsigned lds_at = (unsigned)(uintptr_t)(bbuf + buf * TILE_BYTES + q0 * 16);
                 asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"
                              :: "v"(lane_off[c]), "s"(src), "s"(lds_at) : "memory");
@@ -774,7 +780,7 @@ rescan_groups(const MatchProblem &pd, const int (&q)[2], const int (&idx1)[2], c
 template <int DIM, bool SIGNED>
 __global__ __launch_bounds__(128) void
 match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__restrict__ rowparts,
-    const ColPart *__restrict__ colparts, LoweTable tab, int force_exact,
+    const ColPart *__restrict__ colparts, const RowPart *__restrict__ sp_parts, LoweTable tab, int force_exact,
     ExactItem *__restrict__ exact_items, int32_t *__restrict__ exact_count, int exact_cap,
     int blocks_per_dir, int total_blocks)
 {
@@ -795,13 +801,34 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
 
     // ip1 / idx1: exact best; ip2: second largest GROUP best (lower bound of the
     // true second); code: group of the best (dir 1), idx1 = its row block there
+    // kind1 = 2: (ip1, ip2, idx1) are exact values from match_special_kernel, nothing to re-score
     int ip1 = INT_MIN, ip2 = INT_MIN, idx1 = 0, code = 0, kind1 = 0;
-    if (active && nc > 0) {
+    // Problems whose special descriptors went through match_special_kernel (pd.sp): a special
+    // query takes its complete result from there (one partial per chunk of candidates); any
+    // other query merges the tile kernel's partials below and then the exact top-2 over the
+    // OTHER set's special descriptors, which the tile kernel saw as blanks.
+    int sp_slot = -1;
+    if (active && nc > 0 && pd.sp) {
+        const int ns_mine = dir == 0 ? pd.nsA : pd.nsB;
+        if (ns_mine > 0) sp_slot = (dir == 0 ? pd.special_slot : pd.special_slot_B)[q];
+        if (sp_slot >= 0) {
+            const int ns_pad = (ns_mine + 31) & ~31;
+            const int nchunk = (nc + kSpChunk - 1) / kSpChunk;
+            const RowPart *rp0 = sp_parts + pd.sp_row_off[dir] + sp_slot;
+            for (int c = 0; c < nchunk; ++c) {
+                const RowPart p = rp0[(int64_t)c * ns_pad];
+                ip2 = max(max(ip2, p.ip_second), min(ip1, p.ip_best));
+                if (p.ip_best >= ip1 && p.ip_best != INT_MIN) { ip1 = p.ip_best; idx1 = p.idx_best; }   // later chunk wins ties
+            }
+            kind1 = 2;
+        }
+    }
+    if (active && nc > 0 && sp_slot < 0) {
         if (dir == 0) {
             const int64_t stride = (int64_t)pd.nrb * kRowsPerBlock;
             // special rows keep their partials behind the main row blocks
             int slot = q;
-            if (pd.special_slot) {
+            if (pd.special_slot && !pd.sp) {
                 const int sidx = pd.special_slot[q];
                 if (sidx >= 0) slot = pd.nrb_main * kRowsPerBlock + sidx;
             }
@@ -848,6 +875,17 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
                 }
             }
         }
+        if (pd.sp && (dir == 0 ? pd.nsB : pd.nsA) > 0) {
+            // the other set's special descriptors as candidates of this query (exact values)
+            const RowPart t = sp_parts[pd.sp_col_off[dir ^ 1] + q];
+            ip2 = max(max(ip2, t.ip_second), min(ip1, t.ip_best));
+            if (t.ip_best >= ip1 && t.ip_best != INT_MIN) {
+                // the best is a special descriptor: ip2 = max(best of the others -- an exact score or a
+                // blank's 0 --, second among the special ones) is exact as well
+                ip1 = t.ip_best; kind1 = 2;
+                idx1 = (dir == 0 ? pd.special_map_B : pd.special_map)[t.idx_best];
+            }
+        }
     }
     const int limit = tab.is_signed ? 32767 : 65535;
     bool exact = active && nc > 0 && (force_exact || pd.force_exact || ip1 > limit);
@@ -855,12 +893,12 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
     int res = -1;
     if (active && nc > 0 && !exact) {
         // optimistic test against the lower bound of the second best
-        res = accept_match(ip1, ip2, 0, tab);
+        res = accept_match(ip1, ip2, kind1 == 2 ? idx1 : 0, tab);
         if (res >= 0) {
             if (ip1 < 0) res = 0;             // reference state (0, 0, idx 0): nothing to refine
             else if (ip2 == ip1) exact = true;  // accepted despite a tie for best (NaN accept /
                                                 // ratio >= 1): defer to the sequential-scan kernel
-            else refine = true;
+            else if (kind1 != 2) refine = true; // kind 2: exact already, res is final
         }
     }
     // Queries that pass get their best group re-scored, one query at a time by
@@ -908,7 +946,7 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
 }
 
 void launch_match_finish(const MatchProblem *d_problems, int num_problems, int max_n,
-    const RowPart *rowparts, const ColPart *colparts, LoweTable tab, int force_exact,
+    const RowPart *rowparts, const ColPart *colparts, const RowPart *sp_parts, LoweTable tab, int force_exact,
     ExactItem *exact_items, int32_t *exact_count, int exact_cap, hipStream_t s)
 {
     if (num_problems <= 0 || max_n <= 0) return;
@@ -918,10 +956,10 @@ void launch_match_finish(const MatchProblem *d_problems, int num_problems, int m
     const dim3 grid((unsigned)total);
     if (tab.is_signed)
         hipLaunchKernelGGL((match_finish_kernel<64, true>), grid, dim3(128), 0, s, d_problems, rowparts,
-            colparts, tab, force_exact, exact_items, exact_count, exact_cap, blocks_per_dir, (int)total);
+            colparts, sp_parts, tab, force_exact, exact_items, exact_count, exact_cap, blocks_per_dir, (int)total);
     else
         hipLaunchKernelGGL((match_finish_kernel<128, false>), grid, dim3(128), 0, s, d_problems, rowparts,
-            colparts, tab, force_exact, exact_items, exact_count, exact_cap, blocks_per_dir, (int)total);
+            colparts, sp_parts, tab, force_exact, exact_items, exact_count, exact_cap, blocks_per_dir, (int)total);
 }
 
 // ---------------------------------------------------------------------------

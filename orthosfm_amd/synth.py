@@ -201,6 +201,38 @@ def make_image_set(num_views: int, feats_per_view: int, *, seed: int = BASE_SEED
     return ImageSet(sift, surf, landmark, pos, cams, points, width, height)
 
 
+def add_peaky_rows(iset: "ImageSet", k: int, *, seed: int = BASE_SEED, stream: int = 0x7EA) -> list:
+    """Replaces k SIFT rows of every view by descriptors with their energy in one to three
+    bins, built the way MVE builds them (normalise, clamp at 0.2, normalise again,
+    src/mve/sfm/sift.cc:830-839): the renormalisation lifts the clamped bins to 0.5-1.0,
+    i.e. bytes 128..255 after convert_descriptor -- the rows real images produce at corners
+    and line ends, and the ones a plain Gaussian generator never draws.  Half of the k rows
+    of a view show landmarks shared by all views (the same peaky base descriptor plus
+    noise, so they are each other's best matches), the rest are unique to the view.
+    Returns the replaced row ids per view."""
+    rng = np.random.default_rng([seed & 0xFFFFFFFF, stream, k])
+    n_shared = (k + 1) // 2
+
+    def peaky(n):
+        f = np.abs(rng.normal(size=(n, 128))) * 0.01
+        for i in range(n):
+            nb = int(rng.integers(1, 4))
+            f[i, rng.choice(128, nb, replace=False)] = rng.uniform(0.6, 1.0, nb)
+        return f
+
+    base = peaky(n_shared)
+    rows_out = []
+    for v in range(iset.num_views):
+        n = iset.sift[v].shape[0]
+        rows = np.sort(rng.choice(n, min(k, n), replace=False))
+        f = np.concatenate([base + np.abs(rng.normal(size=base.shape)) * 0.004, peaky(k - n_shared)], axis=0)[:len(rows)]
+        q = quantize_sift(sift_like(f))
+        assert (q.max(axis=1) > 127).all()
+        iset.sift[v][rows] = q[rng.permutation(len(rows))]
+        rows_out.append(rows)
+    return rows_out
+
+
 # ---------------------------------------------------------------------------
 # camera models used to PLACE synthetic observations (generation only)
 # ---------------------------------------------------------------------------

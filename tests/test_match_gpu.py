@@ -270,19 +270,102 @@ def test_special_rows_large_values(hm):
     # duplicates of special rows: ties between special and ordinary blocks
     s1[10] = s1[2990]
     s2[5] = s2[2000]
+    from orthosfm_amd import capi
     om = oracle_lib.oracle_matcher()
     e12, e21 = om.twoway(s1, s2, 0.8)
-    m = hm(2)
-    m.set_view(0, s1)
-    m.set_view(1, s2)
-    got = m.twoway_match(0, 1, 0)       # masked (keyed) kernel
-    assert np.array_equal(got.matches_1_2, e12) and np.array_equal(got.matches_2_1, e21)
     c12, c21 = om.remove_inconsistent(e12, e21)
-    got = m.pairwise_match(0, 1)        # raw + special-row kernel
-    assert np.array_equal(got.matches_1_2, c12) and np.array_equal(got.matches_2_1, c21)
-    got = m.pairwise_match(1, 0)
-    assert np.array_equal(got.matches_1_2, c21) and np.array_equal(got.matches_2_1, c12)
-    m.close()
+    for smax in (-1, 0):                    # the gathered row blocks this test was written for, then the special kernel
+        o = capi.default_match_options()
+        o.special_kernel_max = smax
+        m = hm(2, options=o)
+        m.set_view(0, s1)
+        m.set_view(1, s2)
+        got = m.twoway_match(0, 1, 0)       # masked (keyed) kernel
+        assert np.array_equal(got.matches_1_2, e12) and np.array_equal(got.matches_2_1, e21)
+        got = m.pairwise_match(0, 1)        # raw + special-row blocks / correction-free + special kernel
+        assert np.array_equal(got.matches_1_2, c12) and np.array_equal(got.matches_2_1, c21), smax
+        got = m.pairwise_match(1, 0)
+        assert np.array_equal(got.matches_1_2, c21) and np.array_equal(got.matches_2_1, c12), smax
+        m.close()
+
+
+@pytest.mark.parametrize("k", [1, 20, 200, 600])
+def test_special_descriptors_few_per_view(hm, k):
+    """The case real SIFT data produces (sift.cc:830-839 renormalises after the clamp): k
+    descriptors per view with bytes > 127, built like MVE builds them.  Up to
+    special_kernel_max of them (512) go through match_special_kernel while every other
+    descriptor stays on the correction-free tile kernel; more (600), or a negative option,
+    select the per-view operand forms.  Both against the oracle, all three pair
+    orientations (special rows only in set 1, only in set 2, in both), 5000 features per
+    view = two candidate chunks of the special kernel, k = 200 / 600 = several units."""
+    from orthosfm_amd import capi
+    iset = synth.make_image_set(3, 5000, config_id=31)
+    rows = synth.add_peaky_rows(iset, k)
+    iset.sift[2][rows[2]] = synth.make_image_set(1, 5000, config_id=32).sift[0][rows[2]]   # view 2 stays plain
+    # a special and an ordinary descriptor of view 1 doubled in view 0: ties across the two kernels
+    iset.sift[0][7] = iset.sift[1][rows[1][0]]
+    iset.sift[0][8] = iset.sift[1][rows[1][0]]
+    om = oracle_lib.oracle_matcher()
+    expect = {}
+    for a, b in ((0, 1), (2, 1), (0, 2), (1, 0)):
+        e12, e21 = om.twoway(iset.sift[a], iset.sift[b], 0.8)
+        expect[(a, b)] = om.remove_inconsistent(e12, e21)
+    for smax in (0, -1):
+        o = capi.default_match_options()
+        o.special_kernel_max = smax
+        m = hm(3, options=o)
+        for v in range(3):
+            m.set_view(v, iset.sift[v])
+        for (a, b), (c12, c21) in expect.items():
+            got = m.pairwise_match(a, b)
+            assert np.array_equal(got.matches_1_2, c12) and np.array_equal(got.matches_2_1, c21), (k, smax, a, b)
+            assert (m.stats().special_kernel_launches > 0) == (smax == 0 and k <= 512), (k, smax, a, b)
+        m.close()
+    assert int((expect[(0, 1)][0] >= 0).sum()) > 800
+
+
+def test_special_descriptors_edge_shapes(hm):
+    """match_special_kernel at its edges: views where EVERY descriptor is special (the tile
+    kernel then sees blanks only), 33 special rows (a unit of 32 plus one), a one-descriptor
+    view, sizes off every multiple, exact duplicates (accepted ties go to the scan kernel),
+    lowe ratio 1 (everything accepted, including ties at 0)."""
+    from orthosfm_amd import capi
+    r = np.random.default_rng(77)
+    om = oracle_lib.oracle_matcher()
+
+    def rand_special(n):
+        d = np.zeros((n, 128), np.uint16)
+        for i in range(n):
+            pos = r.choice(128, 4, replace=False)
+            d[i, pos] = [int(r.integers(128, 256)), int(r.integers(0, 200)), int(r.integers(0, 90)), int(r.integers(0, 40))]
+        return d
+
+    plain = synth.make_image_set(2, 700, config_id=33)
+    cases = []
+    cases.append((rand_special(97), rand_special(61)))                     # all special on both sides
+    cases.append((rand_special(33), plain.sift[0][:515].copy()))           # 33 special rows vs a plain view
+    cases.append((plain.sift[1][:1].copy(), rand_special(40)))             # one-descriptor view
+    a = plain.sift[0].copy(); b = plain.sift[1].copy()
+    a[[3, 100, 699]] = rand_special(3); b[[0, 650]] = rand_special(2)
+    b[5] = a[3]; b[6] = a[3]; a[50] = b[650]                               # duplicates of special rows
+    cases.append((a, b))
+    z = plain.sift[0][:300].copy(); z[10:20] = 0                           # zero descriptors: inner products of 0
+    cases.append((z, rand_special(12)))
+    for lowe in (0.8, 1.0):
+        o = capi.default_match_options()
+        o.sift_lowe_ratio = lowe
+        for ci, (s1, s2) in enumerate(cases):
+            e12, e21 = om.twoway(s1, s2, lowe)
+            c12, c21 = om.remove_inconsistent(e12, e21)
+            m = hm(2, options=o)
+            m.set_view(0, s1)
+            m.set_view(1, s2)
+            got = m.pairwise_match(0, 1)
+            assert np.array_equal(got.matches_1_2, c12) and np.array_equal(got.matches_2_1, c21), (lowe, ci)
+            assert m.stats().special_kernel_launches > 0
+            got = m.pairwise_match(1, 0)
+            assert np.array_equal(got.matches_1_2, c21) and np.array_equal(got.matches_2_1, c12), (lowe, ci)
+            m.close()
 
 
 def test_mixed_operand_forms_in_one_batch(hm):
@@ -299,21 +382,26 @@ def test_mixed_operand_forms_in_one_batch(hm):
             d = iset.sift[v][k].copy()
             d[r.choice(128, 2, replace=False)] = [int(r.integers(128, 256)), int(r.integers(128, 200))]
             iset.sift[v][k] = d
-    o = capi.default_match_options()
-    o.use_lowres_matching = 0
-    o.min_feature_matches = 0
-    m = hm(4, options=o)
-    for v in range(4):
-        m.set_view(v, iset.sift[v], iset.surf[v])
-    out = m.compute()
-    assert len(out) == 6
-    for tv in out:
-        a, b = tv.view_1_id, tv.view_2_id
-        e12, _ = oracle_lib.oracle_pairwise_match(iset.sift[a], iset.surf[a], iset.sift[b], iset.surf[b])
-        idx = np.nonzero(e12 >= 0)[0]
-        exp = np.stack([idx, e12[idx]], axis=1).astype(np.int32)
-        assert tv.status == capi.PAIR_MATCHED and np.array_equal(tv.matches, exp), (a, b)
-    m.close()
+    expect = {}
+    for smax in (-1, 0):       # the per-view forms (what the name says), then the special kernel on the same set
+        o = capi.default_match_options()
+        o.use_lowres_matching = 0
+        o.min_feature_matches = 0
+        o.special_kernel_max = smax
+        m = hm(4, options=o)
+        for v in range(4):
+            m.set_view(v, iset.sift[v], iset.surf[v])
+        out = m.compute()
+        assert len(out) == 6
+        assert (m.stats().special_kernel_launches > 0) == (smax == 0)
+        for tv in out:
+            a, b = tv.view_1_id, tv.view_2_id
+            if (a, b) not in expect:
+                e12, _ = oracle_lib.oracle_pairwise_match(iset.sift[a], iset.surf[a], iset.sift[b], iset.surf[b])
+                idx = np.nonzero(e12 >= 0)[0]
+                expect[(a, b)] = np.stack([idx, e12[idx]], axis=1).astype(np.int32)
+            assert tv.status == capi.PAIR_MATCHED and np.array_equal(tv.matches, expect[(a, b)]), (smax, a, b)
+        m.close()
 
 
 def test_gather_reorder_on_device():
@@ -409,31 +497,44 @@ def test_full_size_bit_parity_20k(hm):
     from -- compared with the oracle list by list (two-way lists, then the
     cross-checked ones), and once more with a few hundred rows holding values > 127
     in both views (special-row blocks + the corrected column operand)."""
+    from orthosfm_amd import capi
     iset = synth.make_image_set(2, 20000, config_id=2)
     om = oracle_lib.oracle_matcher()
     m = hm(2)
-    for variant in ("plain", "special"):
+    o_forms = capi.default_match_options()
+    o_forms.special_kernel_max = -1            # "special-forms": the per-view operand forms on the same input
+    m_forms = hm(2, options=o_forms)
+    expect = None
+    for variant in ("plain", "special", "special-forms"):
         s1, s2 = iset.sift[0].copy(), iset.sift[1].copy()
-        if variant == "special":
+        if variant != "plain":
             r = np.random.default_rng(41)
             for s in (s1, s2):
                 for k in r.choice(20000, 400, replace=False):
                     d = s[k].copy()
                     d[r.choice(128, 2, replace=False)] = [int(r.integers(128, 256)), int(r.integers(128, 180))]
                     s[k] = d
-        e12, e21 = om.twoway(s1, s2, 0.8)
-        c12, c21 = om.remove_inconsistent(e12, e21)
-        m.set_view(0, s1)
-        m.set_view(1, s2)
-        got = m.pairwise_match(0, 1)
+        if variant == "special-forms":
+            e12, e21, c12, c21 = expect        # same input as "special"
+            mm = m_forms
+        else:
+            e12, e21 = om.twoway(s1, s2, 0.8)
+            c12, c21 = om.remove_inconsistent(e12, e21)
+            expect = (e12, e21, c12, c21)
+            mm = m
+        mm.set_view(0, s1)
+        mm.set_view(1, s2)
+        got = mm.pairwise_match(0, 1)
         assert np.array_equal(got.matches_1_2, c12) and np.array_equal(got.matches_2_1, c21), variant
+        assert (mm.stats().special_kernel_launches > 0) == (variant == "special"), variant
         if variant == "plain":
             assert int((c12 >= 0).sum()) > 5000
         else:       # the over-long rows out-score the true partners of most queries: few matches survive
             assert 0 < int((c12 >= 0).sum()) < 5000
-        two = m.twoway_match(0, 1, 0)           # the pre-cross-check seam (masked kernel)
+        two = mm.twoway_match(0, 1, 0)           # the pre-cross-check seam (masked kernel)
         assert np.array_equal(two.matches_1_2, e12) and np.array_equal(two.matches_2_1, e21), variant
     m.close()
+    m_forms.close()
 
 
 def test_capacity_overflow_with_verification(hm):
