@@ -80,6 +80,7 @@ def parse():
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the extra passes with RANSAC-F")
     ap.add_argument("--no-e2e", action="store_true", help="skip the 200-image matching run and the end-to-end job")
+    ap.add_argument("--no-realistic", action="store_true", help="skip the passes with special SIFT rows (bytes > 127)")
     ap.add_argument("--e2e-views", type=int, default=200)
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = auto (about 15 s of CPU work)")
     ap.add_argument("--no-lowres-gate", action="store_true",
@@ -357,6 +358,62 @@ def gated_bench(V, F, device_index):
             "mutual_matches_of_matched_pairs": pre, "ransac_inliers": inl,
             "outlier_share_removed_by_ransac": 1.0 - inl / max(pre, 1),
             "inliers_on_the_same_landmark": good / max(tot, 1)}
+
+
+def realistic_operands_bench(iset, V, pairs, capacity, device_index, headline_ms, steps, with_cpu):
+    """The headline workload with k descriptors per view holding a byte in 128-255, built as
+    MVE builds them (few dominant bins, renormalised after the 0.2 clamp: sift.cc:830-839) --
+    the rows a dense Gaussian generator never draws and real images do.  Same 50 x 20k set,
+    same pairs, same gates; per k: pairs/s, device time of the tile kernel and of the kernel
+    that scores the special descriptors, and a few pairs re-done by the CPU oracle."""
+    import copy
+    from orthosfm_amd import capi, synth
+    from orthosfm_amd.matching import HipExhaustiveMatching
+    out = {"what": "k SIFT descriptors per view with a byte > 127 (synth.add_peaky_rows); everything else as the headline",
+           "headline_ms_per_step": headline_ms, "cases": []}
+    for k in (1, 20, 200):
+        sub = copy.copy(iset)
+        sub.sift = [a.copy() for a in iset.sift]
+        synth.add_peaky_rows(sub, k)
+        m = HipExhaustiveMatching(V, device=device_index, copy_results=False)
+        for v in range(V):
+            m.set_view(v, sub.sift[v])
+        m.use_result_buffer(capi.pinned_rows(capacity))
+        m.compute_arrays(pairs, capacity=capacity)
+        t0 = time.perf_counter()
+        tile_ms = sp_ms = 0.0
+        launches = 0
+        for _ in range(steps):
+            ra, corr = m.compute_arrays(pairs, capacity=capacity)
+            st = m.stats()
+            tile_ms += st.tile_kernel_ms; sp_ms += st.special_kernel_ms; launches += st.tile_kernel_launches
+        dt = (time.perf_counter() - t0) / steps
+        case = {"special_rows_per_view": k, "pairs_per_s": len(pairs) / dt, "ms_per_step": dt * 1e3,
+                "relative_to_headline": headline_ms / (dt * 1e3),
+                "tile_kernel_ms_per_step": tile_ms / steps, "special_kernel_ms_per_step": sp_ms / steps,
+                "tile_kernel": "match_tile_kernel<8, false, true, true> only (special_kernel_launches > 0: "
+                               + str(bool(st.special_kernel_launches > 0)) + ")"}
+        if with_cpu:
+            import oracle_lib
+            objs = m.as_objects(ra, corr)
+            bad, checked = [], 0
+            for idx in np.linspace(0, len(pairs) - 1, 3).astype(int):
+                tv = objs[idx]
+                a, b = pairs[idx]
+                e12, _ = oracle_lib.oracle_pairwise_match(sub.sift[a], sub.surf[a], sub.sift[b], sub.surf[b])
+                ids = np.nonzero(e12 >= 0)[0]
+                exp = np.stack([ids, e12[ids]], axis=1).astype(np.int32)
+                if tv.status == capi.PAIR_MATCHED:
+                    checked += 1
+                    if not np.array_equal(np.asarray(tv.matches), exp):
+                        bad.append([int(a), int(b)])
+            case["parity_checked_pairs"] = checked
+            case["parity_ok"] = not bad
+            if bad:
+                case["parity_bad_pairs"] = bad
+        out["cases"].append(case)
+        m.close()
+    return out
 
 
 def per_pair_latency(m, pairs, n=24):
@@ -709,6 +766,14 @@ def main():
                                             "kind": "port", "sample": f"{len(ts)} pairs of the timed pass", "identical_inliers": bool(same)}
         m2.close()
 
+    realistic = None
+    if extras and not args.no_realistic:
+        try:
+            realistic = realistic_operands_bench(iset, V, my_pairs, capacity, device_index, dt / args.steps * 1e3,
+                                                 max(args.steps, 3), not args.no_cpu_baseline)
+        except Exception as e:
+            realistic = {"error": repr(e)}
+
     gated = None
     if extras and not args.no_verify and not args.no_ba:
         try:
@@ -823,6 +888,10 @@ def main():
             line["cascade_hashing"] = cascade
         if verified is not None:
             line["with_geometric_verification"] = verified
+        if realistic is not None:
+            line["realistic_operands"] = realistic
+            if any(not c.get("parity_ok", True) for c in realistic.get("cases", [])):
+                parity_bad = parity_bad + ["realistic_operands"]
         if gated is not None:
             line["gates_at_work"] = gated
         if ba is not None:

@@ -285,7 +285,9 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
                     const int nchunk = (no + kSpChunk - 1) / kSpChunk;
                     pr.sp_row_off[side] = sp_recs; sp_recs += (int64_t)nchunk * round_up(ns, 32);
                     pr.sp_col_off[side] = sp_recs; sp_recs += round_up(no, 32);
-                    for (int c = 0; c < nchunk; ++c) spjobs.push_back({(int)probs[type].size(), side, c, 0});
+                    // pad: the view whose descriptors the job streams (sort key below)
+                    for (int c = 0; c < nchunk; ++c)
+                        spjobs.push_back({(int)probs[type].size(), side, c, side == 0 ? pl.v2 : pl.v1});
                 }
             }
             if (!empty && !limited) (pr.c0 ? any_c0 : any_corrected)[type] = true;
@@ -349,6 +351,13 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
     OSFM_RETURN_IF(m->sp_parts.reserve((size_t)std::max<int64_t>(sp_recs, 1) * sizeof(RowPart)));
     OSFM_RETURN_IF(m->d_spjobs.reserve(std::max<size_t>(spjobs.size(), 1) * sizeof(SpecialJob)));
     hipStream_t s = m->stream;
+    // Workgroups that stream the same 4096 descriptors of the same view run next to each other:
+    // the chunk (512 KB) is then fetched from HBM once per L2 instead of once per pair (in
+    // pair order the streamed view of side 0 changes with every pair: 3 GB of HBM reads per
+    // 1225 pairs for 128 MB of distinct descriptors).
+    std::stable_sort(spjobs.begin(), spjobs.end(), [](const SpecialJob &x, const SpecialJob &y) {
+        return x.pad != y.pad ? x.pad < y.pad : x.chunk < y.chunk;
+    });
     if (!spjobs.empty())
         OSFM_HIP_CHECK(hipMemcpyAsync(m->d_spjobs.ptr, spjobs.data(), spjobs.size() * sizeof(SpecialJob),
             hipMemcpyHostToDevice, s));

@@ -89,31 +89,27 @@ match_special_kernel(const MatchProblem *__restrict__ problems, const SpecialJob
 #pragma unroll
         for (int r = 0; r < 16; ++r) { kbest[r] = kKeyNone; ksec[r] = kKeyNone; }
 
-        v4i bn[4];
-        int cbn = 0;
-        auto fetch = [&](int st) {
-            const int col = col0 + st * 32 + lr;           // below the bank's 256-row padding
+        // Three steps in flight per wave: a step's operands come straight from L2 / HBM (no
+        // other wave shares them), so the loads of steps j+1 .. j+3 are issued before step j is
+        // reduced -- with one step ahead the kernel was bound by that latency (1.05 ms per
+        // 1225 pairs with one unit per view; the MFMA + reduction work is a quarter of it).
+        struct Stage { v4i b[4]; int cb; RowPart old; };
+        auto fetch = [&](Stage &st, int step) {
+            const int col = col0 + min(step, nsteps - 1) * 32 + lr;     // below the bank's 256-row padding
             const int8_t *p = O + (size_t)col * 128 + lh * 16;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) bn[ks] = *reinterpret_cast<const v4i *>(p + ks * 32);
-            cbn = corrO[col];
+            for (int ks = 0; ks < 4; ++ks) st.b[ks] = *reinterpret_cast<const v4i *>(p + ks * 32);
+            st.cb = corrO[col];
+            // the fold of the earlier units (same lane wrote it: program order)
+            st.old.ip_best = INT_MIN; st.old.idx_best = -1; st.old.ip_second = INT_MIN; st.old.pad = 0;
+            if (u > 0 && lh == 0) st.old = colres[col];
         };
-        int step = wave;
-        if (step < nsteps) fetch(step);
-        for (int j = 0; step < nsteps; step += 4, ++j) {
-            v4i b[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) b[ks] = bn[ks];
-            const int cb = cbn;
+        auto process = [&](const Stage &st, int step, int j) {
+            const int cb = st.cb;
             const int col = col0 + step * 32 + lr;
-            RowPart old;
-            old.ip_best = INT_MIN; old.idx_best = -1; old.ip_second = INT_MIN; old.pad = 0;
-            if (u > 0 && lh == 0) old = colres[col];
-            if (step + 4 < nsteps) fetch(step + 4);
-
             v16i acc = ra;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks], b[ks], acc, 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks], st.b[ks], acc, 0, 0, 0);
 
             // row direction: exact ip = acc + cb (acc carries the row correction)
             const unsigned cjt = ((unsigned)cb << 8) + (unsigned)j;
@@ -137,12 +133,22 @@ match_special_kernel(const MatchProblem *__restrict__ problems, const SpecialJob
             if (lh == 0) {
                 const int fr = nb & 31;
                 const int slot = u * 32 + (fr & 3) + 8 * ((fr >> 2) & 3) + 4 * (fr >> 4);
-                int bip = old.ip_best, bidx = old.idx_best, sec = old.ip_second;
+                int bip = st.old.ip_best, bidx = st.old.idx_best, sec = st.old.ip_second;
                 fold_top2(bip, bidx, sec, (nb >> 5) + cb, slot, (nsec >> 5) + cb);
                 RowPart out;
                 out.ip_best = bip; out.idx_best = bidx; out.ip_second = sec; out.pad = 0;
                 colres[col] = out;          // idx_best: slot among the special descriptors (mapped by the finish kernel)
             }
+        };
+        Stage s0, s1, s2;
+        int step = wave, j = 0;
+        if (step < nsteps) { fetch(s0, step); fetch(s1, step + 4); fetch(s2, step + 8); }
+        while (step < nsteps) {
+            process(s0, step, j); fetch(s0, step + 12); step += 4; ++j;
+            if (step >= nsteps) break;
+            process(s1, step, j); fetch(s1, step + 12); step += 4; ++j;
+            if (step >= nsteps) break;
+            process(s2, step, j); fetch(s2, step + 12); step += 4; ++j;
         }
 
         // ---- row direction: merge the 32 lanes of a half-wave, then the four waves ----
