@@ -124,6 +124,22 @@ OSFM_API int osfm_match_create(int device, int num_views,
 OSFM_API int osfm_match_destroy(osfm_matcher *m);
 
 /*
+ * The same matcher over several devices of one node, for the single C++ process that
+ * drives the reference (bundler::Matching::compute, src/mve/sfm/bundler_matching.cc:58-136):
+ * one worker thread and stream set per entry of device_ids for the duration of a call,
+ * the descriptor bank on every device, the pairs of osfm_match_all dealt by work (N1*N2,
+ * longest first), concurrent osfm_match_pair[_lowres] callers spread round robin.  No
+ * data-path exchange between the devices; results (records, list order, bytes) are those
+ * of osfm_match_create on one device.  A device id may appear more than once (logical
+ * shards on one device).  Every other osfm_match_* entry takes the returned handle.
+ */
+OSFM_API int osfm_match_create_multi(const int *device_ids, int num_devices, int num_views,
+    const osfm_match_options *opts, osfm_matcher **out);
+/* The device of every shard (one entry for a single-device matcher). */
+OSFM_API int osfm_match_get_devices(const osfm_matcher *m, int32_t *device_ids, int capacity,
+    int32_t *num_devices);
+
+/*
  * Host quantisation of float descriptors, i.e. convert_descriptor of
  * ExhaustiveMatching::init_sift / init_surf
  * (src/mve/sfm/exhaustive_matching.cc:17-38, 76-112).

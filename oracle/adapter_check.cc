@@ -136,6 +136,29 @@ int main()
         std::printf("adapter_check ok: %d pairs x 3 rounds from 8 OpenMP threads identical to the serial calls\n", num_pairs);
     }
 
+    /* Two and three logical devices behind the same virtual interface (osfm_match_create_multi;
+     * on a one-GPU box device 0 several times): identical to sfm::ExhaustiveMatching from the
+     * serial loop and from the OpenMP team. */
+    for (int nd : { 2, 3 }) {
+        sfm::bundler::ViewportList ve;
+        fill_views(&ve, 7);
+        std::unique_ptr<sfm::MatchingBase> multi(new osfm_adapter::HipMatching(std::vector<int>(nd, 0)));
+        multi->init(&ve);
+        int bad = 0;
+        const int num_pairs = 5 * 4;
+#pragma omp parallel for schedule(dynamic) num_threads(8) reduction(+:bad)
+        for (int i = 0; i < num_pairs; ++i) {
+            const int a = i / 4, b = (i % 4) + ((i % 4) >= a ? 1 : 0);
+            sfm::Matching::Result r1, r2;
+            ref->pairwise_match(a, b, &r1);
+            multi->pairwise_match(a, b, &r2);
+            if (r1.matches_1_2 != r2.matches_1_2 || r1.matches_2_1 != r2.matches_2_1) bad++;
+            if (ref->pairwise_match_lowres(a, b, 500) != multi->pairwise_match_lowres(a, b, 500)) bad++;
+        }
+        if (bad) { std::fprintf(stderr, "MISMATCH: %d calls on %d logical devices differ from sfm::ExhaustiveMatching\n", bad, nd); return 1; }
+        std::printf("adapter_check ok: %d pairs on %d logical devices identical to sfm::ExhaustiveMatching\n", num_pairs, nd);
+    }
+
     bool threw = false;
     try { hip->init(nullptr); } catch (std::invalid_argument const&) { threw = true; }
     if (!threw) { std::fprintf(stderr, "init(nullptr) did not throw\n"); return 1; }

@@ -2,12 +2,15 @@
 // Host orchestration only: every inner product, reduction, ratio test,
 // cross-check and compaction runs in the kernels of match_kernels.hip.
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <queue>
+#include <thread>
 #include <vector>
 
 #include "match_kernels.h"
@@ -138,6 +141,14 @@ struct osfm_matcher {
         int32_t n12 = 0, n21 = 0;
     };
     std::vector<Staging *> comb_staging;      // guarded by comb_mu; blocks live as long as the matcher
+
+    // Multi-device front (osfm_match_create_multi): no device state of its own, one complete
+    // matcher per entry of device_ids (the same device may appear more than once: logical
+    // shards).  Every view goes to every shard; osfm_match_all deals its pairs over them.
+    std::vector<osfm_matcher *> shards;
+    std::vector<Staging> shard_stage;         // page-locked list buffer per shard (grow-only)
+    std::atomic<unsigned> next_shard{0};      // per-pair entries: round robin
+    std::mutex multi_mu;                      // one osfm_match_all at a time on the front
     std::mutex comb_mu;
     std::condition_variable comb_cv;
     std::deque<PairRequest *> comb_queue;
@@ -611,6 +622,163 @@ void reset_stats(osfm_matcher *m) { memset(&m->stats, 0, sizeof(m->stats)); }
 
 }  // namespace
 
+// ---------------------------------------------------------------------------
+// Multi-device front.  The reference's caller is ONE C++ process
+// (bundler::Matching::compute, bundler_matching.cc:58-136), so the sharding over the GPUs of
+// a node has to live behind the C ABI: one worker thread per shard for the duration of a
+// call, every shard a complete single-device matcher holding the full descriptor bank, the
+// pairs of osfm_match_all dealt by work (N1 * N2, longest first, to the least loaded shard:
+// the rule of orthosfm_amd/distributed.py::deal_pairs), no data-path exchange between
+// devices.  Each shard leaves its lists in its own page-locked block; once every count is
+// known the offsets follow in pair order and the shard threads copy their lists to their
+// places in the caller's buffer -- records and bytes are those of a single-device call.
+// ---------------------------------------------------------------------------
+namespace {
+
+template <class F>
+int for_each_shard(osfm_matcher *m, F &&fn)
+{
+    const size_t n = m->shards.size();
+    std::vector<int> st(n, OSFM_OK);
+    std::vector<std::string> msg(n);
+    auto run = [&](size_t k) {
+        st[k] = fn(k);
+        if (st[k] != OSFM_OK) msg[k] = osfm_last_error();      // the error text is per thread
+    };
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < n; ++k) th.emplace_back(run, k);
+    run(0);
+    for (auto &t : th) t.join();
+    // a failure is reported once: the first failing shard's status and text
+    for (size_t k = 0; k < n; ++k)
+        if (st[k] != OSFM_OK) {
+            set_error("device %d (shard %zu of %zu): %s", m->shards[k]->device, k, n, msg[k].c_str());
+            return st[k];
+        }
+    return OSFM_OK;
+}
+
+// Longest processing time first on N1 * N2 (known up front); ties go to the lower shard.
+// Equal work everywhere degenerates to round robin, as in distributed.py.
+void deal_pairs_lpt(const osfm_matcher *m, const osfm_pair *pairs, int num_pairs, std::vector<std::vector<int>> *owner)
+{
+    const int n = (int)m->shards.size();
+    owner->assign(n, {});
+    const auto &views = m->shards[0]->views;
+    std::vector<int64_t> w(num_pairs);
+    bool uniform = true;
+    for (int p = 0; p < num_pairs; ++p) {
+        const ViewData &a = views[pairs[p].view_1], &b = views[pairs[p].view_2];
+        w[p] = (int64_t)(a.ns + a.nu) * (int64_t)(b.ns + b.nu);
+        uniform &= w[p] == w[0];
+    }
+    if (uniform) {
+        for (int p = 0; p < num_pairs; ++p) (*owner)[p % n].push_back(p);
+        return;
+    }
+    std::vector<int> order(num_pairs);
+    for (int p = 0; p < num_pairs; ++p) order[p] = p;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return w[x] > w[y]; });
+    typedef std::pair<int64_t, int> Load;
+    std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+    for (int k = 0; k < n; ++k) heap.push({0, k});
+    std::vector<int> own(num_pairs);
+    for (int p : order) {
+        Load l = heap.top(); heap.pop();
+        own[p] = l.second;
+        heap.push({l.first + w[p], l.second});
+    }
+    for (int p = 0; p < num_pairs; ++p) (*owner)[own[p]].push_back(p);      // ascending inside a shard
+}
+
+int multi_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_pair_result *results,
+    int32_t *corr, int64_t capacity, int64_t *total)
+{
+    std::lock_guard<std::mutex> lock(m->multi_mu);
+    const int n = (int)m->shards.size();
+    for (int p = 0; p < num_pairs; ++p) {
+        OSFM_RETURN_IF(check_view(m->shards[0], pairs[p].view_1, "match_all"));
+        OSFM_RETURN_IF(check_view(m->shards[0], pairs[p].view_2, "match_all"));
+    }
+    std::vector<std::vector<int>> owner;
+    deal_pairs_lpt(m, pairs, num_pairs, &owner);
+    std::vector<std::vector<osfm_pair>> sub_pairs(n);
+    std::vector<std::vector<osfm_pair_result>> sub_res(n);
+    std::vector<int64_t> sub_total(n, 0), sub_cap(n, 0);
+    std::vector<int> sub_status(n, OSFM_OK);
+    const auto &views = m->shards[0]->views;
+    for (int k = 0; k < n; ++k) {
+        int64_t bound = 0;      // a pair has at most min(features of either view) mutual matches
+        for (int p : owner[k]) {
+            sub_pairs[k].push_back(pairs[p]);
+            const ViewData &a = views[pairs[p].view_1], &b = views[pairs[p].view_2];
+            bound += std::min(a.ns + a.nu, b.ns + b.nu);
+        }
+        sub_res[k].resize(owner[k].size());
+        sub_cap[k] = std::min(bound, capacity);
+    }
+    int st = for_each_shard(m, [&](size_t k) -> int {
+        osfm_matcher::Staging &sg = m->shard_stage[k];
+        const size_t need = (size_t)std::max<int64_t>(sub_cap[k], 1) * 2;
+        if (sg.ints < need) {
+            if (sg.ptr) (void)hipHostFree(sg.ptr);
+            sg.ptr = nullptr; sg.ints = 0;
+            OSFM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&sg.ptr), (need + need / 8) * 4, hipHostMallocPortable));
+            sg.ints = need + need / 8;
+        }
+        const int r = osfm_match_all(m->shards[k], sub_pairs[k].data(), (int)sub_pairs[k].size(), sub_res[k].data(),
+            sg.ptr, sub_cap[k], &sub_total[k]);
+        // a shard that runs out of room has still classified and counted every pair
+        sub_status[k] = r;
+        return r == OSFM_E_CAPACITY ? OSFM_OK : r;
+    });
+    if (st != OSFM_OK) return st;
+    const bool verify = m->opts.geometric_verification != 0;
+    int64_t run = 0;
+    std::vector<int64_t> goff(num_pairs, 0);
+    {
+        std::vector<size_t> pos(n, 0);
+        std::vector<int> own(num_pairs, 0);
+        for (int k = 0; k < n; ++k) for (int p : owner[k]) own[p] = k;
+        for (int p = 0; p < num_pairs; ++p) {
+            const int k = own[p];
+            results[p] = sub_res[k][pos[k]++];
+            const int64_t local = results[p].offset;
+            results[p].offset = 0;
+            if (results[p].status == OSFM_PAIR_MATCHED) {
+                results[p].offset = run;
+                goff[p] = local;
+                run += verify ? results[p].num_inliers : results[p].num_matches;
+            }
+        }
+    }
+    bool overflow = run > capacity;
+    for (int k = 0; k < n; ++k) overflow |= sub_status[k] == OSFM_E_CAPACITY;
+    if (total) {
+        // on overflow every shard reports what it needs: the required total
+        int64_t need = 0;
+        for (int k = 0; k < n; ++k) need += sub_total[k];
+        *total = overflow ? need : run;
+    }
+    if (overflow) {
+        set_error("match_all: %lld correspondences need more than the given capacity %lld",
+            (long long)(total ? *total : run), (long long)capacity);
+        return OSFM_E_CAPACITY;
+    }
+    // every shard copies its own lists to their places (pair order) in the caller's buffer
+    return for_each_shard(m, [&](size_t k) -> int {
+        const int32_t *src = m->shard_stage[k].ptr;
+        for (int p : owner[k]) {
+            if (results[p].status != OSFM_PAIR_MATCHED) continue;
+            const int64_t cnt = verify ? results[p].num_inliers : results[p].num_matches;
+            if (cnt > 0) memcpy(corr + 2 * results[p].offset, src + 2 * goff[p], (size_t)cnt * 8);
+        }
+        return OSFM_OK;
+    });
+}
+
+}  // namespace
+
 extern "C" {
 
 const char *osfm_last_error(void) { return g_last_error.c_str(); }
@@ -733,9 +901,45 @@ int osfm_match_create(int device, int num_views, const osfm_match_options *opts,
     return OSFM_OK;
 }
 
+int osfm_match_create_multi(const int *device_ids, int num_devices, int num_views,
+    const osfm_match_options *opts, osfm_matcher **out)
+{
+    if (!out || !device_ids || num_devices < 1 || num_views < 0) { set_error("match_create_multi: bad arguments"); return OSFM_E_ARG; }
+    *out = nullptr;
+    struct Owner { osfm_matcher *p; ~Owner() { if (p) osfm_match_destroy(p); } } owner{new osfm_matcher()};
+    osfm_matcher *m = owner.p;
+    m->device = device_ids[0];
+    if (opts) m->opts = *opts; else osfm_match_options_default(&m->opts);
+    reset_stats(m);
+    for (int k = 0; k < num_devices; ++k) {
+        osfm_matcher *sh = nullptr;
+        OSFM_RETURN_IF(osfm_match_create(device_ids[k], num_views, &m->opts, &sh));
+        m->shards.push_back(sh);
+    }
+    m->shard_stage.resize(num_devices);
+    owner.p = nullptr;
+    *out = m;
+    return OSFM_OK;
+}
+
+int osfm_match_get_devices(const osfm_matcher *m, int32_t *device_ids, int capacity, int32_t *num_devices)
+{
+    if (!m || !num_devices || capacity < 0 || (capacity > 0 && !device_ids)) { set_error("match_get_devices: bad arguments"); return OSFM_E_ARG; }
+    const int n = m->shards.empty() ? 1 : (int)m->shards.size();
+    *num_devices = n;
+    for (int k = 0; k < std::min(n, capacity); ++k) device_ids[k] = m->shards.empty() ? m->device : m->shards[k]->device;
+    return OSFM_OK;
+}
+
 int osfm_match_destroy(osfm_matcher *m)
 {
     if (!m) return OSFM_OK;
+    if (!m->shards.empty() || !m->shard_stage.empty()) {
+        for (auto *sh : m->shards) osfm_match_destroy(sh);
+        for (auto &sg : m->shard_stage) if (sg.ptr) (void)hipHostFree(sg.ptr);
+        delete m;
+        return OSFM_OK;
+    }
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     for (int i = 0; i < 2; ++i)
@@ -781,6 +985,8 @@ int osfm_match_set_view(osfm_matcher *m, int view, const uint16_t *sift, int n_s
     const int16_t *surf, int n_surf)
 {
     if (!m) { set_error("set_view: null matcher"); return OSFM_E_ARG; }
+    if (!m->shards.empty())        // every shard holds the full bank: one host-to-device copy per device, side by side
+        return for_each_shard(m, [&](size_t k) { return osfm_match_set_view(m->shards[k], view, sift, n_sift, surf, n_surf); });
     std::lock_guard<std::mutex> lock(m->mu);
     OSFM_HIP_CHECK(hipSetDevice(m->device));
     return upload_view(m, view, sift, n_sift, surf, n_surf);
@@ -801,6 +1007,7 @@ int osfm_match_set_view_float(osfm_matcher *m, int view, const float *sift, int 
 int osfm_match_view_size(const osfm_matcher *m, int view, int *n_sift, int *n_surf)
 {
     if (!m) { set_error("view_size: null matcher"); return OSFM_E_ARG; }
+    if (!m->shards.empty()) return osfm_match_view_size(m->shards[0], view, n_sift, n_surf);
     OSFM_RETURN_IF(check_view(m, view, "view_size"));
     if (n_sift) *n_sift = m->views[view].ns;
     if (n_surf) *n_surf = m->views[view].nu;
@@ -810,6 +1017,8 @@ int osfm_match_view_size(const osfm_matcher *m, int view, int *n_sift, int *n_su
 int osfm_match_set_positions(osfm_matcher *m, int view, const float *xy, int n)
 {
     if (!m || n < 0 || (n > 0 && !xy)) { set_error("set_positions: bad argument"); return OSFM_E_ARG; }
+    if (!m->shards.empty())
+        return for_each_shard(m, [&](size_t k) { return osfm_match_set_positions(m->shards[k], view, xy, n); });
     std::lock_guard<std::mutex> lock(m->mu);
     OSFM_HIP_CHECK(hipSetDevice(m->device));
     OSFM_RETURN_IF(check_view(m, view, "set_positions"));
@@ -986,6 +1195,8 @@ int osfm_match_pair(osfm_matcher *m, int view_1, int view_2, int32_t *m12, int32
     int32_t *m21, int32_t *len21)
 {
     if (!m || !m12 || !m21) { set_error("match_pair: null argument"); return OSFM_E_ARG; }
+    if (!m->shards.empty())        // concurrent callers spread over the devices; each shard combines its own arrivals
+        return osfm_match_pair(m->shards[m->next_shard++ % m->shards.size()], view_1, view_2, m12, len12, m21, len21);
     // a bad view id fails its own call, not the batch it would have joined
     OSFM_RETURN_IF(check_view(m, view_1, "match"));
     OSFM_RETURN_IF(check_view(m, view_2, "match"));
@@ -998,6 +1209,8 @@ int osfm_match_pair(osfm_matcher *m, int view_1, int view_2, int32_t *m12, int32
 int osfm_match_pair_lowres(osfm_matcher *m, int view_1, int view_2, int num_features, int32_t *count)
 {
     if (!m || !count) { set_error("match_pair_lowres: null argument"); return OSFM_E_ARG; }
+    if (!m->shards.empty())
+        return osfm_match_pair_lowres(m->shards[m->next_shard++ % m->shards.size()], view_1, view_2, num_features, count);
     if (num_features <= 0) { *count = 0; return OSFM_OK; }
     OSFM_RETURN_IF(check_view(m, view_1, "match"));
     OSFM_RETURN_IF(check_view(m, view_2, "match"));
@@ -1014,6 +1227,7 @@ int osfm_match_twoway(osfm_matcher *m, int view_1, int view_2, int descriptor_ty
         set_error("match_twoway: bad argument");
         return OSFM_E_ARG;
     }
+    if (!m->shards.empty()) return osfm_match_twoway(m->shards[0], view_1, view_2, descriptor_type, num_features, m12, m21);
     std::lock_guard<std::mutex> lock(m->mu);
     OSFM_HIP_CHECK(hipSetDevice(m->device));
     reset_stats(m);
@@ -1053,6 +1267,7 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
         set_error("match_all: bad arguments");
         return OSFM_E_ARG;
     }
+    if (!m->shards.empty()) return multi_match_all(m, pairs, num_pairs, results, corr, capacity, total);
     std::lock_guard<std::mutex> lock(m->mu);
     OSFM_HIP_CHECK(hipSetDevice(m->device));
     reset_stats(m);
@@ -1256,6 +1471,7 @@ int osfm_match_get_cascade_hashes(osfm_matcher *m, int view, int type, uint64_t 
     uint8_t *bucket_ids)
 {
     if (!m || type < 0 || type > 1) { set_error("get_cascade_hashes: bad arguments"); return OSFM_E_ARG; }
+    if (!m->shards.empty()) return osfm_match_get_cascade_hashes(m->shards[0], view, type, hashes, bucket_ids);
     std::lock_guard<std::mutex> lock(m->mu);
     OSFM_RETURN_IF(check_view(m, view, "get_cascade_hashes"));
     OSFM_HIP_CHECK(hipSetDevice(m->device));
@@ -1273,6 +1489,20 @@ int osfm_match_get_cascade_hashes(osfm_matcher *m, int view, int type, uint64_t 
 int osfm_match_get_stats(const osfm_matcher *m, osfm_match_stats *out)
 {
     if (!m || !out) { set_error("get_stats: null argument"); return OSFM_E_ARG; }
+    if (!m->shards.empty()) {
+        // sums over the shards' most recent calls (times are device times: they ran side by side)
+        memset(out, 0, sizeof(*out));
+        for (const auto *sh : m->shards) {
+            const osfm_match_stats &t = sh->stats;
+            out->tile_kernel_ms += t.tile_kernel_ms; out->tile_kernel_launches += t.tile_kernel_launches;
+            out->exact_scan_queries += t.exact_scan_queries; out->mac_count += t.mac_count;
+            out->algorithmic_bytes += t.algorithmic_bytes; out->lowres_kernel_ms += t.lowres_kernel_ms;
+            out->lowres_kernel_launches += t.lowres_kernel_launches; out->lowres_mac_count += t.lowres_mac_count;
+            out->cashash_kernel_ms += t.cashash_kernel_ms; out->cashash_kernel_launches += t.cashash_kernel_launches;
+            out->special_kernel_launches += t.special_kernel_launches; out->special_kernel_ms += t.special_kernel_ms;
+        }
+        return OSFM_OK;
+    }
     *out = m->stats;
     return OSFM_OK;
 }

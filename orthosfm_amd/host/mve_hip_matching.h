@@ -32,7 +32,12 @@ public:
     /* matcher_type: OSFM_MATCHER_EXHAUSTIVE (sfm::ExhaustiveMatching) or
      * OSFM_MATCHER_CASCADE_HASHING (sfm::CascadeHashing, the application's default) */
     explicit HipMatching (int device = 0, int matcher_type = OSFM_MATCHER_EXHAUSTIVE)
-        : device(device), matcher_type(matcher_type), handle(nullptr) {}
+        : devices(1, device), matcher_type(matcher_type), handle(nullptr) {}
+    /* Several devices of the node behind the one matcher the single-process caller holds
+     * (osfm_match_create_multi): the OpenMP team of bundler::Matching::compute
+     * (bundler_matching.cc:86-88) is spread over them call by call. */
+    explicit HipMatching (std::vector<int> const& device_ids, int matcher_type = OSFM_MATCHER_EXHAUSTIVE)
+        : devices(device_ids), matcher_type(matcher_type), handle(nullptr) {}
     HipMatching (HipMatching const&) = delete;
     HipMatching& operator= (HipMatching const&) = delete;
 
@@ -59,7 +64,11 @@ public:
         o.surf_lowe_ratio = this->opts.surf_matching_opts.lowe_ratio_threshold;
         o.surf_distance_threshold = this->opts.surf_matching_opts.distance_threshold;
         o.matcher_type = this->matcher_type;
-        check(osfm_match_create(this->device, (int)viewports->size(), &o, &this->handle));
+        if (this->devices.size() == 1)
+            check(osfm_match_create(this->devices[0], (int)viewports->size(), &o, &this->handle));
+        else
+            check(osfm_match_create_multi(this->devices.data(), (int)this->devices.size(),
+                (int)viewports->size(), &o, &this->handle));
 
         std::vector<float> sift, surf;
         for (std::size_t v = 0; v < viewports->size(); ++v)
@@ -112,7 +121,7 @@ private:
             throw std::runtime_error(std::string("osfm: ") + osfm_last_error());
     }
 
-    int device;
+    std::vector<int> devices;
     int matcher_type;
     osfm_matcher* handle;
 };

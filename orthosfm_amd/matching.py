@@ -43,16 +43,29 @@ class HipExhaustiveMatching:
     """Drop-in for sfm::ExhaustiveMatching (src/mve/sfm/exhaustive_matching.h:26-66)
     backed by the gfx950 kernels."""
 
-    def __init__(self, num_views: int, device: int = 0, options: capi.MatchOptions | None = None,
+    def __init__(self, num_views: int, device=0, options: capi.MatchOptions | None = None,
                  copy_results: bool = True):
         """copy_results=False: the lists compute() returns are views into a buffer
         the matcher reuses -- valid until the next compute() (no second pass over
-        the results on the host)."""
+        the results on the host).  device: one device id, or a sequence of them
+        (osfm_match_create_multi: the bank on every device, the pairs of compute() dealt
+        over them by work; an id may repeat -- logical shards on one device)."""
         self.opts = options if options is not None else capi.default_match_options()
         self._copy_results = bool(copy_results)
         self._h = C.c_void_p()
-        capi.check(capi.lib.osfm_match_create(device, num_views, C.byref(self.opts), C.byref(self._h)))
+        if isinstance(device, (list, tuple, np.ndarray)):
+            ids = (C.c_int * len(device))(*[int(d) for d in device])
+            capi.check(capi.lib.osfm_match_create_multi(ids, len(device), num_views, C.byref(self.opts), C.byref(self._h)))
+        else:
+            capi.check(capi.lib.osfm_match_create(int(device), num_views, C.byref(self.opts), C.byref(self._h)))
         self.num_views = num_views
+
+    def devices(self):
+        """The device of every shard (osfm_match_get_devices)."""
+        ids = (C.c_int32 * 64)()
+        n = C.c_int32()
+        capi.check(capi.lib.osfm_match_get_devices(self._h, ids, 64, C.byref(n)))
+        return [int(ids[k]) for k in range(min(n.value, 64))]
 
     # --- MatchingBase::init ---------------------------------------------------
     def init(self, viewports):
@@ -124,22 +137,24 @@ class HipExhaustiveMatching:
         """osfm_match_all as it is: returns (records, corr) -- one record per input pair (status,
         lowres_matches, num_matches, num_inliers, offset: numpy fields of osfm_pair_result) and the
         (rows, 2) buffer all lists lie in, pair k at corr[offset : offset + count].  `pairs` may be
-        an (n, 2) int32 array; the marshalled form of the last pair list is kept, so a caller that
-        passes the same object again pays nothing for it."""
+        an (n, 2) int32 array; the marshalled form of the last pair list is kept and reused when
+        the CONTENT is the same (a list mutated in place is marshalled again).  The records are a
+        fresh array per call; as_objects() takes the pair list from the call it is given."""
         if pairs is None:
             pairs = [capi.pair_from_index(i) for i in range(self.num_views * (self.num_views - 1) // 2)]
+        flat = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
         cached = getattr(self, "_pairs_cache", None)
-        if cached is not None and cached[0] is pairs:
-            _, arr, flat, res = cached
+        if cached is not None and cached[1].shape == flat.shape and np.array_equal(cached[1], flat):
+            arr, flat = cached
         else:
-            n = len(pairs)
+            n = flat.shape[0]
             arr = (capi.Pair * max(n, 1))()
-            flat = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
+            flat = flat.copy()
             if n:
                 np.ctypeslib.as_array(C.cast(arr, C.POINTER(C.c_int32)), shape=(n, 2))[:] = flat
-            res = (capi.PairResult * max(n, 1))()
-            self._pairs_cache = (pairs, arr, flat, res)
+            self._pairs_cache = (arr, flat)
         n = flat.shape[0]
+        res = (capi.PairResult * max(n, 1))()
         if capacity is None:
             capacity = sum(min(sum(self.view_size(a)), sum(self.view_size(b))) for a, b in flat.tolist())
         # One result buffer per call, taken from a pool the matcher keeps (its pages
@@ -152,7 +167,7 @@ class HipExhaustiveMatching:
         corr = corr[:max(int(total.value), 0)].copy() if self._copy_results else corr
         # all lists of the call, concatenated in pair order (what the per-pair views point into)
         self.last_flat = corr[:max(int(total.value), 0)]
-        ra = np.frombuffer(res, dtype=_PAIR_RESULT_DTYPE, count=n)
+        ra = np.frombuffer(res, dtype=_PAIR_RESULT_DTYPE, count=n)      # keeps `res` alive; one per call
         self._last_pairs_flat = flat
         return ra, corr
 
@@ -163,9 +178,11 @@ class HipExhaustiveMatching:
         ra, corr = self.compute_arrays(pairs, capacity)
         return self.as_objects(ra, corr)
 
-    def as_objects(self, ra, corr):
-        """The TwoViewMatching list of what compute_arrays returned."""
-        flat = self._last_pairs_flat
+    def as_objects(self, ra, corr, pairs=None):
+        """The TwoViewMatching list of what compute_arrays returned (pairs: the list that call
+        was given; default: the most recent call's)."""
+        flat = self._last_pairs_flat if pairs is None else np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
+        assert flat.shape[0] == len(ra), "as_objects: records and pair list of different calls"
         n = flat.shape[0]
         empty = np.zeros((0, 2), np.int32)
         verify = bool(self.opts.geometric_verification)

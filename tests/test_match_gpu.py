@@ -252,6 +252,8 @@ def test_cpp_adapter_vs_reference_side_by_side():
     assert "adapter_check ok: 20 pairs identical to sfm::ExhaustiveMatching" in out.stdout
     assert "adapter_check ok: 20 pairs identical to sfm::CascadeHashing" in out.stdout
     assert "from 8 OpenMP threads identical to the serial calls" in out.stdout
+    assert "20 pairs on 2 logical devices identical to sfm::ExhaustiveMatching" in out.stdout
+    assert "20 pairs on 3 logical devices identical to sfm::ExhaustiveMatching" in out.stdout
 
 
 def test_special_rows_large_values(hm):
@@ -597,7 +599,14 @@ def test_matcher_handles_give_their_memory_back():
     for _ in range(6):
         cycle(HipCascadeHashing)
         cycle(HipExhaustiveMatching)
-    free1, _ = capi.device_memory(0)
+    # The driver hands freed blocks back with a delay now and then (seen once: 142 MB missing
+    # right after the last destroy, back a moment later); a leak stays, so read a few times.
+    import time
+    for attempt in range(5):
+        free1, _ = capi.device_memory(0)
+        if free0 - free1 < (8 << 20):
+            break
+        time.sleep(0.5)
     assert free0 - free1 < (8 << 20), (free0, free1)
 
 
@@ -648,3 +657,80 @@ def test_concurrent_pair_calls_are_combined(hm):
         s_low, s12, s21 = serial[(a, b)]
         assert low == s_low and np.array_equal(m12, s12) and np.array_equal(m21, s21), (a, b)
     m.close()
+
+
+def test_multi_device_matcher_logical_shards(hm):
+    """osfm_match_create_multi with device_ids = {0, 0} and {0, 0, 0} (logical shards on the one
+    device of the box): every view on every shard, the pairs of compute() dealt by work --
+    ragged deals: six views of 400..2600 features --, records and list bytes identical to the
+    single-device matcher, with and without RANSAC-F; capacity overflow reports the same
+    required total; a failing shard is reported once; the per-pair entries and twoway_match go
+    through the front as well."""
+    from orthosfm_amd import capi
+    sizes = [2600, 400, 1900, 800, 2200, 1300]
+    big = synth.make_image_set(6, 2600, n_surf=120, config_id=14)
+    sift = [big.sift[v][:sizes[v]] for v in range(6)]
+    pos = [big.pos[v][:sizes[v]] for v in range(6)]
+
+    def build(dev, verify):
+        o = capi.default_match_options()
+        o.geometric_verification = verify
+        o.pairs_per_batch = 4                       # several batches per shard
+        m = hm(6, device=dev, options=o)
+        for v in range(6):
+            m.set_view(v, sift[v], big.surf[v] if v % 2 == 0 else None)
+            npos = sizes[v] + (120 if v % 2 == 0 else 0)
+            xy = np.zeros((npos, 2), np.float32)
+            xy[:sizes[v]] = (pos[v] + 0.5 - np.array([big.width / 2, big.height / 2])) / max(big.width, big.height)
+            m.set_positions(v, xy)
+        return m
+
+    for verify in (0, 1):
+        single = build(0, verify)
+        ra1, corr1 = single.compute_arrays()
+        ra1, corr1 = ra1.copy(), corr1.copy()
+        assert int((ra1["status"] == capi.PAIR_MATCHED).sum()) >= 10
+        for dev in ([0, 0], [0, 0, 0]):
+            m = build(dev, verify)
+            assert m.devices() == dev
+            ra, corr = m.compute_arrays()
+            assert ra.tobytes() == ra1.tobytes(), (verify, dev)
+            assert corr.tobytes() == corr1.tobytes(), (verify, dev)
+            st = m.stats()
+            assert st.tile_kernel_launches >= len(dev)          # every shard worked
+            # an arbitrary pair list (a subset, out of order)
+            sub = [(4, 1), (2, 0), (5, 3), (3, 0)]
+            ra_s, corr_s = m.compute_arrays(sub)
+            ra_1, corr_1 = single.compute_arrays(sub)
+            assert ra_s.tobytes() == ra_1.tobytes() and corr_s.tobytes() == corr_1.tobytes()
+            # capacity: the same error and required total as on one device
+            need = corr1.shape[0]
+            for mm in (single, m):
+                with pytest.raises(capi.OsfmError) as e:
+                    mm.compute(capacity=need - 5)
+                assert e.value.status == capi.E_CAPACITY and str(need) in str(e.value), str(e.value)
+            # per-pair entries and the two-way seam through the front
+            a = m.pairwise_match(4, 2)
+            b = single.pairwise_match(4, 2)
+            assert np.array_equal(a.matches_1_2, b.matches_1_2) and np.array_equal(a.matches_2_1, b.matches_2_1)
+            assert m.pairwise_match_lowres(4, 2, 500) == single.pairwise_match_lowres(4, 2, 500)
+            t1, t2 = m.twoway_match(0, 2, 1), single.twoway_match(0, 2, 1)
+            assert np.array_equal(t1.matches_1_2, t2.matches_1_2) and np.array_equal(t1.matches_2_1, t2.matches_2_1)
+            # a failing shard is reported once, with its device
+            bad = sift[1].copy()
+            bad[0, 0] = 300
+            with pytest.raises(capi.OsfmError) as e:
+                m.set_view(1, bad)
+            assert e.value.status == capi.E_RANGE and str(e.value).count("outside the quantised range") == 1
+            assert "shard 0 of %d" % len(dev) in str(e.value)
+            with pytest.raises(capi.OsfmError) as e:
+                m.compute_arrays([(1, 0)])
+            assert e.value.status == capi.E_STATE                     # view 1 is unset on every shard now
+            m.set_view(1, sift[1])
+            m.set_positions(1, (pos[1] + 0.5 - np.array([big.width / 2, big.height / 2])) / max(big.width, big.height))
+            ra2, corr2 = m.compute_arrays()
+            assert ra2.tobytes() == ra1.tobytes() and corr2.tobytes() == corr1.tobytes()
+            m.close()
+        single.close()
+    with pytest.raises(capi.OsfmError):
+        hm(2, device=[0, 99])
