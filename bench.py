@@ -416,6 +416,30 @@ def realistic_operands_bench(iset, V, pairs, capacity, device_index, headline_ms
     return out
 
 
+def multi_device_front_bench(iset, V, pairs, capacity, device_index, ndev_visible, steps, ref_ra, ref_corr):
+    """osfm_match_create_multi from ONE process (what the reference's single C++ caller can use):
+    all visible devices when there are several, else two logical shards on the one device --
+    then the number says what the front costs (one more pass over the lists on the host), not
+    what a second GPU gains.  Records and list bytes are compared with the timed single-device pass."""
+    from orthosfm_amd import capi
+    from orthosfm_amd.matching import HipExhaustiveMatching
+    devs = list(range(ndev_visible)) if ndev_visible > 1 else [device_index, device_index]
+    m = HipExhaustiveMatching(V, device=devs, copy_results=False)
+    for v in range(V):
+        m.set_view(v, iset.sift[v])
+    m.use_result_buffer(capi.pinned_rows(capacity))
+    m.compute_arrays(pairs, capacity=capacity)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ra, corr = m.compute_arrays(pairs, capacity=capacity)
+    dt = (time.perf_counter() - t0) / steps
+    n = int(np.where(ra["status"] == capi.PAIR_MATCHED, ra["num_matches"], 0).sum())
+    same = ra.tobytes() == ref_ra.tobytes() and corr[:n].tobytes() == ref_corr[:n].tobytes()
+    m.close()
+    return {"devices": devs, "logical_shards_on_one_device": ndev_visible <= 1, "pairs_per_s": len(pairs) / dt,
+            "ms_per_step": dt * 1e3, "identical_to_single_device": bool(same)}
+
+
 def per_pair_latency(m, pairs, n=24):
     """The drop-in interface as the reference calls it: one MatchingBase::pairwise_match
     per pair (osfm_match_pair: launch, finish, cross-check, two device-to-host copies,
@@ -766,6 +790,14 @@ def main():
                                             "kind": "port", "sample": f"{len(ts)} pairs of the timed pass", "identical_inliers": bool(same)}
         m2.close()
 
+    multi_front = None
+    if extras and not args.no_realistic:
+        try:
+            multi_front = multi_device_front_bench(iset, V, my_pairs, capacity, device_index, ndev, max(args.steps, 3),
+                                                   last[0].copy(), np.array(last[1], copy=True))
+        except Exception as e:
+            multi_front = {"error": repr(e)}
+
     realistic = None
     if extras and not args.no_realistic:
         try:
@@ -888,6 +920,8 @@ def main():
             line["cascade_hashing"] = cascade
         if verified is not None:
             line["with_geometric_verification"] = verified
+        if multi_front is not None:
+            line["single_process_multi_device"] = multi_front
         if realistic is not None:
             line["realistic_operands"] = realistic
             if any(not c.get("parity_ok", True) for c in realistic.get("cases", [])):

@@ -48,6 +48,13 @@ OSFM_API int osfm_device_memory(int device, uint64_t *free_bytes, uint64_t *tota
  * hands what is cached on `device` (-1: all devices) back to the driver; *released_bytes
  * (may be NULL) reports how much that was. */
 OSFM_API int osfm_trim_device_memory(int device, uint64_t *released_bytes);
+/* Diagnostic: the one-launch Cholesky of osfm_ba_solve leaves 16 stamps per diagonal workgroup of
+ * its most recent factorisation: stamps[65][16], read by tools/chol_flow_trace.py (100 MHz
+ * counter: start, L of the last column published, factor started, inverse published; shader
+ * cycles of the pivot loop and of the factor; how the inverse arrived: 1 = sc1 copy, 2 =
+ * same-XCD mailbox).  enable != 0 switches the recording on
+ * (current device) and returns what was recorded so far; 0 returns it and switches it off. */
+OSFM_API int osfm_ba_debug_chol_trace(int enable, int64_t *stamps);
 
 /* Diagnostic of the RANSAC-F scoring loop.  Its Sampson tests are pre-classified in packed
  * single precision; a test only counts when the float result is out of reach of its error

@@ -165,6 +165,18 @@ int select_device(int device)
 
 extern "C" {
 
+int osfm_ba_debug_chol_trace(int enable, int64_t *stamps)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("ba_debug_chol_trace: no HIP device available"); return OSFM_E_DEVICE; }
+    OSFM_HIP_CHECK(hipDeviceSynchronize());
+    long long *buf = chol_flow_trace_buffer(1);
+    if (!buf) { set_error("ba_debug_chol_trace: no memory for the trace"); return OSFM_E_DEVICE; }
+    if (stamps) OSFM_HIP_CHECK(hipMemcpy(stamps, buf, 65 * 16 * 8, hipMemcpyDeviceToHost));
+    if (!enable) chol_flow_trace_buffer(0);
+    return OSFM_OK;
+}
+
 int osfm_ba_options_default(osfm_ba_options *o)
 {
     if (!o) { set_error("ba_options_default: null"); return OSFM_E_ARG; }
@@ -265,6 +277,14 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     OSFM_RETURN_IF(gmax_cam.alloc((size_t)std::max(C, 1) * 8));
     OSFM_RETURN_IF(scalars.alloc(16 * 8));
     OSFM_RETURN_IF(info.alloc(16));
+    DevArray flow_flags, flow_mailbox;        // hand-off flags of the one-launch Cholesky, zeroed once per solve
+    const bool use_flow = getenv("OSFM_BA_CHOLESKY_STEPS") == nullptr;
+    if (use_flow) {
+        OSFM_RETURN_IF(flow_flags.alloc((size_t)chol_flow_flag_count(std::max(nc, 1)) * 4));
+        OSFM_HIP_CHECK(hipMemsetAsync(flow_flags.ptr, 0, (size_t)chol_flow_flag_count(std::max(nc, 1)) * 4, s));
+        OSFM_RETURN_IF(flow_mailbox.alloc(chol_flow_mailbox_bytes(std::max(nc, 1))));
+    }
+    int flow_epoch = 0;
     OSFM_HIP_CHECK(hipMemsetAsync(gmax_cam.ptr, 0, (size_t)std::max(C, 1) * 8, s));
 
     PointPassArgs pa;
@@ -387,7 +407,8 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
         const int slot = it + 1;          // h_state[slot]: the state this iteration leaves
         OSFM_RETURN_IF(tic(2));
         if (small) launch_small_solve(S.as<double>(), nc, Ldiag.as<double>(), y_c.as<double>(), info.as<int>(), d, part_cam.as<double>(), s);
-        else if (nc > 0) launch_cholesky_solve(S.as<double>(), Lmat.as<double>(), nc, Ldiag.as<double>(), y_c.as<double>(), info.as<int>(), lm, s);
+        else if (nc > 0) launch_cholesky_solve(S.as<double>(), Lmat.as<double>(), nc, Ldiag.as<double>(), y_c.as<double>(), info.as<int>(), lm, s,
+            use_flow ? flow_flags.as<int>() : nullptr, ++flow_epoch, use_flow ? flow_mailbox.as<double>() : nullptr);
         OSFM_RETURN_IF(toc());
         OSFM_RETURN_IF(tic(3));
         if (!small) launch_cam_update(d, y_c.as<double>(), nullptr, part_cam.as<double>(), s);

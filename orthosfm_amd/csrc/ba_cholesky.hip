@@ -15,11 +15,14 @@
 //   chol_panel(k):  every workgroup factors A_kk redundantly (32^3/3 flops) and
 //                   solves A_ik <- A_ik L_kk^-T for 64 rows of the panel
 //   chol_update(k): A_ij -= L_ik L_jk^T for k < j <= i (incl. the rhs row)
+#include <algorithm>
+
 #include "ba_kernels.h"
 
 namespace osfm {
 
 constexpr int NB = 32;
+int cholesky_padded_dim(int n);
 
 __device__ __forceinline__ double readlane_d(double x, int l)
 {
@@ -38,6 +41,17 @@ __device__ __forceinline__ double rsqrt_newton(double d)
     double y = __builtin_amdgcn_rsq(d);
     y = fma(y, fma(-h * y, y, 0.5), y);
     y = fma(y, fma(-h * y, y, 0.5), y);
+    return y;
+}
+
+// 1 / d to double precision: v_rcp_f64 seed and two Newton steps (four dependent operations)
+__device__ __forceinline__ double rcp_newton(double d)
+{
+    double y = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
     return y;
 }
 
@@ -61,10 +75,32 @@ __device__ __forceinline__ double swap_halves(double v)
     return __hiloint2double(lane_hi ? (int)b[0] : (int)b[1], lane_hi ? (int)a[0] : (int)a[1]);
 }
 
+// Workgroup barrier that only orders LDS traffic.  __syncthreads() also drains the
+// vector-memory counter, which would expose the latency of every prefetch and of every
+// result store (2-3 us for a write-through store) once per step of a chain.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// store that another workgroup of the SAME launch may read (global_store ... sc1: write-through)
+__device__ __forceinline__ void store_sc1(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_sc1(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <bool SC1 = false>
 __device__ __forceinline__ void
 factor_diag_block(const double *Msrc, int lds_ld, double (*LsT)[NB], int kblock, double *Ldiag, int *info,
-    double *linv_lds = nullptr, int linv_ld = 0, int nvalid = NB)
+    double *linv_lds = nullptr, int linv_ld = 0, int nvalid = NB, bool ldiag_is_block = false, long long *dbg = nullptr)
 {
+    const long long dbg_t0 = dbg ? (long long)clock64() : 0;
     // nvalid: rows / columns from there on are identity padding (wave-uniform); their pivot
     // steps and inverse rows change nothing and are skipped -- the chain is serial, so a
     // 17-unknown system (three cameras) is done in half the time of a full block
@@ -80,6 +116,13 @@ factor_diag_block(const double *Msrc, int lds_ld, double (*LsT)[NB], int kblock,
 #pragma unroll
     for (int c = 0; c < NB; ++c) v[c] = h == 0 ? Msrc[r * lds_ld + c] : (c == r ? 1.0 : 0.0);
     int bad = 0;
+    // (Measured and not kept: the elimination in LDL^T form on unscaled columns -- the column goes
+    //  to LDS and lane j+1's entry comes by v_readlane before anything is computed from the pivot,
+    //  the link is d -> 1/d (v_rcp_f64 + two Newton steps) -> t -> fma -> v_readlane, the Cholesky
+    //  scale 1/sqrt(d) applied off the chain: 370 instead of 410 cycles per pivot, but the 32
+    //  square-root iterations pile up behind the loop and the block takes 15.5k cycles instead of
+    //  14.3k.  One wave issues in order: a pivot costs the SUM of its chain stalls, its ~15 trailing
+    //  FMAs and its LDS reads, not the longest of them.)
     // Pivot j: only column j + 1 has to be final before pivot j + 1 can start, so that
     // column takes its multiplier L[j+1][j] by v_readlane right away and the next pivot's
     // reciprocal square root (the longest link of the chain) is started at once; the other
@@ -115,6 +158,7 @@ factor_diag_block(const double *Msrc, int lds_ld, double (*LsT)[NB], int kblock,
             for (int c = j + 2; c < NB; ++c) v[c] = fma(-vj, col[c], v[c]);    // L: meaningful for r >= c
         }
     }
+    if (dbg && (threadIdx.x & 63) == 0) dbg[0] = (long long)clock64() - dbg_t0;
     if (bad && lane == 0) atomicMax(info, kblock * NB + bad);
     // L itself, transposed (LsT[c][i] = L[i][c], zero above the diagonal), for a caller that
     // wants to look at it: lane r writes element r of every row, consecutive addresses
@@ -123,9 +167,9 @@ factor_diag_block(const double *Msrc, int lds_ld, double (*LsT)[NB], int kblock,
         for (int c = 0; c < NB; ++c) LsT[c][r] = c <= r ? v[c] : 0.0;
     }
     if (h == 1) {
-        double *Lk = Ldiag + (size_t)kblock * NB * NB;                          // [i][j] = inv(L)[i][j]
+        double *Lk = Ldiag + (ldiag_is_block ? 0 : (size_t)kblock * NB * NB);   // [i][j] = inv(L)[i][j]
 #pragma unroll
-        for (int i = 0; i < NB; ++i) Lk[i * NB + r] = v[i];
+        for (int i = 0; i < NB; ++i) { if (SC1) store_sc1(&Lk[i * NB + r], v[i]); else Lk[i * NB + r] = v[i]; }
         // a copy in LDS for a caller that goes on to use it (Msrc itself may be the target:
         // the block was read into registers at the top)
         if (linv_lds) {
@@ -271,6 +315,373 @@ chol_step_kernel(double *A, double *Lout, int ld, int nblk, int k, double *Ldiag
     if (tid < 64) factor_diag_block(&Ai[0][0], NB + 1, nullptr, k + 1, Ldiag, info);
 }
 
+
+// ---------------------------------------------------------------------------
+// The whole factorisation (and the forward substitution of the right-hand side riding along)
+// as ONE launch of persistent workgroups that hand tiles to each other: the launch-per-
+// block-column form above spends 15.6 us per column of which 2.7 are the pivot chain.
+//
+// Every workgroup owns tiles of the lower triangle for the whole factorisation and keeps them
+// in registers (right-looking updates as the panels of earlier columns appear):
+//   D_r, r = 0 .. nblk: the last kFlowW + 1 tiles of block row r -- (r, r-kFlowW) .. (r, r) --,
+//        i.e. the diagonal tile and its left neighbours.  For a column k it owns it turns its
+//        tile into L_rk itself as soon as inv(L_kk) appears, applies it to its tiles right of k,
+//        and after the last column factors its diagonal tile and publishes inv(L_rr).
+//        D_nblk is the tail of the right-hand side row (no diagonal tile).
+//   P_(i,j), i - j > kFlowW (the right-hand side row i = nblk included): updates, then
+//        L_ij = tile * inv(L_jj)^T once that inverse appears.
+// Why the band: POTRF(j) -> TRSM(j+1, j) -> SYRK -> POTRF(j+1) is the critical path, and row
+// j+1 enters it with everything the columns before j did to it.  A tile handed from one
+// workgroup to another costs a round trip through memory (sc1 store, drain, flag, poll, sc1
+// load: ~5.5 us measured here, 2x the pivot chain of a block), so the hand-offs on that path
+// must be few and the others need slack: with the diagonal tile alone per workgroup the loop
+// inverse(j-1) -> P computes L(j+1, j-1) -> D_(j+1) updates paced the whole thing at 10 us per
+// column.  With the band, a P tile's result is needed kFlowW columns after the inverse it
+// waited for.
+// The D workgroups talk to each other through their XCD's L2 where they can: the blocks with
+// blockIdx % 8 == 0 are the D's (observed placement: round robin over the XCDs -- speed only),
+// every payload is published twice -- plain stores into a mailbox + a flag that carries the
+// producer's XCC id (s_getreg HW_REG_XCC_ID), then sc1 stores into its place in the factor + a
+// second flag --, and a D reads the mailbox only when the flag says the producer sits on its
+// own XCD (one L2: the plain stores are there once their vmcnt has drained; the reads bypass
+// L1).  Everybody else, and a D on another XCD, takes the sc1 copy as MI355X_MICROARCH.md
+// ("Valid forms") prescribes: every byte stored sc1 and loaded sc1, each storing wave drains
+// its stores before one lane stores the flag behind a workgroup barrier, one lane polls, the
+// others load behind the barrier it joins.  Flags hold the launch's epoch (no reset between
+// factorisations).  All workgroups must be resident (checked against the occupancy query,
+// else the launch-per-column form runs); a poll that outlasts kFlowSpinLimit raises the abort
+// word, which every poll loop watches, and the factorisation is reported as failed (info)
+// instead of hanging the device.
+// ---------------------------------------------------------------------------
+constexpr int kFlowSpinLimit = 1 << 21;
+constexpr int kFlowW = 3;                 // left neighbours of the diagonal tile a D workgroup owns
+
+struct CholFlow {
+    const double *A;      // (N + 32) x N reduced system, rhs in row N
+    double *Lmat;         // factor + solved rhs (same layout)
+    double *Ldiag;        // inv(L_kk), 32 x 32 each
+    double *mailbox;      // [(nblk + 1)][kFlowW + 1][32 x 32]: slot 0 inv(L_rr), slot d = L(r, r - d); same-XCD copies
+    int *flags;           // see flow_*_flag
+    int *info;
+    const LmDev *lm;
+    int ld, nblk, epoch;
+    long long *trace;     // diagnostics (tools/chol_flow_trace.py): [nblk + 1][16] wall_clock64 stamps of the D's, or null
+};
+
+// flag words: sc1 copy of tile (i, k) final | sc1 copy of inverse k | mailbox copies (r, slot) | abort
+__device__ __forceinline__ int flow_tile_flag(const CholFlow &f, int i, int k) { return i * f.nblk + k; }
+__device__ __forceinline__ int flow_inv_flag(const CholFlow &f, int k) { return (f.nblk + 1) * f.nblk + k; }
+__device__ __forceinline__ int flow_box_flag(const CholFlow &f, int r, int slot) { return (f.nblk + 2) * f.nblk + r * (kFlowW + 1) + slot; }
+__device__ __forceinline__ int flow_abort_flag(const CholFlow &f) { return (f.nblk + 2) * f.nblk + (f.nblk + 1) * (kFlowW + 1); }
+__device__ __forceinline__ double *flow_box(const CholFlow &f, int r, int slot) { return f.mailbox + ((size_t)r * (kFlowW + 1) + slot) * NB * NB; }
+__device__ __forceinline__ int flow_xcc() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15; }
+
+// plain store / flag for a reader behind the same L2 (no cache-policy bits)
+__device__ __forceinline__ void store_flag_plain(int *p, int v)
+{
+    asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory");
+}
+
+struct FlowWaiter {
+    int *lds_word;        // verdict: 0 aborted, 1 sc1 copy, 2 mailbox copy
+    int pending_flag;     // sc1 flag to store once this workgroup's sc1 stores have drained (-1: none)
+};
+
+// Waits until the payload behind (slow_flag) or -- D to D only -- (box_flag) is published.
+// One lane polls; every thread drains its own stores first (a pending sc1 publication of this
+// workgroup becomes visible here, for free: the waves would idle at the barrier anyway).
+__device__ __forceinline__ int flow_wait(const CholFlow &f, FlowWaiter &w, int slow_flag, int box_flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (w.pending_flag >= 0) {
+        lds_barrier();
+        if (threadIdx.x == 0) __hip_atomic_store(f.flags + w.pending_flag, f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w.pending_flag = -1;
+    }
+    if (threadIdx.x == 0) {
+        int verdict = 0;
+        const int *ps = f.flags + slow_flag, *pb = f.flags + (box_flag >= 0 ? box_flag : slow_flag), *pab = f.flags + flow_abort_flag(f);
+        const int want_box = f.epoch | ((flow_xcc() + 1) << 24);
+        for (int spins = 0;; ++spins) {
+            if (box_flag >= 0 && __hip_atomic_load(pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want_box) { verdict = 2; break; }
+            if (__hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f.epoch) { verdict = 1; break; }
+            if ((spins & 15) == 15 && __hip_atomic_load(pab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f.epoch) break;
+            if (spins > kFlowSpinLimit) {
+                __hip_atomic_store(f.flags + flow_abort_flag(f), f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!verdict) atomicMax(f.info, 1 << 20);      // reported as a failed factorisation
+        *w.lds_word = verdict;
+    }
+    lds_barrier();
+    return *w.lds_word;
+}
+
+// Thread <-> tile element map of the flow kernel: the accumulator layout of
+// v_mfma_f64_16x16x4_f64 (cdna_hip_programming.md: col = lane & 15, row = (lane >> 4) + 4 * reg),
+// wave w holding the 16 x 16 quadrant (w >> 1, w & 1) of the 32 x 32 tile: element e of a thread
+// is (tr0 + 4 e, tc).
+typedef double v4d __attribute__((ext_vector_type(4)));
+struct FlowPos { int tr0, tc, ar, ak; };    // ar / ak: row inside a quadrant and k offset of the MFMA A / B operand
+__device__ __forceinline__ FlowPos flow_pos()
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    FlowPos p;
+    p.tr0 = 16 * (wave >> 1) + (lane >> 4);
+    p.tc = 16 * (wave & 1) + (lane & 15);
+    p.ar = lane & 15; p.ak = lane >> 4;
+    return p;
+}
+
+// a published 32 x 32 tile (row-major, leading dimension ld) into LDS; sc1 loads (L1 bypass)
+__device__ __forceinline__ void flow_load_tile(const double *G, int ld, double (*dst)[NB + 1], const FlowPos &p)
+{
+    double v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = load_sc1(G + (size_t)(p.tr0 + 4 * e) * ld + p.tc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dst[p.tr0 + 4 * e][p.tc] = v[e];
+}
+
+// acc (+/-)= X Y^T on the matrix cores: D[i][j] += sum_m X[i][m] Y[j][m], eight k-steps of four.
+// A operand: lane holds X[16 qi + (lane & 15)][4 s + (lane >> 4)], B operand Y[16 qj + (lane & 15)][same k].
+// (As 128 vector FMAs per thread fed from LDS this took 2.6 us per tile, on the critical path twice
+//  per block column.)
+template <bool NEG>
+__device__ __forceinline__ void flow_mma(double (&acc)[4], const double (*X)[NB + 1], const double (*Y)[NB + 1], const FlowPos &p)
+{
+    const int wave = threadIdx.x >> 6;
+    const int xi = 16 * (wave >> 1) + p.ar, yj = 16 * (wave & 1) + p.ar;
+    double a[8], bq[8];
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) { a[s8] = X[xi][4 * s8 + p.ak]; bq[s8] = Y[yj][4 * s8 + p.ak]; }
+    v4d c = {acc[0], acc[1], acc[2], acc[3]};
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) c = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -a[s8] : a[s8], bq[s8], c, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = c[e];
+}
+
+__global__ __launch_bounds__(256, 3) void       // three workgroups per CU: the whole grid has to be resident
+chol_flow_kernel(CholFlow f)
+{
+    if (f.lm && (f.lm->stop || f.lm->lin_failed)) return;
+    __shared__ __attribute__((aligned(16))) double Xr[NB][NB + 1];
+    __shared__ __attribute__((aligned(16))) double Xc[NB][NB + 1];
+    __shared__ __attribute__((aligned(16))) double Li[NB][NB + 1];
+    __shared__ __attribute__((aligned(16))) double Mt[NB][NB + 1];
+    __shared__ int lds_word;
+    const int nblk = f.nblk, ld = f.ld;
+    const int tid = threadIdx.x;
+    const FlowPos p = flow_pos();
+    FlowWaiter w;
+    w.lds_word = &lds_word; w.pending_flag = -1;
+
+    // workgroup -> role: blocks 0, 8, 16, ... are D_0, D_1, ... (one XCD under round-robin placement);
+    // the others take the P tiles, column by column
+    const int b = blockIdx.x;
+    const bool is_d = (b & 7) == 0 && (b >> 3) <= nblk;
+    if (!is_d) {
+        // ---- P_(i,j), i - j > kFlowW -------------------------------------------------
+        int idx = b - min((b + 7) >> 3, nblk + 1);          // P index: blocks below b that are not D's
+        int j = 0;
+        // column j holds rows j + kFlowW + 1 .. nblk: nblk - j - kFlowW tiles
+        while (j < nblk && idx >= nblk - j - kFlowW) { idx -= max(nblk - j - kFlowW, 0); ++j; }
+        if (j >= nblk || nblk - j - kFlowW <= 0) return;    // surplus block of the grid
+        const int i = j + kFlowW + 1 + idx;
+        double acc[4];
+        const double *Aij = f.A + (size_t)(i * NB) * ld + j * NB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = Aij[(size_t)(p.tr0 + 4 * e) * ld + p.tc];
+        for (int k = 0; k < j; ++k) {
+            if (!flow_wait(f, w, flow_tile_flag(f, i, k), -1)) return;
+            flow_load_tile(f.Lmat + (size_t)(i * NB) * ld + k * NB, ld, Xr, p);
+            if (!flow_wait(f, w, flow_tile_flag(f, j, k), -1)) return;
+            flow_load_tile(f.Lmat + (size_t)(j * NB) * ld + k * NB, ld, Xc, p);
+            lds_barrier();
+            flow_mma<true>(acc, Xr, Xc, p);
+        }
+        if (!flow_wait(f, w, flow_inv_flag(f, j), -1)) return;
+        flow_load_tile(f.Ldiag + (size_t)j * NB * NB, NB, Li, p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Mt[p.tr0 + 4 * e][p.tc] = acc[e];
+        lds_barrier();
+        // L_ij = tile * inv(L_jj)^T (inv(L) is lower triangular: zeros above the diagonal)
+        double x[4] = {0, 0, 0, 0};
+        flow_mma<false>(x, Mt, Li, p);
+        double *Lij = f.Lmat + (size_t)(i * NB) * ld + j * NB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) store_sc1(Lij + (size_t)(p.tr0 + 4 * e) * ld + p.tc, x[e]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(f.flags + flow_tile_flag(f, i, j), f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+
+    // ---- D_row ---------------------------------------------------------------------------
+    const int row = b >> 3;
+    const bool has_diag = row < nblk;
+    const int lo = max(0, row - kFlowW), hi = min(row, nblk - 1);     // own columns
+    const int my_tag = f.epoch | ((flow_xcc() + 1) << 24);
+    auto stamp = [&](int slot) { if (f.trace && tid == 0) f.trace[row * 16 + slot] = (long long)wall_clock64(); };
+    stamp(0);
+    // (A warm-up pass of the factor on an identity block -- one copy of the code, run twice -- was
+    //  measured and dropped: the instruction fetches are not what the factor waits for, 12k of its
+    //  14k cycles are the pivot loop itself warm or cold, and the loop form cost registers: 256
+    //  VGPRs + scratch, two workgroups per CU instead of three.)
+    double acc[kFlowW + 1][4];
+#pragma unroll
+    for (int t = 0; t <= kFlowW; ++t) {
+        const int c = lo + t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = 0.0;
+        if (c <= hi) {
+            const double *At = f.A + (size_t)(row * NB) * ld + c * NB;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][e] = At[(size_t)(p.tr0 + 4 * e) * ld + p.tc];
+        }
+    }
+    for (int k = 0; k < row; ++k) {
+        // ---- L(row, k) into Xr ----
+        if (k < lo) {
+            if (!flow_wait(f, w, flow_tile_flag(f, row, k), -1)) return;
+            flow_load_tile(f.Lmat + (size_t)(row * NB) * ld + k * NB, ld, Xr, p);
+        } else {
+            const int how = flow_wait(f, w, flow_inv_flag(f, k), flow_box_flag(f, k, 0));
+            if (!how) return;
+            if (k == row - 1 && f.trace && tid == 0) f.trace[row * 16 + 7] = how;
+            flow_load_tile(how == 2 ? flow_box(f, k, 0) : f.Ldiag + (size_t)k * NB * NB, NB, Li, p);
+            // own tile of column k (register index is compile-time under the unrolled select)
+            double t4[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t <= kFlowW; ++t)
+                if (lo + t == k) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t4[e] = acc[t][e];
+                }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Mt[p.tr0 + 4 * e][p.tc] = t4[e];
+            lds_barrier();
+            double x[4] = {0, 0, 0, 0};
+            flow_mma<false>(x, Mt, Li, p);
+            // publish: mailbox (same-XCD D's), then the sc1 copy in the factor (flag at the next wait)
+            double *box = flow_box(f, row, row - k);
+            double *Lrk = f.Lmat + (size_t)(row * NB) * ld + k * NB;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { Xr[p.tr0 + 4 * e][p.tc] = x[e]; box[(p.tr0 + 4 * e) * NB + p.tc] = x[e]; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            if (tid == 0) store_flag_plain(f.flags + flow_box_flag(f, row, row - k), my_tag);
+            if (k == row - 1) stamp(3);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) store_sc1(Lrk + (size_t)(p.tr0 + 4 * e) * ld + p.tc, x[e]);
+            w.pending_flag = flow_tile_flag(f, row, k);
+        }
+        // ---- apply column k to the own tiles right of it ----
+        for (int c = max(k + 1, lo); c <= hi; ++c) {
+            if (c == row) {
+                lds_barrier();
+            } else {
+                // L(c, k): a D's if c - k <= kFlowW, else a P tile
+                const bool from_d = c - k <= kFlowW;
+                const int how = flow_wait(f, w, flow_tile_flag(f, c, k), from_d ? flow_box_flag(f, c, c - k) : -1);
+                if (!how) return;
+                if (how == 2) flow_load_tile(flow_box(f, c, c - k), NB, Xc, p);
+                else flow_load_tile(f.Lmat + (size_t)(c * NB) * ld + k * NB, ld, Xc, p);
+                lds_barrier();
+            }
+#pragma unroll
+            for (int t = 0; t <= kFlowW; ++t)
+                if (lo + t == c) flow_mma<true>(acc[t], Xr, c == row ? Xr : Xc, p);
+        }
+        if (k == row - 1) stamp(9);
+    }
+    if (has_diag) {
+        // the own-tile branch above ends on a barrier-free update: order it before Mt is rewritten
+        lds_barrier();
+#pragma unroll
+        for (int t = 0; t <= kFlowW; ++t)
+            if (lo + t == row) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Mt[p.tr0 + 4 * e][p.tc] = acc[t][e];
+            }
+        lds_barrier();
+        stamp(4);
+        const long long c_start = (long long)clock64();
+        if (tid < 64) {
+            // the critical path: the factor, then its inverse to the mailbox (D_(row+1) is polling)
+            factor_diag_block<false>(&Mt[0][0], NB + 1, nullptr, row, flow_box(f, row, 0), f.info, &Li[0][0], NB + 1, NB, true,
+                f.trace ? f.trace + row * 16 + 1 : nullptr);
+            if (f.trace && tid == 0) f.trace[row * 16 + 2] = (long long)clock64() - c_start;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0) store_flag_plain(f.flags + flow_box_flag(f, row, 0), my_tag);
+            stamp(5);
+            if (f.trace && tid == 0) f.trace[row * 16 + 6] = (long long)clock64() - c_start;
+        }
+        lds_barrier();
+        // the sc1 copy of the inverse for everybody else (Li holds it)
+        double *Lk = f.Ldiag + (size_t)row * NB * NB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) store_sc1(Lk + (p.tr0 + 4 * e) * NB + p.tc, Li[p.tr0 + 4 * e][p.tc]);
+    }
+    // drain, then the flags of what is still pending
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        if (w.pending_flag >= 0) __hip_atomic_store(f.flags + w.pending_flag, f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (has_diag) __hip_atomic_store(f.flags + flow_inv_flag(f, row), f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// diagnostics: where the D workgroups of the most recent factorisation spent their time
+static long long *g_flow_trace = nullptr;
+long long *chol_flow_trace_buffer(int enable)
+{
+    if (enable && !g_flow_trace) { if (hipMalloc(reinterpret_cast<void **>(&g_flow_trace), 65 * 16 * 8) != hipSuccess) g_flow_trace = nullptr; else (void)hipMemset(g_flow_trace, 0, 65 * 16 * 8); }
+    if (!enable && g_flow_trace) { (void)hipFree(g_flow_trace); g_flow_trace = nullptr; }
+    return g_flow_trace;
+}
+
+// residency check of the flow kernel, per device: workgroups that can be resident at once
+int chol_flow_capacity()
+{
+    static int cap[64];
+    static bool known[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!known[dev]) {
+        int per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chol_flow_kernel, 256, 0) != hipSuccess ||
+            hipGetDeviceProperties(&prop, dev) != hipSuccess) { cap[dev] = 0; }
+        else {
+            // The query can promise one block per CU more than the hardware admits when the SGPR
+            // count is what limits (MI355X_MICROARCH.md, residency: 7-8 blocks per CU); this kernel
+            // is bound by its 164 VGPRs (3 per CU), far from that.  A workgroup that is not resident
+            // would be a hang, so: two fewer per CU where the answer is in the doubtful range, and a
+            // tenth of the chip left free on top.
+            if (per_cu >= 6) per_cu -= 2;
+            cap[dev] = (int)(0.9 * per_cu * prop.multiProcessorCount);
+        }
+        known[dev] = true;
+    }
+    return cap[dev];
+}
+
+int chol_flow_flag_count(int n)
+{
+    const int nblk = cholesky_padded_dim(n) / NB;
+    return (nblk + 2) * nblk + (nblk + 1) * (kFlowW + 1) + 16;
+}
+
+size_t chol_flow_mailbox_bytes(int n)
+{
+    const int nblk = cholesky_padded_dim(n) / NB;
+    return (size_t)(nblk + 1) * (kFlowW + 1) * NB * NB * sizeof(double);
+}
+
 // The right-hand side's last block: y_k = b_k inv(L_kk)^T for k = nblk - 1 (every earlier
 // block of the row is solved by the step that finishes its panel column).
 __global__ __launch_bounds__(64) void
@@ -297,10 +708,6 @@ chol_rhs_tail_kernel(const double *A, double *Lout, int ld, int nblk, const doub
 // Workgroup barrier that only orders LDS traffic.  __syncthreads() also drains the
 // vector-memory counter, which here would expose the latency of every prefetch and
 // of every result store once per step of the chain.
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 __global__ __launch_bounds__(1024) void
 chol_backsolve_kernel(const double *A, int ld, int nblk, int n, const double *Ldiag, double *x, const LmDev *lm)
@@ -361,10 +768,30 @@ void launch_small_solve(const double *A, int n, double *Ldiag, double *x, int *i
 
 // A: (N + 32) x N row-major, rows/cols >= n padded with identity, rhs in row N.
 // Ldiag: N * 32 doubles of scratch for the inverses of the factored diagonal blocks.
-void launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double *x, int *info, const LmDev *lm, hipStream_t s)
+void launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double *x, int *info, const LmDev *lm, hipStream_t s,
+    int *flow_flags, int flow_epoch, double *flow_mailbox)
 {
     const int N = cholesky_padded_dim(n);
     const int nblk = N / NB;
+    // the D's sit at the blocks 0, 8, 16, ...; the P tiles (rows more than kFlowW below the diagonal, the
+    // right-hand side row included) fill the blocks between and behind them
+    int num_p = 0;
+    for (int j = 0; j < nblk; ++j) num_p += std::max(nblk - j - kFlowW, 0);
+    int flow_groups = 8 * nblk + 1;                                   // through D_nblk at block 8 * nblk
+    {
+        const int between = 7 * nblk;                                   // non-D blocks below 8 * nblk
+        if (num_p > between) flow_groups += num_p - between;
+    }
+    if (flow_flags && flow_mailbox && nblk >= 2 && nblk <= 64 && flow_groups <= chol_flow_capacity()) {
+        CholFlow f;
+        f.mailbox = flow_mailbox;
+        f.A = A; f.Lmat = Lmat; f.Ldiag = Ldiag; f.flags = flow_flags; f.info = info; f.lm = lm;
+        f.ld = N; f.nblk = nblk; f.epoch = flow_epoch; f.trace = g_flow_trace;
+        hipLaunchKernelGGL(chol_flow_kernel, dim3(flow_groups), dim3(256), 0, s, f);
+        hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(1024), (size_t)2 * N * sizeof(double), s, Lmat, N,
+            nblk, n, Ldiag, x, lm);
+        return;
+    }
     hipLaunchKernelGGL(chol_first_kernel, dim3(1), dim3(64), 0, s, A, N, Ldiag, info, lm);
     for (int k = 0; k < nblk; ++k) {
         // tiles (i, j), k < j <= i <= nblk, j < nblk: for k = nblk - 1 only the right-hand-side

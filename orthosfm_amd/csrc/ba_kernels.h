@@ -133,7 +133,13 @@ int cholesky_padded_dim(int n);
 // lm != nullptr: nothing happens when the solve has stopped or the last linearisation failed
 // Lmat: (N + 32) x N scratch for the factor and the solved right-hand side (A keeps the
 // reduced system's trailing updates)
-void launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double *x, int *info, const LmDev *lm, hipStream_t s);
+// flow_flags (may be null: launch-per-column form): chol_flow_flag_count(n) ints, zeroed ONCE; flow_epoch: a
+// value > 0 that differs from every earlier call on the same flags (the hand-off flags of the one-launch form)
+void launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double *x, int *info, const LmDev *lm, hipStream_t s,
+    int *flow_flags = nullptr, int flow_epoch = 0, double *flow_mailbox = nullptr);
+int chol_flow_flag_count(int n);
+long long *chol_flow_trace_buffer(int enable);     // diagnostics, see osfm_ba_debug_chol_trace
+size_t chol_flow_mailbox_bytes(int n);     // flow_mailbox: scratch of that size (no initialisation needed)
 // n <= 32 (one block): factor, both substitutions and the candidate cameras in one launch
 void launch_small_solve(const double *A, int n, double *Ldiag, double *x, int *info, const BaDev &d,
     double *partials_cam, hipStream_t s);
