@@ -80,6 +80,8 @@ def parse():
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the extra passes with RANSAC-F")
     ap.add_argument("--no-e2e", action="store_true", help="skip the 200-image matching run and the end-to-end job")
+    ap.add_argument("--config", type=int, default=0, help="1: BASELINE configs[0] (3 views of the Suzanne model, solver 0) as a plumbing run, "
+                                                             "one JSON line of its own; 0 (default): the headline workload")
     ap.add_argument("--no-realistic", action="store_true", help="skip the passes with special SIFT rows (bytes > 127)")
     ap.add_argument("--e2e-views", type=int, default=200)
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = auto (about 15 s of CPU work)")
@@ -150,9 +152,46 @@ def cpu_baseline(iset, pairs, n_sample, gpu_lists):
         checked += 1
         if not np.array_equal(np.asarray(gpu_lists[i]), exp):
             bad.append(i)
-    base = {"value": len(sample) / dt, "unit": "pairs/s", "cores": int(threads), "kind": "port",
-            "sample": f"{len(sample)} full-size pairs ({iset.sift[0].shape[0]} x {iset.sift[0].shape[0]} SIFT, "
-                      f"two-way + cross-check) spread over the same image set, {dt:.1f} s"}
+    n = iset.sift[0].shape[0]
+    port = {"value": len(sample) / dt, "unit": "pairs/s", "cores": int(threads), "kind": "port",
+            "sample": f"{len(sample)} full-size pairs ({n} x {n} SIFT, two-way + cross-check) spread over the same "
+                      f"image set, {dt:.1f} s; OpenMP over the queries of a pair"}
+    # The reference's own matcher (sfm::Matching::twoway_match + remove_inconsistent_matches, compiled from
+    # /root/reference into oracle/_ref/libref_match.so) when it travelled: the way the reference runs it, one
+    # pair per thread (bundler_matching.cc:86-88), on as many pairs as there are threads (at least 8).  The
+    # lists it produces are compared with the GPU's as well.
+    rm = oracle_lib.ref_matcher()
+    if rm is None:
+        return port, checked, bad
+    from concurrent.futures import ThreadPoolExecutor
+    n_thr = int(max(1, min(threads, 16)))
+    n_ref = max(8, n_thr)
+    ref_sample = sorted({int(i) for i in np.linspace(0, len(pairs) - 1, n_ref)})
+
+    def one(i):
+        a, b = pairs[i]
+        e12, e21 = rm.twoway(iset.sift[a], iset.sift[b], 0.8)
+        return rm.remove_inconsistent(e12, e21)[0]
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=n_thr) as ex:
+        ref_lists = list(ex.map(one, ref_sample))
+    dt_ref = time.perf_counter() - t0
+    for i, e12 in zip(ref_sample, ref_lists):
+        if gpu_lists is None or gpu_lists[i] is None:
+            continue
+        idx = np.nonzero(e12 >= 0)[0]
+        exp = np.stack([idx, e12[idx]], axis=1).astype(np.int32)
+        checked += 1
+        if not np.array_equal(np.asarray(gpu_lists[i]), exp):
+            bad.append(i)
+    base = {"value": len(ref_sample) / dt_ref, "unit": "pairs/s", "cores": n_thr, "kind": "reference",
+            "sample": f"{len(ref_sample)} full-size pairs ({n} x {n} SIFT) through the reference's own twoway_match + "
+                      f"remove_inconsistent_matches (oracle/_ref/libref_match.so), one pair per thread as "
+                      f"bundler_matching.cc:86-88 runs them, {dt_ref:.1f} s",
+            "port": port,
+            # per core: what the bit-exact restatement (the oracle every parity test uses) costs against the reference
+            "port_vs_reference": (port["value"] / port["cores"]) / (len(ref_sample) / dt_ref / n_thr)}
     return base, checked, bad
 
 
@@ -614,8 +653,49 @@ def end_to_end_bench(args, device_index, cpu_pairs_per_s, cpu_ransac_s_per_pair,
     return out
 
 
+def config1_plumbing():
+    """BASELINE configs[0]: the 3-view Suzanne subset with --solver=0, end to end (match -> verify ->
+    tracks -> group -> local BA -> final BA) and as the test bench's own problem (one track per vertex,
+    every camera), GPU next to the CPU oracle.  A plumbing run: small, no roofline."""
+    import oracle_lib
+    from orthosfm_amd import ba as B, pipeline as P, synth
+    pts, cams, width, height = synth.suzanne_scene(3)
+    iset = synth.make_image_set(3, 3000, config_id=72, landmarks=pts, cameras=cams, width=width, height=height)
+    P.reconstruct(iset, solver=0, seed=3)
+    t0 = time.perf_counter()
+    res = P.reconstruct(iset, solver=0, seed=3)
+    t_e2e = time.perf_counter() - t0
+    gt, _ = P.canonical_ground_truth(iset, 0)
+    err = max(float(np.degrees(np.arccos(np.clip((np.trace(P._cam_rotation(0, gt[v]).T @ P._cam_rotation(0, res.cam_params[v])) - 1) / 2, -1, 1))))
+              for v in range(3))
+    sc = synth.make_suzanne_ba_scene(0, 3)
+    ref = sc.copy()
+    t0 = time.perf_counter()
+    so = oracle_lib.oracle_ba_solve(ref)
+    t_cpu = time.perf_counter() - t0
+    fp = B.FlatProblem.from_scene(sc)
+    B.solve(B.FlatProblem.from_scene(sc.copy()))
+    t0 = time.perf_counter()
+    s = B.solve(fp)
+    t_gpu = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": METRIC, "config": {"workload": "BASELINE configs[0]: 3 views of the reference's Suzanne model (7872 vertices, the first three "
+                                                   "cameras of its test bench), --solver=0 quaternion; plumbing run", "views": 3},
+        "data": "tests/golden/cfg1_suzanne.npz (reference's resources/Suzanne.ply + dataset_generation.cpp:14-38) + synthetic descriptors",
+        "end_to_end_s": t_e2e, "tracks": int(res.num_mve_tracks), "groups": len(res.groups),
+        "ba_calls": [c.kind for c in res.ba_calls], "max_rotation_error_deg": err,
+        "testbench_problem": {"tracks": int(sc.points.shape[0]), "observations": int(sc.obs_xy.shape[0]),
+                              "gpu_iterations": int(s.num_iterations), "oracle_iterations": int(so.num_iterations),
+                              "gpu_final_cost": float(s.final_cost), "oracle_final_cost": float(so.final_cost),
+                              "gpu_solve_ms": t_gpu * 1e3, "cpu_oracle_solve_ms": t_cpu * 1e3,
+                              "identical_iteration_count": bool(s.num_iterations == so.num_iterations)}}))
+
+
 def main():
     args = parse()
+    if args.config == 1:
+        config1_plumbing()
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -120,7 +120,7 @@ def make_image_set(num_views: int, feats_per_view: int, *, seed: int = BASE_SEED
                    config_id: int = 2, n_surf: int = 0, visibility: float = 0.4,
                    distractor_frac: float = 0.2, noise: float = 0.03,
                    width: int = 2048, height: int = 2048, twin_frac: float = 0.0,
-                   unrelated_views: int = 0) -> ImageSet:
+                   unrelated_views: int = 0, landmarks=None, cameras=None) -> ImageSet:
     """L landmarks in the ball |p| <= 0.5 with a base descriptor
     each; view v sees a random subset; descriptor = unit(base + noise*N(0,1)),
     quantised as A1; per-view feature order = descending keypoint scale.
@@ -137,11 +137,17 @@ def make_image_set(num_views: int, feats_per_view: int, *, seed: int = BASE_SEED
     L = max(int(round(n_real / visibility)), n_real)
     st = config_id << 32
 
-    # landmarks
-    d = normal(seed, st | 1, 3 * L).reshape(L, 3)
-    d = _unit_rows(d)
-    rad = 0.5 * np.cbrt(uniform(seed, st | 2, L))
-    points = d * rad[:, None]
+    # landmarks (given: e.g. the vertices of the reference's test model, tests/golden/cfg1_suzanne.npz --
+    # every view then sees a random n_real of them)
+    if landmarks is not None:
+        points = np.asarray(landmarks, dtype=np.float64).reshape(-1, 3)
+        L = points.shape[0]
+        assert L >= n_real, (L, n_real)
+    else:
+        d = normal(seed, st | 1, 3 * L).reshape(L, 3)
+        d = _unit_rows(d)
+        rad = 0.5 * np.cbrt(uniform(seed, st | 2, L))
+        points = d * rad[:, None]
     base_sift = normal(seed, st | 3, 128 * L).reshape(L, 128)
     base_sift_u = _unit_rows(np.minimum(_unit_rows(np.abs(base_sift)), 0.2))
     if twin_frac > 0.0:
@@ -165,6 +171,8 @@ def make_image_set(num_views: int, feats_per_view: int, *, seed: int = BASE_SEED
         phi = 2.0 * np.pi * v / num_views
         theta = np.deg2rad(-30.0 + 60.0 * ang[0])
         rho = np.deg2rad(-30.0 + 60.0 * ang[1])
+        if cameras is not None:
+            phi, theta, rho = (float(x) for x in cameras[v])
         cams.append((phi, theta, rho))
         # visible subset: n_real landmarks with the smallest random keys
         keys = uniform(seed, sv | 1, L)
@@ -199,6 +207,70 @@ def make_image_set(num_views: int, feats_per_view: int, *, seed: int = BASE_SEED
         else:
             surf.append(np.zeros((0, 64), dtype=np.int16))
     return ImageSet(sift, surf, landmark, pos, cams, points, width, height)
+
+
+def suzanne_scene(num_cameras: int = 3):
+    """BASELINE configs[0]: the landmarks of the reference's test model and the first cameras its test
+    bench draws (tests/golden/cfg1_suzanne.npz, made by tests/golden/make_cfg1_suzanne.py from
+    /root/reference/resources/Suzanne.ply and src/testbench/dataset_generation.cpp:14-38).
+    Returns (points (7872, 3), cameras [(phi, theta, rho) in radians], width, height)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "cfg1_suzanne.npz"))
+    cams = [tuple(np.deg2rad(g["cams_deg"][c])) for c in range(num_cameras)]
+    return g["points"], cams, int(g["width"]), int(g["height"])
+
+
+def make_suzanne_ba_scene(model: int = 0, num_cameras: int = 3, *, seed: int = BASE_SEED, noise_px: float = 0.0,
+                          rot_perturb_deg: float = 2.0, off_perturb: float = 0.01, point_perturb: float = 0.01,
+                          euler_free: int = 5):
+    """The reference's synthetic dataset (dataset_generation.cpp:40-93): one track per Suzanne vertex,
+    seen by every camera, observations = exact orthographic projections (stored through float32 as
+    Feature::x / y are) -- as a bundle-adjustment problem from a perturbed start, camera 0 fixed."""
+    pts, cams, width, height = suzanne_scene(num_cameras)
+    C, M = num_cameras, pts.shape[0]
+    gt = np.zeros((C, 7))
+    for c, (phi, theta, rho) in enumerate(cams):
+        if model == MODEL_QUATERNION:
+            gt[c, :4] = euler_to_quat(phi, theta, rho)
+            gt[c, 4:] = (0.0, 0.0, 1.0)
+        else:
+            gt[c, :6] = (phi, theta, rho, 0.0, 0.0, 1.0)
+    obs_point = np.repeat(np.arange(M), C)
+    obs_camera = np.tile(np.arange(C), M)
+    xy = np.zeros((M * C, 2))
+    for c in range(C):
+        sel = np.nonzero(obs_camera == c)[0]
+        xy[sel] = _project(model, gt[c], pts[obs_point[sel]], width, height)
+    st = 0x5A << 32
+    if noise_px > 0:
+        xy += noise_px * normal(seed, st | 1, 2 * M * C).reshape(-1, 2)
+    xy = xy.astype(np.float32).astype(np.float64)
+    camsp = gt.copy()
+    pr = normal(seed, st | 2, 3 * C).reshape(C, 3)
+    po = normal(seed, st | 3, 2 * C).reshape(C, 2)
+    for c in range(1, C):
+        if model == MODEL_QUATERNION:
+            axis = pr[c] / np.linalg.norm(pr[c])
+            a = np.deg2rad(rot_perturb_deg)
+            dq = np.array([*(np.sin(a / 2) * axis), np.cos(a / 2)])
+            camsp[c, :4] = quat_mul(dq, gt[c, :4])
+            camsp[c, 4:6] = gt[c, 4:6] + off_perturb * po[c]
+        else:
+            camsp[c, :3] = gt[c, :3] + np.deg2rad(rot_perturb_deg) * pr[c] / np.sqrt(3.0)
+            camsp[c, 3:5] = gt[c, 3:5] + off_perturb * po[c]
+    P = np.ones((M, 4))
+    P[:, :3] = pts + point_perturb * normal(seed, st | 4, 3 * M).reshape(M, 3)
+    const = np.zeros((C, 7), dtype=np.uint8)
+    if model == MODEL_QUATERNION:
+        const[:, 6] = 1
+    else:
+        free = [0, 1, 2, 3, 4][:euler_free] if euler_free <= 5 else [0, 1, 2, 3, 4, 5]
+        const[:, :] = 1
+        for s_ in free:
+            const[:, s_] = 0
+    const[0, :] = 1
+    return BaScene(model, camsp, const, np.full(C, width, np.int32), np.full(C, height, np.int32), P, xy,
+                   obs_camera.astype(np.int32), obs_point.astype(np.int32), gt, pts)
 
 
 def add_peaky_rows(iset: "ImageSet", k: int, *, seed: int = BASE_SEED, stream: int = 0x7EA) -> list:

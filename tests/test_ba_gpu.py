@@ -89,6 +89,27 @@ def test_lm_matches_oracle_medium(ba, model):
     _compare_solve(ba, sc)
 
 
+@pytest.mark.parametrize("model", [0, 1])
+def test_config1_suzanne_three_cameras(ba, model):
+    """BASELINE configs[0] on the data it names: the reference's synthetic dataset
+    (src/testbench/dataset_generation.cpp:40-93) -- one track per vertex of resources/Suzanne.ply seen
+    by every camera, the first three of the test bench's 16 cameras (tests/golden/cfg1_suzanne.npz) --
+    as one adjustment from a perturbed start: --solver=0 (quaternion cameras) and the Euler model.
+    Same iteration counts / termination / cost as the oracle, cameras back at the ground truth."""
+    sc = synth.make_suzanne_ba_scene(model, 3)
+    assert sc.points.shape[0] == 7872 and sc.obs_xy.shape[0] == 3 * 7872
+    s, fp, _ = _compare_solve(ba, sc)
+    assert s.final_cost < 1e-3 * s.initial_cost
+    assert np.array_equal(fp.cam_params[0], sc.gt_cams[0])
+    # gauge: camera 0 is fixed at its true pose, so the others come back to theirs (the points are free)
+    if model == 0:
+        for c in range(3):
+            q, g = fp.cam_params[c, :4], sc.gt_cams[c, :4]
+            assert min(np.abs(q - g).max(), np.abs(q + g).max()) < 1e-4, c
+    else:
+        assert np.abs(fp.cam_params[:, :3] - sc.gt_cams[:, :3]).max() < 1e-4
+
+
 def test_lm_constant_points_and_three_cameras(ba):
     """optimize_points = 0 (no Schur elimination) and the 3-camera local BA
     shape of the incremental pipeline (reconstruct.cpp:219)."""

@@ -140,11 +140,14 @@ def test_incremental_group_builder_matches_the_oracle():
 
 def test_config1_three_views_quaternion():
     """BASELINE configs[0]: three views, --solver=0 (quaternion): match -> verify -> tracks ->
-    one group -> filter -> local BA (camera 0 fixed) -> triangulate -> final BA.  (The
-    reference's own three-image subset is a download the tree does not hold; the landmarks
-    here are the synthetic scene's, as for the other configs.)"""
+    one group -> filter -> local BA (camera 0 fixed) -> triangulate -> final BA, on the landmarks of
+    the reference's test model and the first three cameras its test bench draws
+    (tests/golden/cfg1_suzanne.npz <- resources/Suzanne.ply, dataset_generation.cpp:14-38); every view
+    sees 2400 of the 7872 vertices plus distractors, descriptors are synthetic (the test bench has
+    none: it builds its tracks from the projections, which test_ba_gpu.py::test_config1_suzanne_* does)."""
     from orthosfm_amd import pipeline as P
-    iset = synth.make_image_set(3, 3000, config_id=72)
+    pts, cams, width, height = synth.suzanne_scene(3)
+    iset = synth.make_image_set(3, 3000, config_id=72, landmarks=pts, cameras=cams, width=width, height=height)
     res = P.reconstruct(iset, solver=0, seed=3)
     assert len(res.groups) == 1 and sorted(res.groups[0].ids) == [0, 1, 2]
     assert [c.kind for c in res.ba_calls] == ["local", "final"]

@@ -10,11 +10,13 @@ KERNEL = "match_tile_kernel<8, false, true, true>"
 
 
 def total(path, counter):
-    best = 0.0
+    # the LAST launch of the kernel in the trace: the timed pass behind the warm-up passes
+    # (rows come in dispatch order; several rows of one dispatch -- one per XCD / shader engine -- add up)
+    per_dispatch = {}
     for row in csv.DictReader(open(path)):
         if KERNEL in row["Kernel_Name"] and row["Counter_Name"] == counter:
-            best = max(best, float(row["Counter_Value"]))     # the full-matching launch
-    return best
+            per_dispatch[int(row["Dispatch_Id"])] = per_dispatch.get(int(row["Dispatch_Id"]), 0.0) + float(row["Counter_Value"])
+    return per_dispatch[max(per_dispatch)] if per_dispatch else 0.0
 
 
 def main():
@@ -25,7 +27,7 @@ def main():
     rec = {
         "kernel": KERNEL,
         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py "
-                   "--steps 1 --warmup 0 --no-ba --no-verify --no-cpu-baseline",
+                   "--steps 1 --warmup 2 --no-ba --no-verify --no-cpu-baseline --no-e2e --no-realistic; the last (warmed) launch",
         "pairs_in_launch": pairs,
         "FETCH_SIZE_KB": fetch_kb,
         "WRITE_SIZE_KB": write_kb,

@@ -19,6 +19,20 @@ else
   cp $f $R/gpurun_out/${round}_bench_kernel_stats_$tag.csv
 fi
 rm -rf $R/gpurun_out/prof_$tag        # the trace itself is large; the summary is what is kept
+# Second summary: a run with ONLY the headline launches (no BA, no RANSAC passes, no end-to-end job, no CPU
+# baseline, no drop-in / realistic-operand legs), so that the AverageNs of match_tile_kernel<8, false, true, true>
+# IS roofline.avg_launch_ms of the line printed by the same command.
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_h_$tag -- python $R/bench.py --steps 10 --warmup 2 --no-ba --no-verify --no-e2e --no-cpu-baseline --no-realistic > $R/gpurun_out/prof_h_$tag.log 2>&1
+tail -1 $R/gpurun_out/prof_h_$tag.log > $R/gpurun_out/${round}_bench_headline_only_$tag.json
+db=$(find $R/gpurun_out/prof_h_$tag -name "*.db" | head -1)
+if [ -n "$db" ]; then
+  python $R/tools/rocpd_stats.py $db > $R/gpurun_out/${round}_bench_headline_only_kernel_stats_$tag.csv
+else
+  f=$(find $R/gpurun_out/prof_h_$tag -name "*kernel_stats.csv" | head -1)
+  cp $f $R/gpurun_out/${round}_bench_headline_only_kernel_stats_$tag.csv
+fi
+rm -rf $R/gpurun_out/prof_h_$tag
+head -6 $R/gpurun_out/${round}_bench_headline_only_kernel_stats_$tag.csv
 head -8 $R/gpurun_out/${round}_bench_kernel_stats_$tag.csv
 python - <<PY
 import json
