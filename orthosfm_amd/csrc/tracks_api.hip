@@ -16,29 +16,47 @@
 
 using namespace osfm;
 
-extern "C" {
+// The merge as a state that takes the match lists pair batch by pair batch (in the reference's
+// pair order): the host can then build tracks while the device matches the next batch.
+struct osfm_tracks_builder {
+    int32_t num_views = 0;
+    std::vector<int32_t> view_sizes;
+    std::vector<int64_t> voff;
+    // node g = voff[view] + feature; nxt[g] = next feature of the same track
+    std::vector<int32_t> tid;
+    std::vector<int64_t> nxt;
+    std::vector<int64_t> head, tail;
+    std::vector<int32_t> size;
+    // a self-match (view_1 == view_2, feature matched to itself) makes the reference push
+    // the same FeatureReference twice (:80-86): the track is invalid for good (two features
+    // of one view) and counts one feature more than it has nodes
+    std::vector<uint8_t> twice;
+};
+
+static int builder_init(osfm_tracks_builder *b, int32_t num_views, const int32_t *view_sizes)
+{
+    if (num_views < 0 || (num_views > 0 && !view_sizes)) { set_error("tracks: null array / negative count"); return OSFM_E_ARG; }
+    b->num_views = num_views;
+    b->view_sizes.assign(view_sizes, view_sizes + num_views);
+    b->voff.assign((size_t)num_views + 1, 0);
+    for (int v = 0; v < num_views; ++v) {
+        if (view_sizes[v] < 0) { set_error("tracks_compute: negative view size"); return OSFM_E_ARG; }
+        b->voff[v + 1] = b->voff[v] + view_sizes[v];
+    }
+    const int64_t G = b->voff[num_views];
+    b->tid.assign((size_t)G, -1);
+    b->nxt.assign((size_t)G, -1);
+    return OSFM_OK;
+}
 
 // pair p owns corr[pair_begin[p] .. pair_end[p])
-static int tracks_compute_impl(int32_t num_views, const int32_t *view_sizes, const uint8_t *colors,
-    int32_t num_pairs, const osfm_pair *pairs, const int64_t *pair_begin, const int64_t *pair_end,
-    const int32_t *corr,
-    int32_t *track_ids, int64_t track_capacity, int64_t feature_capacity,
-    int64_t *track_offsets, int32_t *track_features, uint8_t *track_colors,
-    osfm_tracks_summary *summary)
+static int builder_feed(osfm_tracks_builder *b, int32_t num_pairs, const osfm_pair *pairs, const int64_t *pair_begin,
+    const int64_t *pair_end, const int32_t *corr)
 {
-    if (num_views < 0 || num_pairs < 0 || (num_views > 0 && !view_sizes) ||
-        (num_pairs > 0 && (!pairs || !pair_begin || !pair_end)) || !track_offsets ||
-        (track_capacity > 0 && !track_colors) || (feature_capacity > 0 && !track_features)) {
+    if (num_pairs < 0 || (num_pairs > 0 && (!pairs || !pair_begin || !pair_end))) {
         set_error("tracks_compute: null array / negative count");
         return OSFM_E_ARG;
     }
-    std::vector<int64_t> voff((size_t)num_views + 1, 0);
-    for (int v = 0; v < num_views; ++v) {
-        if (view_sizes[v] < 0) { set_error("tracks_compute: negative view size"); return OSFM_E_ARG; }
-        voff[v + 1] = voff[v] + view_sizes[v];
-    }
-    const int64_t G = voff[num_views];
-    if (G > 0 && !track_ids) { set_error("tracks_compute: track_ids is null"); return OSFM_E_ARG; }
     int64_t total_matches = 0;
     for (int p = 0; p < num_pairs; ++p) {
         if (pair_begin[p] < 0 || pair_end[p] < pair_begin[p]) {
@@ -49,17 +67,10 @@ static int tracks_compute_impl(int32_t num_views, const int32_t *view_sizes, con
         total_matches += pair_end[p] - pair_begin[p];
     }
     if (total_matches > 0 && !corr) { set_error("tracks_compute: corr is null"); return OSFM_E_ARG; }
-
-    // node g = voff[view] + feature; nxt[g] = next feature of the same track
-    std::vector<int32_t> tid((size_t)G, -1);
-    std::vector<int64_t> nxt((size_t)G, -1);
-    std::vector<int64_t> head, tail;
-    std::vector<int32_t> size;
-    // a self-match (view_1 == view_2, feature matched to itself) makes the reference push
-    // the same FeatureReference twice (:80-86): the track is invalid for good (two features
-    // of one view) and counts one feature more than it has nodes
-    std::vector<uint8_t> twice;
-
+    const int num_views = b->num_views;
+    const int32_t *view_sizes = b->view_sizes.data();
+    auto &voff = b->voff; auto &tid = b->tid; auto &nxt = b->nxt; auto &head = b->head; auto &tail = b->tail;
+    auto &size = b->size; auto &twice = b->twice;
     for (int p = 0; p < num_pairs; ++p) {                                       // :66-119
         const int v1 = pairs[p].view_1, v2 = pairs[p].view_2;
         if (v1 < 0 || v1 >= num_views || v2 < 0 || v2 >= num_views) {
@@ -86,15 +97,32 @@ static int tracks_compute_impl(int32_t num_views, const int32_t *view_sizes, con
                 tid[g2] = t1; nxt[tail[t1]] = g2; tail[t1] = g2; size[t1]++;
             } else if (t1 != t2) {
                 // unify into the larger track, the first one on a draw (:28-31)
-                int32_t a = t1, b = t2;
-                if (size[a] < size[b]) { a = t2; b = t1; }
-                for (int64_t g = head[b]; g >= 0; g = nxt[g]) tid[g] = a;
-                nxt[tail[a]] = head[b]; tail[a] = tail[b]; size[a] += size[b];
-                twice[a] |= twice[b];
-                head[b] = -1; tail[b] = -1; size[b] = 0;
+                int32_t a = t1, bq = t2;
+                if (size[a] < size[bq]) { a = t2; bq = t1; }
+                for (int64_t g = head[bq]; g >= 0; g = nxt[g]) tid[g] = a;
+                nxt[tail[a]] = head[bq]; tail[a] = tail[bq]; size[a] += size[bq];
+                twice[a] |= twice[bq];
+                head[bq] = -1; tail[bq] = -1; size[bq] = 0;
             }
         }
     }
+    return OSFM_OK;
+}
+
+static int builder_finish(const osfm_tracks_builder *b, const uint8_t *colors,
+    int32_t *track_ids, int64_t track_capacity, int64_t feature_capacity,
+    int64_t *track_offsets, int32_t *track_features, uint8_t *track_colors,
+    osfm_tracks_summary *summary)
+{
+    if (!track_offsets || (track_capacity > 0 && !track_colors) || (feature_capacity > 0 && !track_features)) {
+        set_error("tracks_compute: null array / negative count");
+        return OSFM_E_ARG;
+    }
+    const int num_views = b->num_views;
+    const auto &voff = b->voff; const auto &tid = b->tid; const auto &nxt = b->nxt; const auto &head = b->head;
+    const auto &size = b->size; const auto &twice = b->twice;
+    const int64_t G = voff[num_views];
+    if (G > 0 && !track_ids) { set_error("tracks_compute: track_ids is null"); return OSFM_E_ARG; }
 
     // remove_invalid_tracks (:149-203): empty tracks, tracks with two features of one view
     const int64_t nt = (int64_t)head.size();
@@ -145,6 +173,65 @@ static int tracks_compute_impl(int32_t num_views, const int32_t *view_sizes, con
         for (int c = 0; c < 3; ++c) track_colors[3 * o + c] = (uint8_t)(col[c] / col[3] + 0.5f);
     }
     track_offsets[valid] = nf;
+    return OSFM_OK;
+}
+
+extern "C" {
+
+static int tracks_compute_impl(int32_t num_views, const int32_t *view_sizes, const uint8_t *colors,
+    int32_t num_pairs, const osfm_pair *pairs, const int64_t *pair_begin, const int64_t *pair_end,
+    const int32_t *corr,
+    int32_t *track_ids, int64_t track_capacity, int64_t feature_capacity,
+    int64_t *track_offsets, int32_t *track_features, uint8_t *track_colors,
+    osfm_tracks_summary *summary)
+{
+    if (num_views < 0 || num_pairs < 0 || (num_views > 0 && !view_sizes) ||
+        (num_pairs > 0 && (!pairs || !pair_begin || !pair_end)) || !track_offsets ||
+        (track_capacity > 0 && !track_colors) || (feature_capacity > 0 && !track_features)) {
+        set_error("tracks_compute: null array / negative count");
+        return OSFM_E_ARG;
+    }
+    osfm_tracks_builder b;
+    OSFM_RETURN_IF(builder_init(&b, num_views, view_sizes));
+    if (b.voff[num_views] > 0 && !track_ids) { set_error("tracks_compute: track_ids is null"); return OSFM_E_ARG; }
+    OSFM_RETURN_IF(builder_feed(&b, num_pairs, pairs, pair_begin, pair_end, corr));
+    return builder_finish(&b, colors, track_ids, track_capacity, feature_capacity, track_offsets, track_features,
+        track_colors, summary);
+}
+
+int osfm_tracks_builder_create(int32_t num_views, const int32_t *view_sizes, osfm_tracks_builder **out)
+{
+    if (!out) { set_error("tracks_builder_create: null argument"); return OSFM_E_ARG; }
+    *out = nullptr;
+    osfm_tracks_builder *b = new osfm_tracks_builder();
+    const int st = builder_init(b, num_views, view_sizes);
+    if (st != OSFM_OK) { delete b; return st; }
+    *out = b;
+    return OSFM_OK;
+}
+
+int osfm_tracks_builder_feed(osfm_tracks_builder *b, int32_t num_pairs, const osfm_pair *pairs,
+    const int64_t *pair_starts, const int64_t *pair_counts, const int32_t *corr)
+{
+    if (!b || num_pairs < 0 || (num_pairs > 0 && (!pair_starts || !pair_counts))) { set_error("tracks_builder_feed: bad arguments"); return OSFM_E_ARG; }
+    std::vector<int64_t> ends((size_t)num_pairs);
+    for (int p = 0; p < num_pairs; ++p) ends[p] = pair_starts[p] + pair_counts[p];
+    return builder_feed(b, num_pairs, pairs, pair_starts, ends.data(), corr);
+}
+
+int osfm_tracks_builder_finish(const osfm_tracks_builder *b, const uint8_t *colors,
+    int32_t *track_ids, int64_t track_capacity, int64_t feature_capacity,
+    int64_t *track_offsets, int32_t *track_features, uint8_t *track_colors,
+    osfm_tracks_summary *summary)
+{
+    if (!b) { set_error("tracks_builder_finish: null builder"); return OSFM_E_ARG; }
+    return builder_finish(b, colors, track_ids, track_capacity, feature_capacity, track_offsets, track_features,
+        track_colors, summary);
+}
+
+int osfm_tracks_builder_destroy(osfm_tracks_builder *b)
+{
+    delete b;
     return OSFM_OK;
 }
 

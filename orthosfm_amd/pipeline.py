@@ -92,6 +92,53 @@ class TrackTable:
     def num_tracks(self):
         return int(self.alive_t.sum())
 
+    def compacted(self):
+        """A working table that holds the live tracks and features only, in the same order, with
+        orig_track / orig_feat naming their rows in the table the job started from.  The filters
+        of the reference return ever smaller std::vector<Track> copies (reconstruct.cpp:205,264-265);
+        here flags are cleared instead, and after the first global round most of the scene is flags
+        (200 views x 20k features: 3.2 M features of which ~5 % stay live) -- every later selection
+        would still scan all of it."""
+        sel_t = np.flatnonzero(self.alive_t)
+        sel_f = np.flatnonzero(self.live_f)
+        w = TrackTable.__new__(TrackTable)
+        lens = self._lengths[sel_t]
+        w.offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        w.view, w.feat, w.xy = self.view[sel_f], self.feat[sel_f], self.xy[sel_f]
+        w.num_views = self.num_views
+        nt = sel_t.shape[0]
+        w.track_of = np.repeat(np.arange(nt, dtype=np.int32), lens)
+        w.point, w.has_point = self.point[sel_t], self.has_point[sel_t]
+        w.alive_t = np.ones(nt, dtype=bool)
+        w.alive_f = np.ones(sel_f.shape[0], dtype=bool)
+        w.live_f = np.ones(sel_f.shape[0], dtype=bool)
+        w.cam_f = self.cam_f[sel_f]
+        w._lengths = lens.astype(np.int64)
+        order = np.argsort(w.view, kind="stable").astype(np.int64)
+        w.by_view = order
+        w.view_start = np.searchsorted(w.view[order], np.arange(w.num_views + 1))
+        w.orig_track = getattr(self, "orig_track", np.arange(self.alive_t.shape[0]))[sel_t]
+        w.orig_feat = getattr(self, "orig_feat", np.arange(self.alive_f.shape[0]))[sel_f]
+        return w
+
+    def write_back(self, work):
+        """The state of a working table (compacted(), possibly several times) into this one."""
+        if work is self:
+            return
+        ot, of = work.orig_track, work.orig_feat
+        self.alive_t[:] = False
+        self.alive_t[ot[work.alive_t]] = True
+        self.alive_f[:] = False
+        self.alive_f[of[work.alive_f]] = True
+        self.live_f[:] = False
+        self.live_f[of[work.live_f]] = True
+        self.has_point[:] = False
+        self.has_point[ot] = work.has_point
+        self.point[ot] = work.point
+        self.cam_f[of] = work.cam_f
+        self._lengths[:] = 0
+        self._lengths[ot] = work._lengths
+
     def features_of_views(self, views):
         """Alive features of alive tracks seen by the given views, in track order."""
         idx = np.concatenate([self.by_view[self.view_start[v]:self.view_start[v + 1]] for v in views])
@@ -257,6 +304,7 @@ class Timings:
     upload_s: float = 0.0
     matching_s: float = 0.0
     tracks_s: float = 0.0
+    tracks_busy_s: float = 0.0
     convert_s: float = 0.0
     groups_s: float = 0.0
     local_ba_s: float = 0.0
@@ -302,6 +350,20 @@ def _problem(model, cams, const, width, height, points, xy, obs_cam, obs_pt):
                          np.full(cams.shape[0], height, np.int32), points, xy, obs_cam, obs_pt)
 
 
+_LIST_BUFFERS = []
+
+
+def _list_buffers(rows, n):
+    """n page-locked (rows, 2) int32 list buffers, kept for the process (page-locked memory is
+    expensive to allocate and capi.pinned_rows never frees): grown when a job needs more."""
+    while len(_LIST_BUFFERS) < n:
+        _LIST_BUFFERS.append(None)
+    for k in range(n):
+        if _LIST_BUFFERS[k] is None or _LIST_BUFFERS[k].shape[0] < rows:
+            _LIST_BUFFERS[k] = capi.pinned_rows(rows)
+    return [_LIST_BUFFERS[k][:rows] for k in range(n)]
+
+
 def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, timings=None, pairs=None):
     """calculateTracksUsingMVE up to (and including) the track conversion."""
     tm = timings if timings is not None else Timings()
@@ -325,22 +387,70 @@ def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, ti
     t0 = time.perf_counter()
     if pairs is None:
         pairs = [capi.pair_from_index(i) for i in range(V * (V - 1) // 2)]
-    cap = sum(min(iset.sift[a].shape[0] + iset.surf[a].shape[0], iset.sift[b].shape[0] + iset.surf[b].shape[0])
-              for a, b in pairs)
-    out = m.compute(pairs, capacity=cap)
+    pf = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
+    sizes = np.array([iset.sift[v].shape[0] + iset.surf[v].shape[0] for v in range(V)], dtype=np.int32)
+    # Matching and track building side by side: the pair list goes through the matcher in batches
+    # (in pair order), and while the device works on batch k + 1 a second thread merges the lists of
+    # batch k into the tracks (Tracks::compute is a sequential merge over the pairs in that order, so
+    # it takes them as they come; both are C calls that release the interpreter lock).  Two list
+    # buffers alternate: a batch's lists stay where they are until the merge has read them.
+    import queue
+    import threading
+    builder = T.TracksBuilder(sizes)
+    n_batches = max(1, min(16, pf.shape[0] // 512))
+    bounds = np.linspace(0, pf.shape[0], n_batches + 1).astype(np.int64)
+    pair_cap = np.minimum(sizes[pf[:, 0]], sizes[pf[:, 1]]).astype(np.int64) if pf.shape[0] else np.zeros(0, np.int64)
+    max_cap = max(int(max((pair_cap[bounds[k]:bounds[k + 1]].sum() for k in range(n_batches)), default=1)), 1)
+    bufs = _list_buffers(max_cap, 2 if n_batches > 1 else 1)
+    free = queue.Queue()
+    for b_ in bufs:
+        free.put(b_)
+    work = queue.Queue()
+    tracks_busy = [0.0]
+    err = []
+
+    def merge_worker():
+        while True:
+            item = work.get()
+            if item is None:
+                return
+            sub, ra, corr_buf = item
+            t1 = time.perf_counter()
+            try:
+                builder.feed(sub, ra, corr_buf)
+            except Exception as e:      # reported by the main thread
+                err.append(e)
+            tracks_busy[0] += time.perf_counter() - t1
+            free.put(corr_buf)
+
+    th = threading.Thread(target=merge_worker, daemon=True)
+    th.start()
+    status = np.zeros(pf.shape[0], dtype=np.int32)
+    for k in range(n_batches):
+        sub = pf[bounds[k]:bounds[k + 1]]
+        buf = free.get()
+        m.use_result_buffer(buf)
+        ra, corr_buf = m.compute_arrays(sub, capacity=max_cap)
+        status[bounds[k]:bounds[k + 1]] = ra["status"]
+        work.put((sub, ra.copy(), buf))
     tm.matching_s = time.perf_counter() - t0
     t0 = time.perf_counter()
-    matched = [tv for tv in out if tv.status == capi.PAIR_MATCHED]
-    sizes = np.array([iset.sift[v].shape[0] + iset.surf[v].shape[0] for v in range(V)], dtype=np.int32)
-    parr, offs, corr = T.flatten_matching(matched)
-    ids, toff, tfeat, tcol, summary = T.compute_flat(sizes, None, parr, offs, corr)
+    work.put(None)
+    th.join()
+    if err:
+        raise err[0]
+    ids, toff, tfeat, tcol, summary = builder.finish()
+    # tracks_s: what the job waited for after the last batch was matched (the merge of the earlier
+    # batches ran beside the matching: tracks_busy_s of it in all)
     tm.tracks_s = time.perf_counter() - t0
+    tm.tracks_busy_s = tracks_busy[0]
     t0 = time.perf_counter()
     tt = TrackTable.from_mve(toff, tfeat, norm, W, V)
     tm.convert_s = time.perf_counter() - t0
-    info = {"num_pairs": len(pairs), "matched_pairs": len(matched), "correspondences": int(offs[-1]),
+    info = {"num_pairs": int(pf.shape[0]), "matched_pairs": int(builder.num_pairs), "correspondences": int(builder.num_matches),
             "num_mve_tracks": int(summary.num_tracks), "invalid_mve_tracks": int(summary.num_invalid_tracks),
-            "pair_status": np.array([tv.status for tv in out], dtype=np.int32)}
+            "pair_status": status}
+    builder.close()
     m.close()
     return tt, info
 
@@ -355,6 +465,7 @@ def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2
     gt, _ = canonical_ground_truth(iset, model)
     rng = np.random.default_rng(seed)
     t_pose = time.perf_counter()
+    full_table = tt          # the caller's table; `tt` becomes a compacted working copy once the filters have thinned it
 
     # ---- buildGroups ----------------------------------------------------------
     t0 = time.perf_counter()
@@ -538,10 +649,16 @@ def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2
                 tm.outlier_filter_s += time.perf_counter() - t0
                 if len(aligned) <= int(tt.alive_lengths().max(initial=0)):
                     reprojection_filter(list(aligned), cams[aligned], const[aligned], permanent=True)
+                # drop what the filters have cleared once it is most of the table
+                t0 = time.perf_counter()
+                if int(tt.live_f.sum()) < 0.6 * tt.live_f.shape[0]:
+                    tt = tt.compacted()
+                tm.pose_host_s += time.perf_counter() - t0
         if verbose:
             print(f"group {processed}/{len(groups)} {ids}: {len(aligned)} cameras, {tt.num_tracks} tracks, "
                   f"{int(tt.has_point.sum())} points")
     _global_ba(tt, model, cams, const, aligned, W, H, V, solve, "final", opt, tm)      # :281
+    full_table.write_back(tt)
     tm.pose_s = time.perf_counter() - t_pose
     return cams, aligned, groups, calls, captured
 

@@ -106,6 +106,70 @@ def compute_flat_ranges(view_sizes, colors, pairs, pair_starts, pair_counts, cor
             track_colors[:nt], summary)
 
 
+class TracksBuilder:
+    """Tracks::compute fed pair batch by pair batch (osfm_tracks_builder_*): feed() takes what
+    HipExhaustiveMatching.compute_arrays returned for one batch of pairs -- in the reference's pair
+    order over the batches -- so the merge of one batch runs on the host while the device matches
+    the next (the C calls release the interpreter lock)."""
+
+    def __init__(self, view_sizes):
+        self.view_sizes = np.ascontiguousarray(view_sizes, dtype=np.int32)
+        self._h = C.c_void_p()
+        capi.check(capi.lib.osfm_tracks_builder_create(len(self.view_sizes), capi._ptr(self.view_sizes, C.c_int32),
+                                                       C.byref(self._h)))
+        self.num_matches = 0
+        self.num_pairs = 0
+
+    def feed(self, pairs_flat, records, corr):
+        """pairs_flat (n, 2) int32, records: osfm_pair_result records of the batch (numpy), corr: the
+        (rows, 2) int32 list buffer the offsets of the records point into."""
+        matched = records["status"] == capi.PAIR_MATCHED
+        cnt = np.where(records["num_inliers"] >= 0, records["num_inliers"], records["num_matches"]).astype(np.int64)
+        cnt = np.where(matched, cnt, 0)
+        starts = np.ascontiguousarray(np.where(matched, records["offset"], 0), dtype=np.int64)
+        cnt = np.ascontiguousarray(cnt, dtype=np.int64)
+        pf = np.ascontiguousarray(pairs_flat, dtype=np.int32).reshape(-1, 2)
+        assert corr.dtype == np.int32 and corr.flags.c_contiguous
+        capi.check(capi.lib.osfm_tracks_builder_feed(self._h, pf.shape[0], pf.ctypes.data_as(C.POINTER(capi.Pair)),
+                                                     capi._ptr(starts, C.c_int64), capi._ptr(cnt, C.c_int64),
+                                                     capi._ptr(corr, C.c_int32)))
+        self.num_matches += int(cnt.sum())
+        self.num_pairs += int(matched.sum())
+
+    def finish(self, colors=None):
+        total = int(self.view_sizes.sum())
+        track_ids = np.full(max(total, 1), -1, dtype=np.int32)
+        tcap, fcap = max(self.num_matches, 1), max(2 * self.num_matches, 1)
+        # a track has at least two features and every feature is in one track at most
+        tcap, fcap = min(tcap, max(total // 2, 1)), min(fcap, max(total, 1))
+        track_offsets = np.zeros(tcap + 1, dtype=np.int64)
+        track_features = np.zeros((fcap, 2), dtype=np.int32)
+        track_colors = np.zeros((tcap, 3), dtype=np.uint8)
+        summary = capi.TracksSummary()
+        col_ptr = None
+        if colors is not None:
+            colors = np.ascontiguousarray(colors, dtype=np.uint8).reshape(-1, 3)
+            col_ptr = capi._ptr(colors, C.c_uint8)
+        capi.check(capi.lib.osfm_tracks_builder_finish(
+            self._h, col_ptr, capi._ptr(track_ids, C.c_int32), C.c_int64(tcap), C.c_int64(fcap),
+            capi._ptr(track_offsets, C.c_int64), capi._ptr(track_features, C.c_int32),
+            capi._ptr(track_colors, C.c_uint8), C.byref(summary)))
+        nt = summary.num_tracks
+        return (track_ids[:total], track_offsets[:nt + 1], track_features[:summary.num_features],
+                track_colors[:nt], summary)
+
+    def close(self):
+        if self._h:
+            capi.lib.osfm_tracks_builder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Tracks:
     """sfm::bundler::Tracks."""
 

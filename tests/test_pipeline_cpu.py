@@ -86,6 +86,44 @@ def test_track_table_indexing():
                                   np.float32(100 * (np.float64(np.float32(-0.2)) + 0.5))])
 
 
+def test_track_table_compaction_round_trip():
+    """compacted() keeps the live tracks / features in order; selections on the working table name
+    the same features (through orig_feat) as on the full one; write_back() restores the flags,
+    points and lengths -- also through two compactions."""
+    r = np.random.default_rng(5)
+    lens = r.integers(2, 6, 40)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    n = int(offs[-1])
+    view = np.concatenate([r.choice(8, l, replace=False) for l in lens])
+    tt = P.TrackTable(offs, view, r.integers(0, 100, n), r.normal(size=(n, 2)), 8)
+    ref = P.TrackTable(offs, view, tt.feat.copy(), tt.xy.copy(), 8)
+    for v in (1, 4, 6):
+        tt.align_view(v, v); ref.align_view(v, v)
+    work = tt
+    for round_ in range(2):
+        kt = r.choice(np.flatnonzero(work.alive_t), 8, replace=False)
+        kf = r.choice(np.flatnonzero(work.live_f), 10, replace=False)
+        ot = getattr(work, "orig_track", np.arange(40))
+        of = getattr(work, "orig_feat", np.arange(n))
+        work.kill(tracks=kt, features=kf)
+        ref.kill(tracks=ot[kt], features=of[kf])
+        work = work.compacted()
+        assert work.alive_t.all() and work.live_f.all()
+        assert np.array_equal(work.orig_feat, np.flatnonzero(ref.live_f))
+        assert np.array_equal(work.orig_track, np.flatnonzero(ref.alive_t))
+        assert np.array_equal(work.offsets[1:] - work.offsets[:-1], ref.alive_lengths()[ref.alive_t])
+        for views in ([1, 4], [6], [0, 2, 7]):
+            assert np.array_equal(work.orig_feat[work.features_of_views(views)], ref.features_of_views(views))
+        assert np.array_equal(work.cam_f, ref.cam_f[work.orig_feat])
+    work.point[:] = r.normal(size=work.point.shape)
+    work.has_point[::2] = True
+    tt.write_back(work)
+    assert np.array_equal(tt.alive_t, ref.alive_t) and np.array_equal(tt.live_f, ref.live_f)
+    assert np.array_equal(tt.alive_lengths(), ref.alive_lengths())
+    assert np.array_equal(tt.point[work.orig_track], work.point) and tt.has_point.sum() == work.has_point.sum()
+    assert not tt.has_point[~tt.alive_t].any()
+
+
 def test_const_masks_follow_the_solver():
     assert P.default_const_mask(B.MODEL_QUATERNION).tolist() == [0, 0, 0, 0, 0, 0, 1]
     assert P.default_const_mask(B.MODEL_EULER, euler_dof=P.euler_dof_of_solver(3)).tolist() == [0, 0, 0, 0, 0, 1, 1]

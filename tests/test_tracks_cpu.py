@@ -155,3 +155,46 @@ def test_self_match_is_an_invalid_track_not_a_hang():
     assert got["track_offsets"].shape[0] - 1 == 2
     if oracle_lib.ref_tracks() is not None:
         same(oracle_lib.ref_tracks_compute(**m), want)
+
+
+def test_tracks_builder_equals_one_shot():
+    """osfm_tracks_builder_*: the merge fed in several batches (pair order kept) yields exactly what
+    osfm_tracks_compute yields on the whole list; finish() may be called between feeds."""
+    from orthosfm_amd import capi, tracks as T
+    r = np.random.default_rng(9)
+    V = 7
+    sizes = r.integers(30, 60, V).astype(np.int32)
+    pairs, lists = [], []
+    for a in range(1, V):
+        for b in range(a):
+            k = int(r.integers(0, 25))
+            f1 = r.choice(sizes[a], k, replace=False)
+            f2 = r.choice(sizes[b], k, replace=False)
+            pairs.append((a, b)); lists.append(np.stack([f1, f2], 1).astype(np.int32))
+    offs = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int64)
+    corr = np.concatenate(lists)
+    parr = (capi.Pair * len(pairs))()
+    for i, (a, b) in enumerate(pairs):
+        parr[i].view_1, parr[i].view_2 = a, b
+    want = T.compute_flat(sizes, None, parr, offs, corr)
+    rec = np.zeros(len(pairs), dtype=[("status", np.int32), ("lowres_matches", np.int32), ("num_matches", np.int32),
+                                      ("num_inliers", np.int32), ("offset", np.int64)])
+    rec["status"] = capi.PAIR_MATCHED
+    rec["num_inliers"] = -1
+    rec["num_matches"] = np.diff(offs)
+    b = T.TracksBuilder(sizes)
+    cuts = [0, 5, 6, 14, len(pairs)]
+    pf = np.array(pairs, np.int32)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        sub = rec[lo:hi].copy()
+        base = int(offs[lo])
+        sub["offset"] = offs[lo:hi] - base                      # a batch's offsets are relative to its own buffer
+        b.feed(pf[lo:hi], sub, np.ascontiguousarray(corr[base:int(offs[hi])]))
+        if hi == 6:
+            b.finish()                                            # a look at the state changes nothing
+    got = b.finish()
+    for x, y in zip(got[:4], want[:4]):
+        assert np.array_equal(x, y)
+    assert got[4].num_tracks == want[4].num_tracks and got[4].num_invalid_tracks == want[4].num_invalid_tracks
+    assert b.num_pairs == len(pairs) and b.num_matches == int(offs[-1])
+    b.close()
