@@ -798,11 +798,14 @@ def main():
     barrier()
     t0 = time.perf_counter()
     kern_ms, kern_launches, macs, n_corr = 0.0, 0, 0, 0
+    shader_cycles = refclk_ticks = 0.0
     for _ in range(args.steps):
         out, st, n_corr = step()
         kern_ms += st.tile_kernel_ms
         kern_launches += st.tile_kernel_launches
         macs += st.mac_count
+        shader_cycles += st.tile_shader_cycles
+        refclk_ticks += st.tile_refclk_ticks
     barrier()
     dt = time.perf_counter() - t0
     dt = D.max_over_ranks(dt, world, device=tdev)
@@ -977,6 +980,11 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "match_tile_kernel<8, false, true, true>", "launches_per_step": kern_launches / args.steps,
                          "avg_launch_ms": avg_launch_s * 1e3,
+                         # the clock the chip held under this kernel (shader cycles over 100 MHz ticks of sampled
+                         # workgroups) and the fraction of the int8 peak AT that clock (the nominal peak is at 2.4 GHz)
+                         "held_clock_ghz": (shader_cycles / refclk_ticks * 0.1) if refclk_ticks > 0 else None,
+                         "frac_at_held_clock": (achieved / (I8_MFMA_PEAK_TOPS * (shader_cycles / refclk_ticks * 0.1) / 2.4))
+                                               if refclk_ticks > 0 else None,
                          "algorithmic_bytes_per_launch": st.algorithmic_bytes / max(st.tile_kernel_launches, 1),
                          "hbm_algorithmic_GBs": (st.algorithmic_bytes / max(st.tile_kernel_launches, 1))
                                                 / max(avg_launch_s, 1e-12) / 1e9},

@@ -262,6 +262,10 @@ typedef struct osfm_match_stats {
     int32_t cashash_kernel_launches;
     int32_t special_kernel_launches;
     double special_kernel_ms;    /* special descriptors (a byte > 127) against the other view */
+    /* sampled workgroups of the correction-free tile kernel: shader cycles and ticks of the 100 MHz
+     * counter they took; cycles / ticks * 100 MHz = the clock the chip held under that kernel */
+    double tile_shader_cycles;
+    double tile_refclk_ticks;
 } osfm_match_stats;
 OSFM_API int osfm_match_get_stats(const osfm_matcher *m, osfm_match_stats *out);
 

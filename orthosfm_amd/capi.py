@@ -67,7 +67,7 @@ class MatchStats(C.Structure):
                 ("lowres_kernel_launches", C.c_int32), ("reserved", C.c_int32),
                 ("lowres_mac_count", C.c_int64), ("cashash_kernel_ms", C.c_double),
                 ("cashash_kernel_launches", C.c_int32), ("special_kernel_launches", C.c_int32),
-                ("special_kernel_ms", C.c_double)]
+                ("special_kernel_ms", C.c_double), ("tile_shader_cycles", C.c_double), ("tile_refclk_ticks", C.c_double)]
 
 
 class BaProblem(C.Structure):

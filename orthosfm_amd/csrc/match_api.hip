@@ -109,6 +109,7 @@ struct osfm_matcher {
     DeviceBuffer d_problems[2], rowparts, colparts, out, keep, mark_off[2], counts[2];
     DeviceBuffer exact_items, exact_count, stage_in, flags;
     DeviceBuffer sp_parts, d_spjobs;      // match_special_kernel: results, job list
+    DeviceBuffer clock_probe;
     int special_max = 512;                // views with more special descriptors take the per-view operand forms
     DeviceBuffer d_m12_off, d_len12, d_corr_off, d_keep_pair, d_corr;
     DeviceBuffer d_jobs, d_inl, d_inl_count, d_corr2, d_gather_off;
@@ -383,6 +384,7 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
 
     OSFM_HIP_CHECK(hipMemsetAsync(m->exact_count.ptr, 0, 16, s));
     bool timed[2] = {false, false};
+    bool probed = false;
     for (int type = 0; type < 2; ++type) {
         const int np = (int)probs[type].size();
         if (np == 0) continue;
@@ -411,9 +413,16 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
             OSFM_HIP_CHECK(hipEventRecord(m->ev[type][1], s));
         } else {
             if (total_blocks[type] > 0) { OSFM_HIP_CHECK(hipEventRecord(m->ev[type][0], s)); timed[type] = true; }
+            unsigned long long *probe = nullptr;
+            if (type == 0 && mode.limit == 0) {
+                OSFM_RETURN_IF(m->clock_probe.reserve(16));
+                OSFM_HIP_CHECK(hipMemsetAsync(m->clock_probe.ptr, 0, 16, s));
+                probe = m->clock_probe.as<unsigned long long>();
+                probed = true;
+            }
             launch_match_tiles(type == 0 ? 8 : 4, needs_mask[type], any_special[type], any_c0[type],
                 any_corrected[type], dp, np, total_blocks[type],
-                m->rowparts.as<RowPart>(), m->colparts.as<ColPart>(), s);
+                m->rowparts.as<RowPart>(), m->colparts.as<ColPart>(), s, probe);
             if (timed[type]) OSFM_HIP_CHECK(hipEventRecord(m->ev[type][1], s));
             if (type == 0 && !spjobs.empty()) {
                 OSFM_HIP_CHECK(hipEventRecord(m->ev_sp[0], s));
@@ -443,7 +452,11 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
                 hc[type].size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     }
     OSFM_HIP_CHECK(hipMemcpyAsync(hexact, m->exact_count.ptr, 16, hipMemcpyDeviceToHost, s));
+    unsigned long long hprobe[2] = {0, 0};
+    if (probed) OSFM_HIP_CHECK(hipMemcpyAsync(hprobe, m->clock_probe.ptr, 16, hipMemcpyDeviceToHost, s));
     OSFM_HIP_CHECK(hipStreamSynchronize(s));
+    m->stats.tile_shader_cycles += (double)hprobe[0];
+    m->stats.tile_refclk_ticks += (double)hprobe[1];
     for (int p = 0; p < num_pairs; ++p) {
         int c = 0;
         for (int type = 0; type < 2; ++type)
@@ -1535,6 +1548,7 @@ int osfm_match_get_stats(const osfm_matcher *m, osfm_match_stats *out)
             out->lowres_kernel_launches += t.lowres_kernel_launches; out->lowres_mac_count += t.lowres_mac_count;
             out->cashash_kernel_ms += t.cashash_kernel_ms; out->cashash_kernel_launches += t.cashash_kernel_launches;
             out->special_kernel_launches += t.special_kernel_launches; out->special_kernel_ms += t.special_kernel_ms;
+            out->tile_shader_cycles += t.tile_shader_cycles; out->tile_refclk_ticks += t.tile_refclk_ticks;
         }
         return OSFM_OK;
     }

@@ -108,7 +108,8 @@ void launch_match_special(const MatchProblem *d_problems, const SpecialJob *d_jo
 // any_c0 / any_corrected: some problem has / lacks the correction-free column operand
 void launch_match_tiles(int ch, bool masked, bool any_special, bool any_c0, bool any_corrected,
     const MatchProblem *d_problems,
-    int num_problems, int total_blocks, RowPart *rowparts, ColPart *colparts, hipStream_t s);
+    int num_problems, int total_blocks, RowPart *rowparts, ColPart *colparts, hipStream_t s,
+    unsigned long long *clock_probe = nullptr);      // [2]: shader cycles / 100 MHz ticks, added up by sampled workgroups of the C0 kernel
 
 void launch_match_finish(const MatchProblem *d_problems, int num_problems,
     int max_n, const RowPart *rowparts, const ColPart *colparts, const RowPart *sp_parts, LoweTable tab,

@@ -569,7 +569,7 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
 template <int CH, bool MASKED, bool RAW, bool C0>
 __global__ __launch_bounds__(256, 2) void
 match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, int total_blocks,
-    RowPart *__restrict__ rowparts, ColPart *__restrict__ colparts)
+    RowPart *__restrict__ rowparts, ColPart *__restrict__ colparts, unsigned long long *__restrict__ clock_probe)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lin = xcd_remap(blockIdx.x, total_blocks);
@@ -585,19 +585,31 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
     const int seg = local - rb * pd.nseg;
     if (!MASKED && (rb < pd.nrb_main) != RAW) return;
     if (RAW && (pd.c0 != 0) != C0) return;
+    // Every 1024th workgroup of the correction-free kernel reports how many shader cycles (s_memtime)
+    // and how much wall time (the 100 MHz counter) its sweep took: their ratio is the clock the chip
+    // actually held under this kernel, which is what the matrix pipes' peak scales with (bench.py:
+    // roofline.frac_at_held_clock).  Both counters are scalar reads: no vector register is spent.
+    if (C0 && clock_probe != nullptr && (blockIdx.x & 1023) == 0) {
+        const unsigned long long c0 = (unsigned long long)clock64(), w0 = (unsigned long long)wall_clock64();
+        tile_body<CH, MASKED, RAW, C0>(pd, rb, seg, rowparts, colparts, smem);
+        const unsigned long long c1 = (unsigned long long)clock64(), w1 = (unsigned long long)wall_clock64();
+        if (threadIdx.x == 0) { atomicAdd(clock_probe, c1 - c0); atomicAdd(clock_probe + 1, w1 - w0); }
+        return;
+    }
     tile_body<CH, MASKED, RAW, C0>(pd, rb, seg, rowparts, colparts, smem);
 }
 
 void launch_match_tiles(int ch, bool masked, bool any_special, bool any_c0, bool any_corrected,
     const MatchProblem *d_problems, int num_problems, int total_blocks, RowPart *rowparts,
-    ColPart *colparts, hipStream_t s)
+    ColPart *colparts, hipStream_t s, unsigned long long *clock_probe)
 {
     if (total_blocks <= 0) return;
     const int d = ch * 16;
     const size_t lds = std::max<size_t>(2 * (size_t)kTileCols * d, 16384) + 2 * 64 * 4 + 8 * 4 * 64 * sizeof(ColPart) + 32 * 256 * 4;
     const dim3 grid(total_blocks), block(256);
 #define OSFM_LAUNCH_TILES(CHV, MASKEDV, RAWV, C0V) \
-    hipLaunchKernelGGL((match_tile_kernel<CHV, MASKEDV, RAWV, C0V>), grid, block, lds, s, d_problems, num_problems, total_blocks, rowparts, colparts)
+    for (unsigned long long *PROBE = ((C0V) ? clock_probe : nullptr), *once_ = (unsigned long long *)1; once_; once_ = nullptr) \
+    hipLaunchKernelGGL((match_tile_kernel<CHV, MASKEDV, RAWV, C0V>), grid, block, lds, s, d_problems, num_problems, total_blocks, rowparts, colparts, PROBE)
     if (masked) {
         if (ch == 8) OSFM_LAUNCH_TILES(8, true, false, false); else OSFM_LAUNCH_TILES(4, true, false, false);
         return;

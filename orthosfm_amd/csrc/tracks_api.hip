@@ -124,53 +124,58 @@ static int builder_finish(const osfm_tracks_builder *b, const uint8_t *colors,
     const int64_t G = voff[num_views];
     if (G > 0 && !track_ids) { set_error("tracks_compute: track_ids is null"); return OSFM_E_ARG; }
 
-    // remove_invalid_tracks (:149-203): empty tracks, tracks with two features of one view
+    // remove_invalid_tracks (:149-203: empty tracks, tracks with two features of one view) and the
+    // output in ONE walk over each track's list: the walk is a chain of cache misses (the nodes of a
+    // track lie all over the feature array), and two walks -- validate, then write -- were most of
+    // this function's time.  A track is written where it would go and discarded (the write position
+    // rolls back) when a second feature of one view turns up.
     const int64_t nt = (int64_t)head.size();
     std::vector<int32_t> map((size_t)nt, -1);
     std::vector<int64_t> seen((size_t)num_views, -1);
     int32_t invalid = 0, valid = 0;
-    int64_t kept_features = 0;
+    int64_t nf = 0;
+    bool overflow = false;
     for (int64_t t = 0; t < nt; ++t) {
         if (size[t] == 0) continue;
         bool bad = twice[t] != 0;
+        const int64_t start = nf;
+        float col[4] = {0.0f, 0.0f, 0.0f, 0.0f};                                // :133-143
         for (int64_t g = head[t]; g >= 0 && !bad; g = nxt[g]) {
             // view of node g: the last voff entry <= g (views are few: binary search)
             int lo = 0, hi = num_views - 1;
             while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (voff[mid] <= g) lo = mid; else hi = mid - 1; }
-            if (seen[lo] == t) bad = true;
+            if (seen[lo] == t) { bad = true; break; }
             seen[lo] = t;
+            if (nf < feature_capacity) {
+                track_features[2 * nf] = lo;
+                track_features[2 * nf + 1] = (int32_t)(g - voff[lo]);
+            } else {
+                overflow = true;
+            }
+            ++nf;
+            for (int c = 0; c < 3; ++c) col[c] += colors ? (float)colors[3 * g + c] : 0.0f;
+            col[3] += 1.0f;
         }
-        if (bad) { invalid++; continue; }
+        if (bad) { invalid++; nf = start; continue; }
+        if (valid < track_capacity) {
+            track_offsets[valid] = start;
+            for (int c = 0; c < 3; ++c) track_colors[3 * valid + c] = (uint8_t)(col[c] / col[3] + 0.5f);
+        } else {
+            overflow = true;
+        }
         map[t] = valid++;
-        kept_features += size[t];
     }
+    const int64_t kept_features = nf;
     for (int64_t g = 0; g < G; ++g) track_ids[g] = tid[g] >= 0 ? map[tid[g]] : -1;
     if (summary) {
         summary->num_tracks = valid;
         summary->num_invalid_tracks = invalid;
         summary->num_features = kept_features;
     }
-    if (valid > track_capacity || kept_features > feature_capacity) {
+    if (overflow || valid > track_capacity || kept_features > feature_capacity) {
         set_error("tracks_compute: %d tracks / %lld features exceed the output capacity (%lld / %lld)",
             valid, (long long)kept_features, (long long)track_capacity, (long long)feature_capacity);
         return OSFM_E_CAPACITY;
-    }
-    int64_t nf = 0;
-    for (int64_t t = 0; t < nt; ++t) {
-        if (map[t] < 0) continue;
-        const int32_t o = map[t];
-        track_offsets[o] = nf;
-        float col[4] = {0.0f, 0.0f, 0.0f, 0.0f};                                // :133-143
-        for (int64_t g = head[t]; g >= 0; g = nxt[g]) {
-            int lo = 0, hi = num_views - 1;
-            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (voff[mid] <= g) lo = mid; else hi = mid - 1; }
-            track_features[2 * nf] = lo;
-            track_features[2 * nf + 1] = (int32_t)(g - voff[lo]);
-            ++nf;
-            for (int c = 0; c < 3; ++c) col[c] += colors ? (float)colors[3 * g + c] : 0.0f;
-            col[3] += 1.0f;
-        }
-        for (int c = 0; c < 3; ++c) track_colors[3 * o + c] = (uint8_t)(col[c] / col[3] + 0.5f);
     }
     track_offsets[valid] = nf;
     return OSFM_OK;

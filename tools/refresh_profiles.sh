@@ -8,7 +8,7 @@ tag=${2:-vX}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $R/gpurun_out/bench_$tag.log 2>&1
-tail -1 $R/gpurun_out/bench_$tag.log > $R/gpurun_out/${round}_bench_$tag.json
+grep "^{" $R/gpurun_out/bench_$tag.log | tail -1 > $R/gpurun_out/${round}_bench_$tag.json
 rm -rf $R/gpurun_out/prof_$tag
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -- python $R/bench.py --steps 5 --warmup 2 --no-e2e --no-cpu-baseline > $R/gpurun_out/prof_$tag.log 2>&1
 db=$(find $R/gpurun_out/prof_$tag -name "*.db" | head -1)
@@ -23,7 +23,7 @@ rm -rf $R/gpurun_out/prof_$tag        # the trace itself is large; the summary i
 # baseline, no drop-in / realistic-operand legs), so that the AverageNs of match_tile_kernel<8, false, true, true>
 # IS roofline.avg_launch_ms of the line printed by the same command.
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_h_$tag -- python $R/bench.py --steps 10 --warmup 2 --no-ba --no-verify --no-e2e --no-cpu-baseline --no-realistic > $R/gpurun_out/prof_h_$tag.log 2>&1
-tail -1 $R/gpurun_out/prof_h_$tag.log > $R/gpurun_out/${round}_bench_headline_only_$tag.json
+grep "^{" $R/gpurun_out/prof_h_$tag.log | tail -1 > $R/gpurun_out/${round}_bench_headline_only_$tag.json
 db=$(find $R/gpurun_out/prof_h_$tag -name "*.db" | head -1)
 if [ -n "$db" ]; then
   python $R/tools/rocpd_stats.py $db > $R/gpurun_out/${round}_bench_headline_only_kernel_stats_$tag.csv
