@@ -108,7 +108,7 @@ struct osfm_matcher {
     // scratch (grow-only)
     DeviceBuffer d_problems[2], rowparts, colparts, out, keep, mark_off[2], counts[2];
     DeviceBuffer exact_items, exact_count, stage_in, flags;
-    DeviceBuffer sp_parts, d_spjobs;      // match_special_kernel: results, job list
+    DeviceBuffer sp_parts, sp_col, d_spjobs;      // match_special_kernel: row results, column results, job list
     DeviceBuffer clock_probe;
     int special_max = 512;                // views with more special descriptors take the per-view operand forms
     DeviceBuffer d_m12_off, d_len12, d_corr_off, d_keep_pair, d_corr;
@@ -218,7 +218,9 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
     res->counts.assign(num_pairs, 0);
     std::vector<MatchProblem> probs[2];
     std::vector<SpecialJob> spjobs;
-    int64_t sp_recs = 0;
+    struct SpEntry { int problem, side, view, units, nchunk; };
+    std::vector<SpEntry> spentries;
+    int64_t sp_recs = 0, sp_cols = 0;
     std::vector<int64_t> mark_off[2];
     int64_t out_ints = 0, rowpart_recs = 0, colpart_recs = 0, keep_bytes = 0, total_queries = 0;
     int total_blocks[2] = {0, 0}, max_n[2] = {0, 0};
@@ -302,10 +304,8 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
                     if (ns == 0) continue;
                     const int nchunk = (no + kSpChunk - 1) / kSpChunk;
                     pr.sp_row_off[side] = sp_recs; sp_recs += (int64_t)nchunk * round_up(ns, 32);
-                    pr.sp_col_off[side] = sp_recs; sp_recs += round_up(no, 32);
-                    // pad: the view whose descriptors the job streams (sort key below)
-                    for (int c = 0; c < nchunk; ++c)
-                        spjobs.push_back({(int)probs[type].size(), side, c, side == 0 ? pl.v2 : pl.v1});
+                    pr.sp_col_off[side] = sp_cols; sp_cols += round_up(no, 32);
+                    spentries.push_back({(int)probs[type].size(), side, side == 0 ? pl.v2 : pl.v1, (ns + 31) / 32, nchunk});
                 }
             }
             if (!empty && !limited) (pr.c0 ? any_c0 : any_corrected)[type] = true;
@@ -367,15 +367,36 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
     OSFM_RETURN_IF(m->exact_items.reserve((size_t)std::max<int64_t>(total_queries, 1) * sizeof(ExactItem)));
     OSFM_RETURN_IF(m->exact_count.reserve(16));
     OSFM_RETURN_IF(m->sp_parts.reserve((size_t)std::max<int64_t>(sp_recs, 1) * sizeof(RowPart)));
-    OSFM_RETURN_IF(m->d_spjobs.reserve(std::max<size_t>(spjobs.size(), 1) * sizeof(SpecialJob)));
     hipStream_t s = m->stream;
     // Workgroups that stream the same 4096 descriptors of the same view run next to each other:
     // the chunk (512 KB) is then fetched from HBM once per L2 instead of once per pair (in
     // pair order the streamed view of side 0 changes with every pair: 3 GB of HBM reads per
     // 1225 pairs for 128 MB of distinct descriptors).
-    std::stable_sort(spjobs.begin(), spjobs.end(), [](const SpecialJob &x, const SpecialJob &y) {
-        return x.pad != y.pad ? x.pad < y.pad : x.chunk < y.chunk;
+    // Jobs of match_special_kernel: the entries (one side of one problem) grouped by the view they
+    // stream -- up to kSpSlots one-unit entries share a workgroup, an entry with more units has workgroups of
+    // its own -- and, per group, one job per chunk; groups of one view next to each other, so that a chunk
+    // (512 KB) is fetched from HBM once per L2 and not once per pair.
+    std::stable_sort(spentries.begin(), spentries.end(), [](const SpEntry &x, const SpEntry &y) {
+        return x.view != y.view ? x.view < y.view : x.units < y.units;
     });
+    for (size_t e = 0; e < spentries.size();) {
+        SpecialJob j;
+        memset(&j, 0, sizeof(j));
+        const SpEntry &f = spentries[e];
+        if (f.units > 1) {
+            j.problem[0] = f.problem; j.side[0] = f.side; j.count = 0;
+            ++e;
+        } else {
+            int c = 0;
+            while (c < kSpSlots && e < spentries.size() && spentries[e].view == f.view && spentries[e].units == 1) {
+                j.problem[c] = spentries[e].problem; j.side[c] = spentries[e].side; ++c; ++e;
+            }
+            j.count = c;
+        }
+        for (int c = 0; c < f.nchunk; ++c) { j.chunk = c; spjobs.push_back(j); }
+    }
+    OSFM_RETURN_IF(m->sp_col.reserve((size_t)std::max<int64_t>(sp_cols, 1) * 4));
+    OSFM_RETURN_IF(m->d_spjobs.reserve(std::max<size_t>(spjobs.size(), 1) * sizeof(SpecialJob)));
     if (!spjobs.empty())
         OSFM_HIP_CHECK(hipMemcpyAsync(m->d_spjobs.ptr, spjobs.data(), spjobs.size() * sizeof(SpecialJob),
             hipMemcpyHostToDevice, s));
@@ -426,11 +447,13 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
             if (timed[type]) OSFM_HIP_CHECK(hipEventRecord(m->ev[type][1], s));
             if (type == 0 && !spjobs.empty()) {
                 OSFM_HIP_CHECK(hipEventRecord(m->ev_sp[0], s));
-                launch_match_special(dp, m->d_spjobs.as<SpecialJob>(), (int)spjobs.size(), m->sp_parts.as<RowPart>(), s);
+                launch_match_special(dp, m->d_spjobs.as<SpecialJob>(), (int)spjobs.size(), m->sp_parts.as<RowPart>(),
+                    m->sp_col.as<int32_t>(), s);
                 OSFM_HIP_CHECK(hipEventRecord(m->ev_sp[1], s));
             }
             launch_match_finish(dp, np, max_n[type], m->rowparts.as<RowPart>(),
-                m->colparts.as<ColPart>(), m->sp_parts.as<RowPart>(), tab, 0, m->exact_items.as<ExactItem>(), ecount, ecap, s);
+                m->colparts.as<ColPart>(), m->sp_parts.as<RowPart>(), m->sp_col.as<int32_t>(), tab, 0,
+                m->exact_items.as<ExactItem>(), ecount, ecap, s);
             launch_exact_scan(type == 0 ? 128 : 64, dp, m->exact_items.as<ExactItem>(), ecount, ecap,
                 tab, s);
         }

@@ -55,9 +55,10 @@ struct MatchProblem {
     //   side 0: special rows of set 1 (A_special) x all of set 2;  side 1: special rows of
     //   set 2 (B_special) x all of set 1.
     // sp_row_off[side]: RowPart[chunks of the other set][ns rounded up to 32] -- the complete
-    //   (best, second, index) of every special descriptor per 4096-candidate chunk;
-    // sp_col_off[side]: RowPart[n of the other set] -- for every descriptor of the other set
-    //   its exact (best, second, index) over the special descriptors of this side.
+    //   (best stream, its maximum, second largest stream maximum) of every special descriptor per
+    //   4096-candidate chunk;
+    // sp_col_off[side]: int32[n of the other set] in the column buffer -- for every descriptor of the
+    //   other set its largest inner product over the special descriptors of this side.
     int32_t sp;
     int32_t nsA, nsB;                  // special descriptors of set 1 / set 2
     const int8_t *B_special;           // [nsB padded to 256][128], value - 128 form
@@ -100,9 +101,12 @@ struct ExactItem { int32_t problem; int32_t dir; int32_t query; };
 // One workgroup of match_special_kernel: the special descriptors of one side of a problem
 // against one chunk of kSpChunk descriptors of the other set.
 constexpr int kSpChunk = 4096;
-struct SpecialJob { int32_t problem, side, chunk, pad; };
+// count > 0: `count` entries (problem[e], side[e]) with ONE unit of special rows each, all streaming the same
+// view (count <= kSpSlots); count == 0: entry 0 alone, with as many units as it has (passes of kSpSlots).
+constexpr int kSpSlots = 2;             // units of 32 special rows a workgroup carries through one pass over a chunk
+struct SpecialJob { int32_t problem[4], side[4]; int32_t count, chunk, pad0, pad1; };
 void launch_match_special(const MatchProblem *d_problems, const SpecialJob *d_jobs, int num_jobs,
-    RowPart *sp_parts, hipStream_t s);
+    RowPart *sp_parts, int32_t *sp_col, hipStream_t s);
 
 // any_special: some problem has row blocks behind nrb_main (gathered special rows);
 // any_c0 / any_corrected: some problem has / lacks the correction-free column operand
@@ -112,7 +116,7 @@ void launch_match_tiles(int ch, bool masked, bool any_special, bool any_c0, bool
     unsigned long long *clock_probe = nullptr);      // [2]: shader cycles / 100 MHz ticks, added up by sampled workgroups of the C0 kernel
 
 void launch_match_finish(const MatchProblem *d_problems, int num_problems,
-    int max_n, const RowPart *rowparts, const ColPart *colparts, const RowPart *sp_parts, LoweTable tab,
+    int max_n, const RowPart *rowparts, const ColPart *colparts, const RowPart *sp_parts, const int32_t *sp_col, LoweTable tab,
     int force_exact, ExactItem *exact_items, int32_t *exact_count, int exact_cap,
     hipStream_t s);
 

@@ -724,7 +724,11 @@ rescan_groups(const MatchProblem &pd, const int (&q)[2], const int (&idx1)[2], c
         for (int j = 0; j < J; ++j) {
             const int n = j * CPL + k;
             int cd;
-            if (DIR == 0) {
+            if (kind[u] == 3) {
+                // a special query's winning stream (match_special_kernel): 32 candidates at a stride of 128
+                cd = idx1[u] + 128 * n;
+                if (cd >= (DIR == 0 ? pd.n2 : pd.n1)) cd = -1;
+            } else if (DIR == 0) {
                 cd = base0 + (n >> 1) * kTileCols + (n & 1) * 32 + lr;
                 if (cd >= pd.n2 || (!kind[u] && n >= 2 * kGroupTiles)) cd = -1;
             } else {
@@ -734,7 +738,7 @@ rescan_groups(const MatchProblem &pd, const int (&q)[2], const int (&idx1)[2], c
             }
             cand[u][j] = cd;
         }
-        if (DIR == 1 && idx1[u] >= pd.nrb_main) {
+        if (DIR == 1 && kind[u] != 3 && idx1[u] >= pd.nrb_main) {
             // a block of gathered special rows (uniform, rare): back to the original rows,
             // all look-ups of the query together and BEFORE any descriptor load -- a
             // look-up between the loads makes the compiler drain the load counter at
@@ -789,11 +793,49 @@ rescan_groups(const MatchProblem &pd, const int (&q)[2], const int (&idx1)[2], c
     }
 }
 
+// Exact (best, second, index) of query q of direction dir over the special descriptors of the OTHER set
+// (value - 128 form with corrections, as everywhere in this kernel); the whole wave works on one query.
+template <int DIM>
+__device__ __forceinline__ void
+scan_specials(const MatchProblem &pd, int dir, int q, int lane, int &best_out, int &second_out, int &idx_out)
+{
+    constexpr int LPC = DIM / 16, CPL = 64 / LPC;
+    const int c = lane % LPC, k = lane / LPC;
+    const int8_t *Q = dir == 0 ? pd.A : pd.B;
+    const int8_t *Cm = dir == 0 ? pd.B_special : pd.A_special;
+    const int32_t *corrC = dir == 0 ? pd.corrB_special : pd.corrA_special;
+    const int32_t *map = dir == 0 ? pd.special_map_B : pd.special_map;
+    const int ns = dir == 0 ? pd.nsB : pd.nsA;
+    const int4 qv = *reinterpret_cast<const int4 *>(Q + (size_t)q * DIM + c * 16);
+    const int corr_q = (dir == 0 ? pd.corrA : pd.corrB)[q];
+    int kbest = INT_MIN, ksec = INT_MIN;
+    for (int base = 0; base < ns; base += CPL) {
+        const int slot = base + k;
+        const bool live = slot < ns;
+        const int4 cv = *reinterpret_cast<const int4 *>(Cm + (size_t)(live ? slot : 0) * DIM + c * 16);
+        int acc = __builtin_amdgcn_sdot4(qv.x, cv.x, 0, false);
+        acc = __builtin_amdgcn_sdot4(qv.y, cv.y, acc, false);
+        acc = __builtin_amdgcn_sdot4(qv.z, cv.z, acc, false);
+        acc = __builtin_amdgcn_sdot4(qv.w, cv.w, acc, false);
+        acc += dpp_mov<kDppXor1>(acc, 0);
+        acc += dpp_mov<kDppXor2>(acc, 0);
+        if (LPC == 8) acc += dpp_mov<kDppHalfMirror>(acc, 0);
+        const int key = live ? (acc + corr_q + corrC[live ? slot : 0]) * 512 + slot : INT_MIN;
+        ksec = med3a(kbest, ksec, key);
+        kbest = max(kbest, key);
+    }
+    const int wbest = wave_max(kbest);
+    const int wsec = wave_max(kbest == wbest ? ksec : kbest);
+    best_out = wbest >> 9;
+    second_out = wsec == INT_MIN ? INT_MIN : wsec >> 9;
+    idx_out = map[wbest & 511];
+}
+
 template <int DIM, bool SIGNED>
 __global__ __launch_bounds__(128) void
 match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__restrict__ rowparts,
-    const ColPart *__restrict__ colparts, const RowPart *__restrict__ sp_parts, LoweTable tab, int force_exact,
-    ExactItem *__restrict__ exact_items, int32_t *__restrict__ exact_count, int exact_cap,
+    const ColPart *__restrict__ colparts, const RowPart *__restrict__ sp_parts, const int32_t *__restrict__ sp_col,
+    LoweTable tab, int force_exact, ExactItem *__restrict__ exact_items, int32_t *__restrict__ exact_count, int exact_cap,
     int blocks_per_dir, int total_blocks)
 {
     // every XCD works through a contiguous run of problems, so the descriptors the
@@ -813,12 +855,14 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
 
     // ip1 / idx1: exact best; ip2: second largest GROUP best (lower bound of the
     // true second); code: group of the best (dir 1), idx1 = its row block there
-    // kind1 = 2: (ip1, ip2, idx1) are exact values from match_special_kernel, nothing to re-score
+    // kind1 = 3: a special query: (ip1, idx1) = the largest stream maximum of match_special_kernel and the
+    // first column of that stream (its 32 candidates follow at a stride of 128), ip2 the second largest
+    // stream maximum
     int ip1 = INT_MIN, ip2 = INT_MIN, idx1 = 0, code = 0, kind1 = 0;
     // Problems whose special descriptors went through match_special_kernel (pd.sp): a special
-    // query takes its complete result from there (one partial per chunk of candidates); any
-    // other query merges the tile kernel's partials below and then the exact top-2 over the
-    // OTHER set's special descriptors, which the tile kernel saw as blanks.
+    // query takes its result from there (one partial per chunk of candidates); any other query
+    // merges the tile kernel's partials below and then the largest inner product over the OTHER
+    // set's special descriptors, which the tile kernel saw as blanks.
     int sp_slot = -1;
     if (active && nc > 0 && pd.sp) {
         const int ns_mine = dir == 0 ? pd.nsA : pd.nsB;
@@ -832,9 +876,13 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
                 ip2 = max(max(ip2, p.ip_second), min(ip1, p.ip_best));
                 if (p.ip_best >= ip1 && p.ip_best != INT_MIN) { ip1 = p.ip_best; idx1 = p.idx_best; }   // later chunk wins ties
             }
-            kind1 = 2;
+            kind1 = 3;
         }
     }
+    // an ordinary query whose best candidate is (or ties with) a special descriptor of the other set:
+    // sp_m1 = the best of the ordinary candidates (exact value), the special ones are scanned below
+    bool sp_scan = false;
+    int sp_m1 = INT_MIN;
     if (active && nc > 0 && sp_slot < 0) {
         if (dir == 0) {
             const int64_t stride = (int64_t)pd.nrb * kRowsPerBlock;
@@ -888,14 +936,15 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
             }
         }
         if (pd.sp && (dir == 0 ? pd.nsB : pd.nsA) > 0) {
-            // the other set's special descriptors as candidates of this query (exact values)
-            const RowPart t = sp_parts[pd.sp_col_off[dir ^ 1] + q];
-            ip2 = max(max(ip2, t.ip_second), min(ip1, t.ip_best));
-            if (t.ip_best >= ip1 && t.ip_best != INT_MIN) {
-                // the best is a special descriptor: ip2 = max(best of the others -- an exact score or a
-                // blank's 0 --, second among the special ones) is exact as well
-                ip1 = t.ip_best; kind1 = 2;
-                idx1 = (dir == 0 ? pd.special_map_B : pd.special_map)[t.idx_best];
+            // the other set's special descriptors as candidates of this query: their largest inner product
+            const int t1 = sp_col[pd.sp_col_off[dir ^ 1] + q];
+            if (t1 >= ip1 && t1 != INT_MIN) {
+                // the best is a special descriptor (or ties with one): which one, and the second best among
+                // them, is found by scanning them -- only if the ratio test can still pass (the best of the
+                // ordinary candidates, an exact score or a blank's 0, bounds the second best from below)
+                sp_m1 = ip1; ip1 = t1; sp_scan = true;
+            } else {
+                ip2 = max(ip2, t1);
             }
         }
     }
@@ -905,13 +954,17 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
     int res = -1;
     if (active && nc > 0 && !exact) {
         // optimistic test against the lower bound of the second best
-        res = accept_match(ip1, ip2, kind1 == 2 ? idx1 : 0, tab);
+        res = accept_match(ip1, sp_scan ? max(sp_m1, ip2) : ip2, 0, tab);
         if (res >= 0) {
-            if (ip1 < 0) res = 0;             // reference state (0, 0, idx 0): nothing to refine
-            else if (ip2 == ip1) exact = true;  // accepted despite a tie for best (NaN accept /
-                                                // ratio >= 1): defer to the sequential-scan kernel
-            else if (kind1 != 2) refine = true; // kind 2: exact already, res is final
+            if (ip1 < 0) { res = 0; sp_scan = false; }   // reference state (0, 0, idx 0): nothing to refine
+            else if ((sp_scan ? sp_m1 : ip2) == ip1) { exact = true; sp_scan = false; }   // accepted despite a tie for best
+                                                // (NaN accept / ratio >= 1): defer to the sequential-scan kernel
+            else if (!sp_scan) refine = true;
+        } else {
+            sp_scan = false;
         }
+    } else {
+        sp_scan = false;
     }
     // Queries that pass get their best group re-scored, one query at a time by
     // the whole wave.  The rescan also yields the exact best of the group: it
@@ -946,6 +999,24 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
         // reference keeps depends on scan order -- leave it to the sequential scan
         if (res >= 0 && rsecond == rbest) exact = true;
     }
+    // Ordinary queries whose best candidate is a special descriptor of the other set (rare): the whole
+    // wave scores that set's special descriptors for one query at a time -- eight lanes per candidate,
+    // exact top-2 on keys value * 512 + slot (slots < 512 = special_kernel_max; inner products < 2^22 here:
+    // the wrap-exact path has taken anything above 65535).
+    unsigned long long todo2 = __ballot(sp_scan);
+    while (todo2) {
+        const int src = __ffsll((long long)todo2) - 1;
+        todo2 &= todo2 - 1;
+        const int qs = __builtin_amdgcn_readlane(q, src);
+        int wb, ws, wi;
+        scan_specials<DIM>(pd, dir, qs, lane, wb, ws, wi);
+        if (lane == src) { rbest = wb; rsecond = ws; ridx = wi; }
+    }
+    if (sp_scan) {
+        rsecond = max(max(rsecond, sp_m1), ip2);
+        res = accept_match(rbest, rsecond, ridx, tab);
+        if (res >= 0 && rsecond == rbest) exact = true;
+    }
     if (exact) {
         const int slot = atomicAdd(exact_count, 1);
         if (slot < exact_cap) {
@@ -958,7 +1029,7 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
 }
 
 void launch_match_finish(const MatchProblem *d_problems, int num_problems, int max_n,
-    const RowPart *rowparts, const ColPart *colparts, const RowPart *sp_parts, LoweTable tab, int force_exact,
+    const RowPart *rowparts, const ColPart *colparts, const RowPart *sp_parts, const int32_t *sp_col, LoweTable tab, int force_exact,
     ExactItem *exact_items, int32_t *exact_count, int exact_cap, hipStream_t s)
 {
     if (num_problems <= 0 || max_n <= 0) return;
@@ -968,10 +1039,10 @@ void launch_match_finish(const MatchProblem *d_problems, int num_problems, int m
     const dim3 grid((unsigned)total);
     if (tab.is_signed)
         hipLaunchKernelGGL((match_finish_kernel<64, true>), grid, dim3(128), 0, s, d_problems, rowparts,
-            colparts, sp_parts, tab, force_exact, exact_items, exact_count, exact_cap, blocks_per_dir, (int)total);
+            colparts, sp_parts, sp_col, tab, force_exact, exact_items, exact_count, exact_cap, blocks_per_dir, (int)total);
     else
         hipLaunchKernelGGL((match_finish_kernel<128, false>), grid, dim3(128), 0, s, d_problems, rowparts,
-            colparts, sp_parts, tab, force_exact, exact_items, exact_count, exact_cap, blocks_per_dir, (int)total);
+            colparts, sp_parts, sp_col, tab, force_exact, exact_items, exact_count, exact_cap, blocks_per_dir, (int)total);
 }
 
 // ---------------------------------------------------------------------------
