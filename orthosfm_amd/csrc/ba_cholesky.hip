@@ -364,6 +364,7 @@ struct CholFlow {
     int *flags;           // see flow_*_flag
     int *info;
     const LmDev *lm;
+    double *x;            // solution of the reduced system (n entries used), written by the backward phase; null: factor only
     int ld, nblk, epoch;
     long long *trace;     // diagnostics (tools/chol_flow_trace.py): [nblk + 1][16] wall_clock64 stamps of the D's, or null
 };
@@ -374,6 +375,10 @@ __device__ __forceinline__ int flow_inv_flag(const CholFlow &f, int k) { return 
 __device__ __forceinline__ int flow_box_flag(const CholFlow &f, int r, int slot) { return (f.nblk + 2) * f.nblk + r * (kFlowW + 1) + slot; }
 __device__ __forceinline__ int flow_abort_flag(const CholFlow &f) { return (f.nblk + 2) * f.nblk + (f.nblk + 1) * (kFlowW + 1); }
 __device__ __forceinline__ double *flow_box(const CholFlow &f, int r, int slot) { return f.mailbox + ((size_t)r * (kFlowW + 1) + slot) * NB * NB; }
+// backward phase: block k of the solution, sc1 copy in f.x / same-XCD copy behind the tiles of the mailbox
+__device__ __forceinline__ int flow_x_flag(const CholFlow &f, int k) { return flow_abort_flag(f) + 1 + k; }
+__device__ __forceinline__ int flow_xbox_flag(const CholFlow &f, int k) { return flow_abort_flag(f) + 1 + f.nblk + k; }
+__device__ __forceinline__ double *flow_xbox(const CholFlow &f, int k) { return f.mailbox + (size_t)(f.nblk + 1) * (kFlowW + 1) * NB * NB + (size_t)k * NB; }
 __device__ __forceinline__ int flow_xcc() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15; }
 
 // plain store / flag for a reader behind the same L2 (no cache-policy bits)
@@ -473,6 +478,7 @@ chol_flow_kernel(CholFlow f)
     __shared__ __attribute__((aligned(16))) double Li[NB][NB + 1];
     __shared__ __attribute__((aligned(16))) double Mt[NB][NB + 1];
     __shared__ int lds_word;
+    __shared__ double sv[NB], xv[NB];
     const int nblk = f.nblk, ld = f.ld;
     const int tid = threadIdx.x;
     const FlowPos p = flow_pos();
@@ -633,6 +639,60 @@ chol_flow_kernel(CholFlow f)
         if (w.pending_flag >= 0) __hip_atomic_store(f.flags + w.pending_flag, f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (has_diag) __hip_atomic_store(f.flags + flow_inv_flag(f, row), f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    w.pending_flag = -1;
+    if (!has_diag || f.x == nullptr) return;
+
+    // ---- backward substitution, same launch: x_k = inv(L_kk)^T (y_k - sum_{i > k} L_ik^T x_i) ----------------
+    // D_k owns block k of the solution.  It still holds inv(L_kk) in LDS; y_k is row 0 of the right-hand side
+    // tile (nblk, k); the tiles L(i, k) of ITS column come in from i = nblk - 1 downwards, each fetched while
+    // the workgroup waits for x_i (two LDS buffers), so that a step costs the hand-off of 32 doubles and two
+    // 32 x 32 matrix-vector products -- the single-workgroup kernel it replaces walked the same chain at
+    // 3.7 us per step with a trip to L2 for every block row.
+    auto tile_into = [&](int i, double (*dst)[NB + 1]) -> bool {
+        const bool from_d = i - row <= kFlowW;
+        const int how = flow_wait(f, w, flow_tile_flag(f, i, row), from_d ? flow_box_flag(f, i, i - row) : -1);
+        if (!how) return false;
+        if (how == 2) flow_load_tile(flow_box(f, i, i - row), NB, dst, p);
+        else flow_load_tile(f.Lmat + (size_t)(i * NB) * ld + row * NB, ld, dst, p);
+        return true;
+    };
+    {
+        const bool from_d = nblk - row <= kFlowW;
+        const int how = flow_wait(f, w, flow_tile_flag(f, nblk, row), from_d ? flow_box_flag(f, nblk, nblk - row) : -1);
+        if (!how) return;
+        if (tid < NB) sv[tid] = load_sc1(how == 2 ? flow_box(f, nblk, nblk - row) + tid : f.Lmat + (size_t)(nblk * NB) * ld + row * NB + tid);
+    }
+    int cur = 0;
+    if (nblk - 1 > row && !tile_into(nblk - 1, Xr)) return;
+    for (int i = nblk - 1; i > row; --i) {
+        double (*T)[NB + 1] = cur ? Xc : Xr;
+        if (i - 1 > row && !tile_into(i - 1, cur ? Xr : Xc)) return;
+        const int how = flow_wait(f, w, flow_x_flag(f, i), flow_xbox_flag(f, i));
+        if (!how) return;
+        if (tid < NB) xv[tid] = load_sc1(how == 2 ? flow_xbox(f, i) + tid : f.x + (size_t)i * NB + tid);
+        lds_barrier();
+        if (tid < NB) {
+            double a = sv[tid];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) a = fma(-T[r][tid], xv[r], a);
+            sv[tid] = a;
+        }
+        lds_barrier();
+        cur ^= 1;
+    }
+    lds_barrier();
+    if (tid < NB) {
+        // x_k[m] = sum_{c >= m} inv(L)[c][m] * s[c]
+        double v = 0.0;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) v += (c >= tid) ? Li[c][tid] * sv[c] : 0.0;
+        flow_xbox(f, row)[tid] = v;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) store_flag_plain(f.flags + flow_xbox_flag(f, row), my_tag);
+        store_sc1(f.x + (size_t)row * NB + tid, v);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) __hip_atomic_store(f.flags + flow_x_flag(f, row), f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // diagnostics: where the D workgroups of the most recent factorisation spent their time
@@ -673,13 +733,13 @@ int chol_flow_capacity()
 int chol_flow_flag_count(int n)
 {
     const int nblk = cholesky_padded_dim(n) / NB;
-    return (nblk + 2) * nblk + (nblk + 1) * (kFlowW + 1) + 16;
+    return (nblk + 2) * nblk + (nblk + 1) * (kFlowW + 1) + 1 + 2 * nblk + 16;
 }
 
 size_t chol_flow_mailbox_bytes(int n)
 {
     const int nblk = cholesky_padded_dim(n) / NB;
-    return (size_t)(nblk + 1) * (kFlowW + 1) * NB * NB * sizeof(double);
+    return ((size_t)(nblk + 1) * (kFlowW + 1) * NB * NB + (size_t)nblk * NB) * sizeof(double);
 }
 
 // The right-hand side's last block: y_k = b_k inv(L_kk)^T for k = nblk - 1 (every earlier
@@ -787,9 +847,12 @@ void launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double
         f.mailbox = flow_mailbox;
         f.A = A; f.Lmat = Lmat; f.Ldiag = Ldiag; f.flags = flow_flags; f.info = info; f.lm = lm;
         f.ld = N; f.nblk = nblk; f.epoch = flow_epoch; f.trace = g_flow_trace;
+        // the backward substitution runs inside the same launch; x has room for the padded system (N entries)
+        f.x = getenv("OSFM_BA_FLOW_FACTOR_ONLY") ? nullptr : x;
         hipLaunchKernelGGL(chol_flow_kernel, dim3(flow_groups), dim3(256), 0, s, f);
-        hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(1024), (size_t)2 * N * sizeof(double), s, Lmat, N,
-            nblk, n, Ldiag, x, lm);
+        if (!f.x)
+            hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(1024), (size_t)2 * N * sizeof(double), s, Lmat, N,
+                nblk, n, Ldiag, x, lm);
         return;
     }
     hipLaunchKernelGGL(chol_first_kernel, dim3(1), dim3(64), 0, s, A, N, Ldiag, info, lm);
