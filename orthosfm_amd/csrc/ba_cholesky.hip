@@ -203,7 +203,7 @@ chol_small_kernel(const double *A, int ld, int n, double *Ldiag, double *x, int 
     double *partials_cam)
 {
     if (!lm_resolve(d)) return;
-    if (d.lm->lin_failed) return;
+    if (d.lm == nullptr || d.lm->lin_failed) return;      // this kernel writes the candidate cameras of an LM solve: no state, nothing to do
     __shared__ __attribute__((aligned(16))) double M[NB][NB + 1];
     __shared__ double ys[NB], xs[NB];
     const int lane = threadIdx.x, r = lane & 31;

@@ -112,6 +112,12 @@ struct osfm_matcher {
     DeviceBuffer clock_probe;
     int special_max = 512;                // views with more special descriptors take the per-view operand forms
     DeviceBuffer d_m12_off, d_len12, d_corr_off, d_keep_pair, d_corr;
+    // osfm_match_all without verification: the lists of chunk k leave the device on a copy stream while
+    // chunk k + 1 is matched (two list buffers alternate)
+    DeviceBuffer d_corr_alt;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_compact[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+    bool copied_used[2] = {false, false};
     DeviceBuffer d_jobs, d_inl, d_inl_count, d_corr2, d_gather_off;
     hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipEvent_t ev_sp[2] = {nullptr, nullptr};
@@ -949,6 +955,11 @@ int osfm_match_create(int device, int num_views, const osfm_match_options *opts,
         for (int j = 0; j < 2; ++j) OSFM_HIP_CHECK(hipEventCreate(&m->ev[i][j]));
     for (int j = 0; j < 2; ++j) OSFM_HIP_CHECK(hipEventCreate(&m->ev_sp[j]));
     for (int j = 0; j < 2; ++j) OSFM_HIP_CHECK(hipEventCreateWithFlags(&m->pin_ev[j], hipEventDisableTiming));
+    OSFM_HIP_CHECK(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+    for (int j = 0; j < 2; ++j) {
+        OSFM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_compact[j], hipEventDisableTiming));
+        OSFM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_copied[j], hipEventDisableTiming));
+    }
     if (m->opts.special_kernel_max != 0) m->special_max = std::max(m->opts.special_kernel_max, 0);
     std::vector<int32_t> t;
     build_lowe_table(m->opts.sift_lowe_ratio, false, &t);
@@ -1017,6 +1028,11 @@ int osfm_match_destroy(osfm_matcher *m)
     for (int j = 0; j < 2; ++j) {
         if (m->pin_ev[j]) (void)hipEventDestroy(m->pin_ev[j]);
         if (m->pin_ptr[j]) (void)hipHostFree(m->pin_ptr[j]);
+    }
+    if (m->copy_stream) { (void)hipStreamSynchronize(m->copy_stream); (void)hipStreamDestroy(m->copy_stream); }
+    for (int j = 0; j < 2; ++j) {
+        if (m->ev_compact[j]) (void)hipEventDestroy(m->ev_compact[j]);
+        if (m->ev_copied[j]) (void)hipEventDestroy(m->ev_copied[j]);
     }
     if (m->stream) (void)hipStreamDestroy(m->stream);
     for (auto *sg : m->comb_staging) { if (sg->ptr) (void)hipHostFree(sg->ptr); delete sg; }
@@ -1238,7 +1254,15 @@ int combine(osfm_matcher *m, osfm_matcher::PairRequest &rq)
                 }
             }
             lk.unlock();
-            serve_requests(m, batch);
+            // The leader must not leave the others waiting for ever, and no exception may cross the C ABI into
+            // the caller's OpenMP loop: a failure inside the batch (an allocation, say) fails the batch.
+            try {
+                serve_requests(m, batch);
+            } catch (const std::exception &e) {
+                for (auto *r : batch) { r->status = OSFM_E_STATE; r->error = std::string("match_pair: ") + e.what(); r->stage = nullptr; }
+            } catch (...) {
+                for (auto *r : batch) { r->status = OSFM_E_STATE; r->error = "match_pair: unknown failure in the combined batch"; r->stage = nullptr; }
+            }
             lk.lock();
             for (auto *r : batch) r->done = true;
             m->comb_cv.notify_all();
@@ -1343,6 +1367,8 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
     OSFM_HIP_CHECK(hipSetDevice(m->device));
     reset_stats(m);
     const osfm_match_options &o = m->opts;
+    // whatever way this call ends, no copy into the caller's buffer is still in flight afterwards
+    struct CopyDrain { hipStream_t s; ~CopyDrain() { if (s) (void)hipStreamSynchronize(s); } } copy_drain{m->copy_stream};
 
     // ---- classify (bundler_matching.cc:96-99, 146-158) ---------------------
     std::vector<int> lowres_idx, full_idx;
@@ -1371,6 +1397,14 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
         }
         const size_t budget = (size_t)24 << 30;
         return (int)std::max<size_t>(1, std::min<size_t>(budget / worst, 4096));
+    };
+    // A call that fits one batch is still cut in three when it is large: the lists of one part then leave
+    // the device (63 MB per 1225 pairs: 2.5 ms of an otherwise idle device) while the next part is matched.
+    auto full_batch_size = [&](size_t n_full) {
+        int bs = batch_size_for(false);
+        if (o.pairs_per_batch <= 0 && !o.geometric_verification && n_full >= 768)
+            bs = std::min<int>(bs, (int)((n_full + 2) / 3));
+        return bs;
     };
 
     // ---- low-res gate -------------------------------------------------------
@@ -1402,7 +1436,8 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
     int64_t written = 0, written_out = 0;     // pre-RANSAC / post-RANSAC correspondence counts
     bool overflow = false;
     {
-        const int bs = batch_size_for(false);
+        const int bs = full_batch_size(full_idx.size());
+        int chunk_no = 0;
         std::vector<osfm_pair> chunk;
         std::vector<int64_t> h_m12_off, h_corr_off;
         std::vector<int32_t> h_len12;
@@ -1439,19 +1474,27 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
                 OSFM_RETURN_IF(m->d_corr_off.reserve(n * 8));
                 OSFM_RETURN_IF(m->d_len12.reserve(n * 4));
                 OSFM_RETURN_IF(m->d_keep_pair.reserve(n));
-                OSFM_RETURN_IF(m->d_corr.reserve((size_t)chunk_corr * 8));
+                // without verification two list buffers alternate: the copy of the one is in flight on the
+                // copy stream while the next chunk is matched and compacted into the other
+                const int cb = o.geometric_verification ? 0 : (chunk_no++ & 1);
+                DeviceBuffer &dcorr = cb ? m->d_corr_alt : m->d_corr;
+                if (m->copied_used[cb]) OSFM_HIP_CHECK(hipEventSynchronize(m->ev_copied[cb]));      // before a reserve may free it
+                OSFM_RETURN_IF(dcorr.reserve((size_t)chunk_corr * 8));
                 OSFM_HIP_CHECK(hipMemcpyAsync(m->d_m12_off.ptr, h_m12_off.data(), n * 8, hipMemcpyHostToDevice, s));
                 OSFM_HIP_CHECK(hipMemcpyAsync(m->d_corr_off.ptr, h_corr_off.data(), n * 8, hipMemcpyHostToDevice, s));
                 OSFM_HIP_CHECK(hipMemcpyAsync(m->d_len12.ptr, h_len12.data(), n * 4, hipMemcpyHostToDevice, s));
                 OSFM_HIP_CHECK(hipMemcpyAsync(m->d_keep_pair.ptr, h_keep.data(), n, hipMemcpyHostToDevice, s));
                 launch_compact_pairs(n, m->out.as<int32_t>(), m->d_m12_off.as<int64_t>(),
                     m->d_len12.as<int32_t>(), m->d_corr_off.as<int64_t>(), m->d_keep_pair.as<uint8_t>(),
-                    m->d_corr.as<int32_t>(), s);
+                    dcorr.as<int32_t>(), s);
                 OSFM_HIP_CHECK(hipGetLastError());
                 if (!o.geometric_verification) {
-                    OSFM_HIP_CHECK(hipMemcpyAsync(corr + 2 * written, m->d_corr.ptr, (size_t)chunk_corr * 8,
-                        hipMemcpyDeviceToHost, s));
-                    OSFM_HIP_CHECK(hipStreamSynchronize(s));
+                    OSFM_HIP_CHECK(hipEventRecord(m->ev_compact[cb], s));
+                    OSFM_HIP_CHECK(hipStreamWaitEvent(m->copy_stream, m->ev_compact[cb], 0));
+                    OSFM_HIP_CHECK(hipMemcpyAsync(corr + 2 * written, dcorr.ptr, (size_t)chunk_corr * 8,
+                        hipMemcpyDeviceToHost, m->copy_stream));
+                    OSFM_HIP_CHECK(hipEventRecord(m->ev_copied[cb], m->copy_stream));
+                    m->copied_used[cb] = true;
                 }
             }
             if (o.geometric_verification && chunk_corr > 0) {
@@ -1528,6 +1571,7 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
             written += chunk_corr;
         }
     }
+    if (!o.geometric_verification) OSFM_HIP_CHECK(hipStreamSynchronize(m->copy_stream));      // every list has arrived
     if (o.geometric_verification) written = written_out;
     if (total) *total = written;
     if (overflow) {
