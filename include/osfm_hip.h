@@ -507,6 +507,21 @@ OSFM_API int osfm_tracks_builder_finish(const osfm_tracks_builder *b, const uint
     osfm_tracks_summary *summary);
 OSFM_API int osfm_tracks_builder_destroy(osfm_tracks_builder *b);
 
+/* The observation arrays of an osfm_ba_problem from a scene's tracks in one pass -- what
+ * runBundleAdjustment / triangulateOrthographicTracks build residual by residual from their
+ * std::vector<Track> (bundle_adjustment.cpp:86-123, triangulation.cpp:23-60): features are in
+ * track order; feature i is taken when live[i] != 0, camera_of_feature[i] >= 0 (its view has a
+ * camera) and (track_mask == NULL or track_mask[track_of[i]] != 0).  obs_point[k] = track_slot[track]
+ * when track_slot is given (the caller's numbering of the point blocks), else the rank of the track
+ * among the tracks that contributed a feature -- their ids then go to tracks_out (capacity rows as
+ * well).  feature_ids (may be NULL) receives the taken feature indices.  *num_observations is always
+ * set; OSFM_E_CAPACITY when it exceeds `capacity`. */
+OSFM_API int osfm_tracks_select_observations(int64_t num_features, const int32_t *track_of,
+    const int32_t *camera_of_feature, const uint8_t *live, const uint8_t *track_mask,
+    const int32_t *track_slot, const double *xy, int64_t capacity, int32_t *feature_ids,
+    double *obs_xy, int32_t *obs_camera, int32_t *obs_point, int32_t *tracks_out,
+    int64_t *num_observations, int64_t *num_tracks_out);
+
 /* orthosfm::buildGroups (src/data_structures/group.cpp:13-88, completeGroup
  * :90-155): the order in which the incremental reconstruction adds views, as
  * groups of group_size views (3 in the reference's algorithms).

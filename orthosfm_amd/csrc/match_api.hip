@@ -570,14 +570,33 @@ int upload_view(osfm_matcher *m, int view, const uint16_t *sift, int n_sift, con
     int32_t *p_special = reinterpret_cast<int32_t *>(pin + b_sift + b_surf), *p_slot = p_special + n_sift;
     int n_special = 0;
     bool bad = false;
-    for (int i = 0; i < n_sift; ++i) {
-        const uint16_t *d = sift + (size_t)i * 128;
-        uint16_t *o = p_sift + (size_t)i * 128;
-        unsigned mx = 0;
-        for (int k = 0; k < 128; ++k) { o[k] = d[k]; mx = std::max<unsigned>(mx, d[k]); }
-        bad |= mx > 255;
-        p_slot[i] = -1;
-        if (mx > 127) { p_slot[i] = n_special; p_special[n_special++] = i; }     // ascending: the same gathered set on every run
+    {
+        // copy + row maxima on a few threads (the pass is memory bound: 5 MB per 20k-feature view), then the
+        // special rows numbered in ascending order: the same gathered set on every run
+        auto rows = [&](int lo, int hi, int *bad_out) {
+            int b = 0;
+            for (int i = lo; i < hi; ++i) {
+                const uint16_t *d = sift + (size_t)i * 128;
+                uint16_t *o = p_sift + (size_t)i * 128;
+                unsigned mx = 0;
+                for (int k = 0; k < 128; ++k) { o[k] = d[k]; mx = std::max<unsigned>(mx, d[k]); }
+                b |= mx > 255;
+                p_slot[i] = mx > 127 ? 1 : 0;
+            }
+            *bad_out = b;
+        };
+        const int nthr = n_sift >= 8192 ? 4 : 1;
+        int bad_t[4] = {0, 0, 0, 0};
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthr; ++t)
+            th.emplace_back(rows, (int)((int64_t)n_sift * t / nthr), (int)((int64_t)n_sift * (t + 1) / nthr), &bad_t[t]);
+        rows(0, (int)((int64_t)n_sift / nthr), &bad_t[0]);
+        for (auto &t : th) t.join();
+        for (int t = 0; t < nthr; ++t) bad |= bad_t[t] != 0;
+        for (int i = 0; i < n_sift; ++i) {
+            if (p_slot[i]) { p_slot[i] = n_special; p_special[n_special++] = i; }
+            else p_slot[i] = -1;
+        }
     }
     long long norm2_max = 0;
     for (int i = 0; i < n_surf; ++i) {

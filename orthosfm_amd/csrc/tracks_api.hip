@@ -240,6 +240,48 @@ int osfm_tracks_builder_destroy(osfm_tracks_builder *b)
     return OSFM_OK;
 }
 
+// The observation arrays of an osfm_ba_problem from the tracks of a scene in one pass: what the
+// reference builds residual block by residual block from its std::vector<Track>
+// (bundle_adjustment.cpp:86-123: every feature of a selected track whose view has a camera).
+// Feature i (features in track order) is taken when live[i] != 0, camera_of_feature[i] >= 0 and
+// (track_mask == NULL or track_mask[track_of[i]] != 0).  obs_point[k] = track_slot[track] when
+// track_slot is given (the caller's numbering of the parameter blocks), else the rank of the track
+// among the tracks that contributed a feature, whose ids then go to tracks_out.
+int osfm_tracks_select_observations(int64_t num_features, const int32_t *track_of, const int32_t *camera_of_feature,
+    const uint8_t *live, const uint8_t *track_mask, const int32_t *track_slot, const double *xy,
+    int64_t capacity, int32_t *feature_ids, double *obs_xy, int32_t *obs_camera, int32_t *obs_point,
+    int32_t *tracks_out, int64_t *num_observations, int64_t *num_tracks_out)
+{
+    if (num_features < 0 || capacity < 0 || !num_observations ||
+        (num_features > 0 && (!track_of || !camera_of_feature || !live || !xy)) ||
+        (capacity > 0 && (!obs_xy || !obs_camera || !obs_point))) {
+        set_error("tracks_select_observations: bad arguments");
+        return OSFM_E_ARG;
+    }
+    int64_t n = 0, nt = 0;
+    int32_t last = -1;
+    for (int64_t i = 0; i < num_features; ++i) {
+        if (!live[i] || camera_of_feature[i] < 0) continue;
+        const int32_t t = track_of[i];
+        if (track_mask && !track_mask[t]) continue;
+        if (n < capacity) {
+            if (feature_ids) feature_ids[n] = (int32_t)i;
+            obs_xy[2 * n] = xy[2 * i]; obs_xy[2 * n + 1] = xy[2 * i + 1];
+            obs_camera[n] = camera_of_feature[i];
+            if (t != last) { if (!track_slot && tracks_out) tracks_out[nt] = t; ++nt; last = t; }
+            obs_point[n] = track_slot ? track_slot[t] : (int32_t)(nt - 1);
+        } else if (t != last) { ++nt; last = t; }
+        ++n;
+    }
+    *num_observations = n;
+    if (num_tracks_out) *num_tracks_out = nt;
+    if (n > capacity) {
+        set_error("tracks_select_observations: %lld observations exceed the capacity %lld", (long long)n, (long long)capacity);
+        return OSFM_E_CAPACITY;
+    }
+    return OSFM_OK;
+}
+
 int osfm_tracks_compute(int32_t num_views, const int32_t *view_sizes, const uint8_t *colors,
     int32_t num_pairs, const osfm_pair *pairs, const int64_t *pair_offsets, const int32_t *corr,
     int32_t *track_ids, int64_t track_capacity, int64_t feature_capacity,

@@ -529,18 +529,17 @@ def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2
     tri = {"full": True}
 
     def _triangulate(tracks_subset):
-        if tracks_subset is None:
-            fsel = np.flatnonzero(tt.live_f & (tt.cam_f >= 0))
-        else:
-            lo, hi = tt.offsets[tracks_subset], tt.offsets[tracks_subset + 1]
-            n = hi - lo
-            fsel = np.repeat(lo - np.concatenate([[0], np.cumsum(n)[:-1]]), n) + np.arange(int(n.sum()))
-            fsel = fsel[(tt.cam_f[fsel] >= 0) & tt.alive_f[fsel]]
-        uniq, _, _, run = _runs(tt.track_of[fsel])              # fsel is in track order
+        # the observation arrays in one pass over the table (osfm_tracks_select_observations): the live
+        # features of the selected tracks whose view has a camera, the tracks numbered as they appear
+        mask = None
+        if tracks_subset is not None:
+            mask = np.zeros(tt.alive_t.shape[0], dtype=np.uint8)
+            mask[tracks_subset] = 1
+        obs_xy, obs_cam, obs_pt, uniq, _ = T.select_observations(tt.track_of, tt.cam_f, tt.live_f, tt.xy, track_mask=mask)
+        uniq = uniq.astype(np.int64)
         start = np.zeros((uniq.size, 4))
         start[:, 3] = 1.0
-        prob = _problem(model, cams[aligned], const[aligned], W, H, start,
-                        tt.xy[fsel], tt.cam_f[fsel], run.astype(np.int32))
+        prob = _problem(model, cams[aligned], const[aligned], W, H, start, obs_xy, obs_cam, obs_pt)
         valid = (B.triangulate(prob, device) if uniq.size else np.zeros(0, np.uint8)).astype(bool)
         return uniq, valid, prob.points
 
@@ -682,10 +681,10 @@ def _global_ba(tt, model, cams, const, aligned, W, H, V, solve, kind, opt, tm):
     t0 = time.perf_counter()
     with_point = tt.alive_t & tt.has_point
     tsel = np.flatnonzero(with_point)
-    fsel = np.flatnonzero(tt.live_f & (tt.cam_f >= 0) & with_point[tt.track_of])
-    slot = np.cumsum(with_point) - 1                                     # track -> row of tsel
-    prob = _problem(model, cams[aligned], const[aligned], W, H, tt.point[tsel], tt.xy[fsel], tt.cam_f[fsel],
-                    slot[tt.track_of[fsel]].astype(np.int32))
+    slot = (np.cumsum(with_point) - 1).astype(np.int32)                  # track -> row of tsel
+    obs_xy, obs_cam, obs_pt, _, _ = T.select_observations(tt.track_of, tt.cam_f, tt.live_f, tt.xy,
+                                                          track_mask=with_point, track_slot=slot)
+    prob = _problem(model, cams[aligned], const[aligned], W, H, tt.point[tsel], obs_xy, obs_cam, obs_pt)
     tm.pose_host_s += time.perf_counter() - t0
     s, dt = solve(kind, prob, opt)
     tm.global_ba_s += dt

@@ -106,6 +106,33 @@ def compute_flat_ranges(view_sizes, colors, pairs, pair_starts, pair_counts, cor
             track_colors[:nt], summary)
 
 
+def select_observations(track_of, cam_f, live, xy, track_mask=None, track_slot=None, want_features=False):
+    """osfm_tracks_select_observations: (obs_xy, obs_camera, obs_point, tracks, feature_ids) of the live
+    features whose view has a camera, optionally restricted to the tracks of a mask; obs_point numbers the
+    tracks by track_slot when given, else densely in order of appearance (tracks = their ids)."""
+    n = int(track_of.shape[0])
+    # a selection is rarely the whole table: size the outputs by what the mask can admit
+    cap = n
+    obs_xy = np.empty((cap, 2), dtype=np.float64)
+    obs_cam = np.empty(cap, dtype=np.int32)
+    obs_pt = np.empty(cap, dtype=np.int32)
+    tracks = np.empty(cap, dtype=np.int32) if track_slot is None else None
+    fids = np.empty(cap, dtype=np.int32) if want_features else None
+    nobs, nt = C.c_int64(), C.c_int64()
+    live8 = live.view(np.uint8) if live.dtype == np.bool_ else live
+    mask8 = None if track_mask is None else (track_mask.view(np.uint8) if track_mask.dtype == np.bool_ else track_mask)
+    capi.check(capi.lib.osfm_tracks_select_observations(
+        C.c_int64(n), capi._ptr(track_of, C.c_int32), capi._ptr(cam_f, C.c_int32), capi._ptr(live8, C.c_uint8),
+        capi._ptr(mask8, C.c_uint8) if mask8 is not None else None,
+        capi._ptr(track_slot, C.c_int32) if track_slot is not None else None,
+        capi._ptr(xy, C.c_double), C.c_int64(cap), capi._ptr(fids, C.c_int32) if fids is not None else None,
+        capi._ptr(obs_xy, C.c_double), capi._ptr(obs_cam, C.c_int32), capi._ptr(obs_pt, C.c_int32),
+        capi._ptr(tracks, C.c_int32) if tracks is not None else None, C.byref(nobs), C.byref(nt)))
+    k, t = int(nobs.value), int(nt.value)
+    return (obs_xy[:k], obs_cam[:k], obs_pt[:k], None if tracks is None else tracks[:t],
+            None if fids is None else fids[:k])
+
+
 class TracksBuilder:
     """Tracks::compute fed pair batch by pair batch (osfm_tracks_builder_*): feed() takes what
     HipExhaustiveMatching.compute_arrays returned for one batch of pairs -- in the reference's pair

@@ -198,3 +198,33 @@ def test_tracks_builder_equals_one_shot():
     assert got[4].num_tracks == want[4].num_tracks and got[4].num_invalid_tracks == want[4].num_invalid_tracks
     assert b.num_pairs == len(pairs) and b.num_matches == int(offs[-1])
     b.close()
+
+
+def test_select_observations_equals_numpy():
+    """osfm_tracks_select_observations against the index arithmetic it replaces: live features whose view has
+    a camera, optionally of masked tracks; points numbered by a slot table or densely in order of appearance."""
+    from orthosfm_amd import tracks as T
+    r = np.random.default_rng(3)
+    lens = r.integers(1, 7, 300)
+    track_of = np.repeat(np.arange(300, dtype=np.int32), lens)
+    n = track_of.shape[0]
+    cam_f = r.integers(-1, 5, n).astype(np.int32)
+    live = r.random(n) < 0.8
+    xy = r.normal(size=(n, 2))
+    mask = r.random(300) < 0.5
+    # dense numbering, no mask / with mask
+    for m in (None, mask):
+        sel = live & (cam_f >= 0) & (True if m is None else m[track_of])
+        ids = np.flatnonzero(sel)
+        uniq, inv = np.unique(track_of[ids], return_inverse=True)
+        oxy, ocam, opt, tracks, fids = T.select_observations(track_of, cam_f, live, xy, track_mask=m, want_features=True)
+        assert np.array_equal(fids, ids) and np.array_equal(oxy, xy[ids]) and np.array_equal(ocam, cam_f[ids])
+        assert np.array_equal(tracks, uniq) and np.array_equal(opt, inv)
+    # the caller's numbering
+    slot = (np.cumsum(mask) - 1).astype(np.int32)
+    sel = live & (cam_f >= 0) & mask[track_of]
+    oxy, ocam, opt, tracks, _ = T.select_observations(track_of, cam_f, live, xy, track_mask=mask, track_slot=slot)
+    assert tracks is None and np.array_equal(opt, slot[track_of[sel]]) and np.array_equal(oxy, xy[sel])
+    # nothing selected
+    oxy, ocam, opt, tracks, _ = T.select_observations(track_of, np.full(n, -1, np.int32), live, xy)
+    assert oxy.shape == (0, 2) and tracks.size == 0
