@@ -585,7 +585,8 @@ int upload_view(osfm_matcher *m, int view, const uint16_t *sift, int n_sift, con
             }
             *bad_out = b;
         };
-        const int nthr = n_sift >= 8192 ? 4 : 1;
+        static const int max_thr = getenv("OSFM_UPLOAD_THREADS") ? std::max(1, std::min(4, atoi(getenv("OSFM_UPLOAD_THREADS")))) : 4;
+        const int nthr = n_sift >= 8192 ? max_thr : 1;
         int bad_t[4] = {0, 0, 0, 0};
         std::vector<std::thread> th;
         for (int t = 1; t < nthr; ++t)
