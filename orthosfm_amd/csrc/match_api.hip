@@ -1422,7 +1422,8 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
     // the device (63 MB per 1225 pairs: 2.5 ms of an otherwise idle device) while the next part is matched.
     auto full_batch_size = [&](size_t n_full) {
         int bs = batch_size_for(false);
-        if (o.pairs_per_batch <= 0 && !o.geometric_verification && n_full >= 768)
+        // (not in cascade-hashing mode: its bucket kernels want the large launch)
+        if (o.pairs_per_batch <= 0 && !o.geometric_verification && o.matcher_type != OSFM_MATCHER_CASCADE_HASHING && n_full >= 768)
             bs = std::min<int>(bs, (int)((n_full + 2) / 3));
         return bs;
     };

@@ -16,13 +16,25 @@ def total(path, counter):
     for row in csv.DictReader(open(path)):
         if KERNEL in row["Kernel_Name"] and row["Counter_Name"] == counter:
             per_dispatch[int(row["Dispatch_Id"])] = per_dispatch.get(int(row["Dispatch_Id"]), 0.0) + float(row["Counter_Value"])
+            GRID[int(row["Dispatch_Id"])] = int(row["Grid_Size"])
     return per_dispatch[max(per_dispatch)] if per_dispatch else 0.0
+
+
+GRID = {}
+
+
+def pairs_of_last_launch(features=20000):
+    """Pairs in the launch the counters come from, from its grid: a pair of two `features`-descriptor views
+    is ceil(n / 256) row blocks x ceil(n / 8192) column segments of 256 threads (osfm_match_all cuts a large
+    call into three launches, so this is not the pair count of the call)."""
+    nrb, nseg = (features + 255) // 256, (features + 8191) // 8192
+    return round(GRID[max(GRID)] / 256 / (nrb * nseg)) if GRID else 0
 
 
 def main():
     fetch_kb = total(sys.argv[1], "FETCH_SIZE")
     write_kb = total(sys.argv[2], "WRITE_SIZE")
-    pairs = int(sys.argv[3])
+    pairs = pairs_of_last_launch() if sys.argv[3] == "auto" else int(sys.argv[3])
     hbm = (2.0 * fetch_kb + write_kb) * 1024.0
     rec = {
         "kernel": KERNEL,

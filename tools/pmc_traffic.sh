@@ -13,4 +13,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   cp $f $R/gpurun_out/${round}_match_pmc_$(echo $c | tr A-Z a-z).csv
   rm -rf $R/gpurun_out/pmc_$c
 done
-python $R/tools/pmc_traffic.py $R/gpurun_out/${round}_match_pmc_fetch_size.csv $R/gpurun_out/${round}_match_pmc_write_size.csv 1225 $R/gpurun_out/${round}_match_traffic_pmc.json
+python $R/tools/pmc_traffic.py $R/gpurun_out/${round}_match_pmc_fetch_size.csv $R/gpurun_out/${round}_match_pmc_write_size.csv auto $R/gpurun_out/${round}_match_traffic_pmc.json
