@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the extra passes with RANSAC-F")
     ap.add_argument("--no-e2e", action="store_true", help="skip the 200-image matching run and the end-to-end job")
+    ap.add_argument("--single-process", action="store_true",
+                    help="with --gpus N and WITHOUT torchrun: one process, N devices behind osfm_match_create_multi "
+                         "(the form the reference's single C++ caller can use) instead of one rank per GPU")
     ap.add_argument("--config", type=int, default=0, help="1: BASELINE configs[0] (3 views of the Suzanne model, solver 0) as a plumbing run, "
                                                              "one JSON line of its own; 0 (default): the headline workload")
     ap.add_argument("--no-realistic", action="store_true", help="skip the passes with special SIFT rows (bytes > 127)")
@@ -729,7 +732,7 @@ def main():
     scaling = "strong"
     config_id = 2
     if V <= 0:
-        if world == 1:
+        if world == 1 and not (args.single_process and args.gpus > 1):
             V = 50
         elif args.weak:
             scaling = "weak"
@@ -750,7 +753,11 @@ def main():
     if args.no_lowres_gate:
         o1.use_lowres_matching = 0
         o1.min_feature_matches = 0
-    m = HipExhaustiveMatching(V, device=device_index, options=o1, copy_results=False)
+    front_devices = None
+    if world == 1 and args.single_process and args.gpus > 1:
+        # one process, several devices behind the C ABI (logical shards on device 0 when the box has fewer)
+        front_devices = [d % ndev for d in range(args.gpus)]
+    m = HipExhaustiveMatching(V, device=front_devices if front_devices else device_index, options=o1, copy_results=False)
     t0 = time.perf_counter()
     for v in range(V):
         m.set_view(v, iset.sift[v])
@@ -965,7 +972,7 @@ def main():
         traffic, traffic_src = pmc_traffic_per_launch(len(my_pairs) * args.steps / max(kern_launches, 1))
         line = {
             "metric": METRIC,
-            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "value": value, "unit": "pairs/s", "n_gpus": len(front_devices) if front_devices else world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "i8",
             "data": "synthetic",
@@ -994,6 +1001,9 @@ def main():
             "correspondences_rank0": int(n_corr),
             "upload_s": upload_s,
         }
+        if front_devices:
+            line["multi_gpu_note"] = ("one process, osfm_match_create_multi over devices %s: the bank on every device, pairs dealt "
+                                      "longest-first, no data-path exchange" % front_devices)
         if world > 1:
             line["multi_gpu_note"] = "every rank holds the full descriptor bank; no data-path collective; exchange = " + args.exchange
         if cpu_base is not None:
