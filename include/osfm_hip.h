@@ -496,7 +496,8 @@ OSFM_API int osfm_tracks_compute_ranges(int32_t num_views, const int32_t *view_s
  * bundler_tracks.cc:66-119 is a sequential merge over the pairs): the host can merge the lists of
  * one batch of osfm_match_all while the device matches the next.  feed: pair p of the batch owns
  * corr[pair_starts[p] .. pair_starts[p] + pair_counts[p]) (2 ints per correspondence); finish
- * writes what osfm_tracks_compute writes (same arguments) and leaves the builder usable. */
+ * writes what osfm_tracks_compute writes (same arguments; track_ids may be NULL here) and leaves
+ * the builder usable. */
 typedef struct osfm_tracks_builder osfm_tracks_builder;
 OSFM_API int osfm_tracks_builder_create(int32_t num_views, const int32_t *view_sizes, osfm_tracks_builder **out);
 OSFM_API int osfm_tracks_builder_feed(osfm_tracks_builder *b, int32_t num_pairs, const osfm_pair *pairs,

@@ -51,6 +51,14 @@ struct ViewData {
     DeviceBuffer cas_hash[2], cas_bucket[2], cas_start[2], cas_items[2], cas_rec[2];
     DeviceBuffer positions;      // [ns + nu][2] floats (geometric verification only)
     int n_positions = -1;
+    // recorded on the upload stream behind the view's transfer and conversion kernels; the matching
+    // stream waits for it before a batch that names the view (uploads do not wait for matching and
+    // matching does not wait for uploads of views it does not use)
+    hipEvent_t ready = nullptr;
+    ~ViewData() { if (ready) (void)hipEventDestroy(ready); }
+    ViewData() = default;
+    ViewData(const ViewData &) = delete;
+    ViewData &operator=(const ViewData &) = delete;
 };
 
 // Host twin of matching.h:126-127,138-143 for every (d1, d2): the smallest
@@ -104,6 +112,10 @@ struct osfm_matcher {
     DeviceBuffer lowe_sift, lowe_surf;
     LoweTable tab_sift, tab_surf;
     std::mutex mu;
+    // uploads (osfm_match_set_view) have a stream and a lock of their own: a view can be uploaded while a
+    // batch that does not name it is being matched
+    hipStream_t up_stream = nullptr;
+    std::mutex up_mu;
 
     // scratch (grow-only)
     DeviceBuffer d_problems[2], rowparts, colparts, out, keep, mark_off[2], counts[2];
@@ -131,7 +143,7 @@ struct osfm_matcher {
     // cascade hashing: projection matrices (transposed), running sums, average; the
     // hashes depend on the average over ALL views, hence the dirty flag
     DeviceBuffer cas_proj[2], cas_sum[2], cas_avg[2], cas_state;
-    bool cas_dirty = true;
+    std::atomic<bool> cas_dirty{true};
 
     osfm_match_stats stats;
 
@@ -374,6 +386,13 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
     OSFM_RETURN_IF(m->exact_count.reserve(16));
     OSFM_RETURN_IF(m->sp_parts.reserve((size_t)std::max<int64_t>(sp_recs, 1) * sizeof(RowPart)));
     hipStream_t s = m->stream;
+    {
+        // the views this batch names: their uploads (own stream) before anything of the batch
+        std::vector<uint8_t> seen(m->views.size(), 0);
+        for (int p = 0; p < num_pairs; ++p)
+            for (int v : {res->plans[p].v1, res->plans[p].v2})
+                if (!seen[v]) { seen[v] = 1; if (m->views[v].ready) OSFM_HIP_CHECK(hipStreamWaitEvent(s, m->views[v].ready, 0)); }
+    }
     // Workgroups that stream the same 4096 descriptors of the same view run next to each other:
     // the chunk (512 KB) is then fetched from HBM once per L2 instead of once per pair (in
     // pair order the streamed view of side 0 changes with every pair: 3 GB of HBM reads per
@@ -537,7 +556,7 @@ int upload_view(osfm_matcher *m, int view, const uint16_t *sift, int n_sift, con
         return OSFM_E_ARG;
     }
     ViewData &v = m->views[view];
-    hipStream_t s = m->stream;
+    hipStream_t s = m->up_stream;
     v.set = false;
     v.ns = n_sift; v.nu = n_surf;
     v.ns_pad = round_up(std::max(n_sift, 1), kRowsPerBlock);
@@ -639,6 +658,8 @@ int upload_view(osfm_matcher *m, int view, const uint16_t *sift, int n_sift, con
     OSFM_HIP_CHECK(hipGetLastError());
     OSFM_HIP_CHECK(hipEventRecord(m->pin_ev[ps], s));
     m->pin_used[ps] = true;
+    if (!v.ready) OSFM_HIP_CHECK(hipEventCreateWithFlags(&v.ready, hipEventDisableTiming));
+    OSFM_HIP_CHECK(hipEventRecord(v.ready, s));
     v.surf_norm2_max = (int)std::min<long long>(norm2_max, 0x7fffffff);
     v.set = true;
     m->cas_dirty = true;           // the cascade hashes depend on the average over all views
@@ -653,6 +674,7 @@ int upload_view(osfm_matcher *m, int view, const uint16_t *sift, int n_sift, con
 int ensure_cashash(osfm_matcher *m)
 {
     if (!m->cas_dirty) return OSFM_OK;
+    OSFM_HIP_CHECK(hipStreamSynchronize(m->up_stream));       // the hashes are built from every view
     hipStream_t s = m->stream;
     for (int type = 0; type < 2; ++type) {
         const int dim = type == 0 ? 128 : 64;
@@ -968,7 +990,7 @@ int osfm_match_create(int device, int num_views, const osfm_match_options *opts,
     osfm_matcher *m = owner.p;
     m->device = device;
     if (opts) m->opts = *opts; else osfm_match_options_default(&m->opts);
-    m->views.resize(num_views);
+    m->views = std::vector<ViewData>(num_views);
     reset_stats(m);
     OSFM_HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i)
@@ -976,6 +998,7 @@ int osfm_match_create(int device, int num_views, const osfm_match_options *opts,
     for (int j = 0; j < 2; ++j) OSFM_HIP_CHECK(hipEventCreate(&m->ev_sp[j]));
     for (int j = 0; j < 2; ++j) OSFM_HIP_CHECK(hipEventCreateWithFlags(&m->pin_ev[j], hipEventDisableTiming));
     OSFM_HIP_CHECK(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+    OSFM_HIP_CHECK(hipStreamCreateWithFlags(&m->up_stream, hipStreamNonBlocking));
     for (int j = 0; j < 2; ++j) {
         OSFM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_compact[j], hipEventDisableTiming));
         OSFM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_copied[j], hipEventDisableTiming));
@@ -1050,6 +1073,7 @@ int osfm_match_destroy(osfm_matcher *m)
         if (m->pin_ptr[j]) (void)hipHostFree(m->pin_ptr[j]);
     }
     if (m->copy_stream) { (void)hipStreamSynchronize(m->copy_stream); (void)hipStreamDestroy(m->copy_stream); }
+    if (m->up_stream) { (void)hipStreamSynchronize(m->up_stream); (void)hipStreamDestroy(m->up_stream); }
     for (int j = 0; j < 2; ++j) {
         if (m->ev_compact[j]) (void)hipEventDestroy(m->ev_compact[j]);
         if (m->ev_copied[j]) (void)hipEventDestroy(m->ev_copied[j]);
@@ -1094,7 +1118,7 @@ int osfm_match_set_view(osfm_matcher *m, int view, const uint16_t *sift, int n_s
     if (!m) { set_error("set_view: null matcher"); return OSFM_E_ARG; }
     if (!m->shards.empty())        // every shard holds the full bank: one host-to-device copy per device, side by side
         return for_each_shard(m, [&](size_t k) { return osfm_match_set_view(m->shards[k], view, sift, n_sift, surf, n_surf); });
-    std::lock_guard<std::mutex> lock(m->mu);
+    std::lock_guard<std::mutex> lock(m->up_mu);
     OSFM_HIP_CHECK(hipSetDevice(m->device));
     return upload_view(m, view, sift, n_sift, surf, n_surf);
 }

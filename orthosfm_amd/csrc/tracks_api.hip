@@ -122,7 +122,6 @@ static int builder_finish(const osfm_tracks_builder *b, const uint8_t *colors,
     const auto &voff = b->voff; const auto &tid = b->tid; const auto &nxt = b->nxt; const auto &head = b->head;
     const auto &size = b->size; const auto &twice = b->twice;
     const int64_t G = voff[num_views];
-    if (G > 0 && !track_ids) { set_error("tracks_compute: track_ids is null"); return OSFM_E_ARG; }
 
     // remove_invalid_tracks (:149-203: empty tracks, tracks with two features of one view) and the
     // output in ONE walk over each track's list: the walk is a chain of cache misses (the nodes of a
@@ -166,7 +165,8 @@ static int builder_finish(const osfm_tracks_builder *b, const uint8_t *colors,
         map[t] = valid++;
     }
     const int64_t kept_features = nf;
-    for (int64_t g = 0; g < G; ++g) track_ids[g] = tid[g] >= 0 ? map[tid[g]] : -1;
+    if (track_ids)          // Viewport::track_ids (the builder's finish may leave them out)
+        for (int64_t g = 0; g < G; ++g) track_ids[g] = tid[g] >= 0 ? map[tid[g]] : -1;
     if (summary) {
         summary->num_tracks = valid;
         summary->num_invalid_tracks = invalid;

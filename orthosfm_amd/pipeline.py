@@ -81,7 +81,7 @@ class TrackTable:
         self._lengths = np.diff(self.offsets).astype(np.int64)        # alive features per alive track
         order = _stable_order_by_view(self.view, self.num_views)             # feature ids grouped by view, ascending inside
         self.by_view = order
-        self.view_start = np.searchsorted(self.view[order], np.arange(self.num_views + 1))
+        self.view_start = np.concatenate([[0], np.cumsum(np.bincount(self.view, minlength=self.num_views))]).astype(np.int64)
 
     @classmethod
     def from_mve(cls, track_offsets, track_features, norm_positions, image_width, num_views):
@@ -123,7 +123,7 @@ class TrackTable:
         w._lengths = lens.astype(np.int64)
         order = _stable_order_by_view(w.view, w.num_views)
         w.by_view = order
-        w.view_start = np.searchsorted(w.view[order], np.arange(w.num_views + 1))
+        w.view_start = np.concatenate([[0], np.cumsum(np.bincount(w.view, minlength=w.num_views))]).astype(np.int64)
         w.orig_track = getattr(self, "orig_track", np.arange(self.alive_t.shape[0]))[sel_t]
         w.orig_feat = getattr(self, "orig_feat", np.arange(self.alive_f.shape[0]))[sel_f]
         return w
@@ -378,20 +378,47 @@ def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, ti
     o = capi.default_match_options()
     o.geometric_verification = 1 if verify else 0
     cls = HipExhaustiveMatching if matcher == "exhaustive" else HipCascadeHashing
+    import queue
+    import threading
     t0 = time.perf_counter()
     m = cls(V, device=device, options=o, copy_results=False)
-    norm = []
+    norm = [None] * V
     W, H = iset.width, iset.height
-    for v in range(V):
-        m.set_view(v, iset.sift[v], iset.surf[v] if iset.surf[v].shape[0] else None)
-        xy = ((iset.pos[v] + 0.5 - np.array([W / 2, H / 2])) / max(W, H)).astype(np.float32)   # feature_set.cc:42-55
-        if iset.surf[v].shape[0]:
-            xy = np.concatenate([xy, np.zeros((iset.surf[v].shape[0], 2), np.float32)])
-        norm.append(xy)
-        if verify:
-            m.set_positions(v, xy)
-    tm.upload_s = time.perf_counter() - t0
-    t0 = time.perf_counter()
+    # The views go up on a thread of their own (the library gives uploads their own stream and lock): the
+    # first batch of pairs -- in the reference's order pair i names views up to sqrt(2 i) -- starts as soon
+    # as the views it names are there, the rest of the bank follows beside the matching.
+    uploaded = [0]
+    up_cv = threading.Condition()
+    up_err = []
+
+    def upload_worker():
+        try:
+            for v in range(V):
+                m.set_view(v, iset.sift[v], iset.surf[v] if iset.surf[v].shape[0] else None)
+                xy = ((iset.pos[v] + 0.5 - np.array([W / 2, H / 2])) / max(W, H)).astype(np.float32)   # feature_set.cc:42-55
+                if iset.surf[v].shape[0]:
+                    xy = np.concatenate([xy, np.zeros((iset.surf[v].shape[0], 2), np.float32)])
+                norm[v] = xy
+                if verify:
+                    m.set_positions(v, xy)
+                with up_cv:
+                    uploaded[0] = v + 1
+                    up_cv.notify_all()
+        except Exception as e:
+            with up_cv:
+                up_err.append(e)
+                up_cv.notify_all()
+
+    def wait_for_views(n_views):
+        with up_cv:
+            while uploaded[0] < n_views and not up_err:
+                up_cv.wait()
+        if up_err:
+            raise up_err[0]
+
+    up_thread = threading.Thread(target=upload_worker, daemon=True)
+    up_thread.start()
+    upload_wait = 0.0
     if pairs is None:
         pairs = [capi.pair_from_index(i) for i in range(V * (V - 1) // 2)]
     pf = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
@@ -401,8 +428,6 @@ def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, ti
     # batch k into the tracks (Tracks::compute is a sequential merge over the pairs in that order, so
     # it takes them as they come; both are C calls that release the interpreter lock).  Two list
     # buffers alternate: a batch's lists stay where they are until the merge has read them.
-    import queue
-    import threading
     builder = T.TracksBuilder(sizes)
     n_batches = max(1, min(16, pf.shape[0] // 512))
     bounds = np.linspace(0, pf.shape[0], n_batches + 1).astype(np.int64)
@@ -435,18 +460,26 @@ def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, ti
     status = np.zeros(pf.shape[0], dtype=np.int32)
     for k in range(n_batches):
         sub = pf[bounds[k]:bounds[k + 1]]
+        t1 = time.perf_counter()
+        wait_for_views(int(sub.max()) + 1 if sub.size else 0)
+        upload_wait += time.perf_counter() - t1
         buf = free.get()
         m.use_result_buffer(buf)
         ra, corr_buf = m.compute_arrays(sub, capacity=max_cap)
         status[bounds[k]:bounds[k + 1]] = ra["status"]
         work.put((sub, ra.copy(), buf))
-    tm.matching_s = time.perf_counter() - t0
+    wait_for_views(V)
+    up_thread.join()
+    # upload_s: what the job waited for views (before the first batch and between batches); the rest of
+    # the uploads ran beside the matching
+    tm.upload_s = upload_wait
+    tm.matching_s = time.perf_counter() - t0 - upload_wait
     t0 = time.perf_counter()
     work.put(None)
     th.join()
     if err:
         raise err[0]
-    ids, toff, tfeat, tcol, summary = builder.finish()
+    ids, toff, tfeat, tcol, summary = builder.finish(want_track_ids=False)      # Viewport::track_ids are not used downstream
     # tracks_s: what the job waited for after the last batch was matched (the merge of the earlier
     # batches ran beside the matching: tracks_busy_s of it in all)
     tm.tracks_s = time.perf_counter() - t0

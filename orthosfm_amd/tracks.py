@@ -163,9 +163,9 @@ class TracksBuilder:
         self.num_matches += int(cnt.sum())
         self.num_pairs += int(matched.sum())
 
-    def finish(self, colors=None):
+    def finish(self, colors=None, want_track_ids=True):
         total = int(self.view_sizes.sum())
-        track_ids = np.full(max(total, 1), -1, dtype=np.int32)
+        track_ids = np.full(max(total, 1), -1, dtype=np.int32) if want_track_ids else None
         tcap, fcap = max(self.num_matches, 1), max(2 * self.num_matches, 1)
         # a track has at least two features and every feature is in one track at most
         tcap, fcap = min(tcap, max(total // 2, 1)), min(fcap, max(total, 1))
@@ -178,12 +178,12 @@ class TracksBuilder:
             colors = np.ascontiguousarray(colors, dtype=np.uint8).reshape(-1, 3)
             col_ptr = capi._ptr(colors, C.c_uint8)
         capi.check(capi.lib.osfm_tracks_builder_finish(
-            self._h, col_ptr, capi._ptr(track_ids, C.c_int32), C.c_int64(tcap), C.c_int64(fcap),
+            self._h, col_ptr, capi._ptr(track_ids, C.c_int32) if track_ids is not None else None, C.c_int64(tcap), C.c_int64(fcap),
             capi._ptr(track_offsets, C.c_int64), capi._ptr(track_features, C.c_int32),
             capi._ptr(track_colors, C.c_uint8), C.byref(summary)))
         nt = summary.num_tracks
-        return (track_ids[:total], track_offsets[:nt + 1], track_features[:summary.num_features],
-                track_colors[:nt], summary)
+        return (track_ids[:total] if track_ids is not None else None, track_offsets[:nt + 1],
+                track_features[:summary.num_features], track_colors[:nt], summary)
 
     def close(self):
         if self._h:
