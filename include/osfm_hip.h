@@ -162,7 +162,12 @@ OSFM_API int osfm_quantize_surf(const float *src, int n, int16_t *dst);
  * quantised 16-bit lanes (0..255 / -127..127 [-128 accepted]).  Data is
  * copied to the device; the caller keeps ownership of its buffers (the
  * reference frees the float descriptors right after init,
- * bundler_matching.cc:54-55).
+ * bundler_matching.cc:54-55): values are range-checked and copied to page-locked
+ * memory before the call returns, the transfer and the conversion kernels are
+ * queued on a stream of their own and not waited for.  A view may be set while
+ * matching calls that do not name it are in flight (a matching call waits for
+ * the uploads of the views it names); setting a view that a running call names
+ * is the caller's error.
  */
 OSFM_API int osfm_match_set_view(osfm_matcher *m, int view,
     const uint16_t *sift, int n_sift, const int16_t *surf, int n_surf);
