@@ -87,3 +87,19 @@ def test_product_does_not_touch_the_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "oracle_lib" not in src and "liboracle" not in src and "oracle/" not in src, fn
+
+
+def test_m0_is_written_only_by_hand_in_the_pipe_kernels():
+    """The correction-free tile kernels set m0 inside an asm statement (hipcc rejects m0 as a clobber: a reserved
+    register).  That is sound only while nothing else in those kernels uses m0; tools/check_m0.sh disassembles
+    match_kernels.hip for gfx950 and fails when a C0 instantiation holds any other m0 instruction."""
+    import os
+    import shutil
+    import subprocess
+    import pytest
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([os.path.join(root, "tools", "check_m0.sh")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("[C0]") >= 2 and "0 other than s_mov_b32 m0 [C0]" in out.stdout
