@@ -16,6 +16,7 @@
 //                   solves A_ik <- A_ik L_kk^-T for 64 rows of the panel
 //   chol_update(k): A_ij -= L_ik L_jk^T for k < j <= i (incl. the rhs row)
 #include <algorithm>
+#include <mutex>
 
 #include "ba_kernels.h"
 
@@ -849,7 +850,21 @@ void launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double
         f.ld = N; f.nblk = nblk; f.epoch = flow_epoch; f.trace = g_flow_trace;
         // the backward substitution runs inside the same launch; x has room for the padded system (N entries)
         f.x = getenv("OSFM_BA_FLOW_FACTOR_ONLY") ? nullptr : x;
-        hipLaunchKernelGGL(chol_flow_kernel, dim3(flow_groups), dim3(256), 0, s, f);
+        {
+            // Two of these launches must never share the device: each needs ALL its workgroups resident, and two
+            // half-resident grids would wait for each other until the spin limit fails both.  Solves on different
+            // streams (host threads) are therefore chained on the device: a launch waits for the previous one's event.
+            static std::mutex flow_mu[64];
+            static hipEvent_t flow_ev[64];
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            dev = std::min(std::max(dev, 0), 63);
+            std::lock_guard<std::mutex> lock(flow_mu[dev]);
+            if (flow_ev[dev]) (void)hipStreamWaitEvent(s, flow_ev[dev], 0);
+            else (void)hipEventCreateWithFlags(&flow_ev[dev], hipEventDisableTiming);
+            hipLaunchKernelGGL(chol_flow_kernel, dim3(flow_groups), dim3(256), 0, s, f);
+            if (flow_ev[dev]) (void)hipEventRecord(flow_ev[dev], s);
+        }
         if (!f.x)
             hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(1024), (size_t)2 * N * sizeof(double), s, Lmat, N,
                 nblk, n, Ldiag, x, lm);

@@ -40,13 +40,6 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 namespace {
 
-__device__ __forceinline__ int med3s(int a, int b, int c)
-{
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 // (best, index, second) <- candidate (ip, idx) with its own second; larger index wins ties
 __device__ __forceinline__ void fold_top2(int &bip, int &bidx, int &sec, int ip, int idx, int ip2)
 {
@@ -74,7 +67,6 @@ match_special_kernel(const MatchProblem *__restrict__ problems, const SpecialJob
 
     const SpecialJob job = jobs[blockIdx.x];
     const bool many = job.count == 0;
-    const int nslots_max = many ? NS : job.count;
     // the streamed operand: the other set of entry 0 (the same view for every entry of the job)
     const MatchProblem &p0 = problems[job.problem[0]];
     const int8_t *__restrict__ O = job.side[0] == 0 ? p0.B : p0.A;
@@ -112,7 +104,6 @@ match_special_kernel(const MatchProblem *__restrict__ problems, const SpecialJob
 #pragma unroll
             for (int r = 0; r < 16; ++r) ra[t][r] = corrS[(r & 3) + 8 * (r >> 2) + 4 * lh];
         }
-        (void)nslots_max;
         // resident A fragments of the slots' rows
         v4i a[NS][4];
 #pragma unroll

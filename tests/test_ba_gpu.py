@@ -313,3 +313,25 @@ def test_work_arrays_are_cached_and_can_be_handed_back(ba):
     # (the driver accounts whole pages, so its numbers and the pool's byte count differ slightly)
     assert released > 0 and free3 > free1 and free3 >= free0 - (1 << 22)
     assert capi.trim_device_memory() == 0    # nothing left
+
+
+def test_concurrent_solves_share_the_device(ba):
+    """Two host threads solving at once (their own streams): the one-launch Cholesky needs all its workgroups
+    resident, so such launches are chained on the device instead of interleaving -- every solve finishes and
+    equals the serial one bit for bit."""
+    import threading
+    sc = synth.make_ba_scene(0, 60, 6000, config_id=36)          # 300 camera unknowns: ten block columns
+    ref = ba.FlatProblem.from_scene(sc.copy())
+    s0 = ba.solve(ref)
+    out = [None] * 6
+    def work(k):
+        fp = ba.FlatProblem.from_scene(sc.copy())
+        s = ba.solve(fp)
+        out[k] = (s.num_iterations, s.final_cost, fp.cam_params.copy(), s.termination)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for k in range(6):
+        assert out[k] is not None
+        assert out[k][0] == s0.num_iterations and out[k][1] == s0.final_cost and out[k][3] == s0.termination
+        assert np.array_equal(out[k][2], ref.cam_params)
