@@ -515,7 +515,7 @@ OSFM_API int osfm_tracks_builder_destroy(osfm_tracks_builder *b);
 
 /* The observation arrays of an osfm_ba_problem from a scene's tracks in one pass -- what
  * runBundleAdjustment / triangulateOrthographicTracks build residual by residual from their
- * std::vector<Track> (bundle_adjustment.cpp:86-123, triangulation.cpp:23-60): features are in
+ * std::vector<Track> (bundle_adjustment.cpp:86-123, triangulation.cpp:43-93): features are in
  * track order; feature i is taken when live[i] != 0, camera_of_feature[i] >= 0 (its view has a
  * camera) and (track_mask == NULL or track_mask[track_of[i]] != 0).  obs_point[k] = track_slot[track]
  * when track_slot is given (the caller's numbering of the point blocks), else the rank of the track
