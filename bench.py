@@ -261,6 +261,23 @@ def ba_roofline(ba):
             "iterations_per_s": its}
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """File descriptor 1 points at stderr inside the block (C++ code of the reference writes to std::cout):
+    the bench's stdout carries the one JSON line and nothing else."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def cascade_bench(iset, V, pairs, capacity, device_index, with_cpu):
     """The same pairs through the cascade-hashing mode (sfm::CascadeHashing, the
     application's default, approximate matcher).  CPU baseline: the reference's
@@ -291,7 +308,8 @@ def cascade_bench(iset, V, pairs, capacity, device_index, with_cpu):
             nv = min(V, 6)
             empty = [np.zeros((0, 64), np.int16)] * nv
             t0 = time.perf_counter()
-            ref = oracle_lib.RefCasHash(iset.sift[:nv], empty)
+            with stdout_to_stderr():          # the reference's init prints its timing to std::cout
+                ref = oracle_lib.RefCasHash(iset.sift[:nv], empty)
             t_init = time.perf_counter() - t0
             sample = [(a, b) for a in range(nv) for b in range(a)]
             t0 = time.perf_counter()
