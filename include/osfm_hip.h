@@ -115,7 +115,8 @@ typedef struct osfm_match_options {
      * do not fit the raw int8 operand of the correction-free score-tile kernel.  A view with
      * at most this many of them keeps all its other descriptors on that kernel and the
      * special ones are scored by a kernel of their own; a view with more takes the slower
-     * per-view operand forms.  0: default (512); negative: always the per-view forms.
+     * per-view operand forms.  0: default (512, also the largest value taken); negative: always the
+     * per-view forms.
      * Results are identical either way. */
     int32_t special_kernel_max;
 } osfm_match_options;

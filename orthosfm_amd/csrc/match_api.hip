@@ -1003,7 +1003,8 @@ int osfm_match_create(int device, int num_views, const osfm_match_options *opts,
         OSFM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_compact[j], hipEventDisableTiming));
         OSFM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_copied[j], hipEventDisableTiming));
     }
-    if (m->opts.special_kernel_max != 0) m->special_max = std::max(m->opts.special_kernel_max, 0);
+    // at most 512: the finish kernel's scan of the special rows keys them with nine bits
+    if (m->opts.special_kernel_max != 0) m->special_max = std::min(std::max(m->opts.special_kernel_max, 0), 512);
     std::vector<int32_t> t;
     build_lowe_table(m->opts.sift_lowe_ratio, false, &t);
     OSFM_RETURN_IF(m->lowe_sift.reserve(t.size() * 4));
