@@ -370,6 +370,55 @@ def test_special_descriptors_edge_shapes(hm):
             m.close()
 
 
+def test_special_descriptors_random_sweep(hm):
+    """Thirty random pairs: sizes 1..2500 (off every multiple), 0..70 special rows per view of several kinds
+    (peaky rows as MVE makes them, rows with one byte just over 127, near-duplicates of ordinary rows lifted over
+    the limit, all-255 rows whose products leave the 16-bit range), ties planted between special and ordinary rows,
+    three ratios -- the special-descriptor kernel and the per-view forms both against the oracle."""
+    from orthosfm_amd import capi
+    om = oracle_lib.oracle_matcher()
+    base = synth.make_image_set(2, 2500, config_id=37)
+    r = np.random.default_rng(123)
+
+    def mutate(s, k):
+        n = s.shape[0]
+        for _ in range(k):
+            i = int(r.integers(n))
+            kind = int(r.integers(5))
+            if kind == 0:
+                d = np.zeros(128, np.uint16); d[r.choice(128, 2, replace=False)] = [int(r.integers(128, 256)), int(r.integers(0, 128))]
+            elif kind == 1:
+                d = s[i].copy(); d[int(r.integers(128))] = 128
+            elif kind == 2:
+                d = s[int(r.integers(n))].copy(); d[int(r.integers(128))] = int(r.integers(128, 200))
+            elif kind == 3:
+                d = np.full(128, 255, np.uint16)
+            else:
+                d = s[i].copy(); d[:4] = 200
+            s[i] = d
+        return s
+
+    for case in range(30):
+        n1, n2 = int(r.integers(1, 2500)), int(r.integers(1, 2500))
+        s1 = mutate(base.sift[0][r.permutation(2500)[:n1]].copy(), int(r.integers(0, 71)) if case % 5 else 0)
+        s2 = mutate(base.sift[1][r.permutation(2500)[:n2]].copy(), int(r.integers(0, 71)) if case % 7 else 0)
+        if n1 > 3 and n2 > 3:                # a row of the one view planted twice in the other: ties
+            s2[0] = s1[1]; s2[2] = s1[1]; s1[3] = s2[1]
+        lowe = (0.6, 0.8, 1.0)[case % 3]
+        e12, e21 = om.twoway(s1, s2, lowe)
+        c12, c21 = om.remove_inconsistent(e12, e21)
+        for smax in (0, -1):
+            o = capi.default_match_options()
+            o.sift_lowe_ratio = lowe
+            o.special_kernel_max = smax
+            m = hm(2, options=o)
+            m.set_view(0, s1)
+            m.set_view(1, s2)
+            got = m.pairwise_match(0, 1)
+            assert np.array_equal(got.matches_1_2, c12) and np.array_equal(got.matches_2_1, c21), (case, smax, n1, n2, lowe)
+            m.close()
+
+
 def test_mixed_operand_forms_in_one_batch(hm):
     """One compute() over views with and without entries > 127: the launch then
     holds problems for all three kernel kinds (correction-free raw operands,
