@@ -491,7 +491,9 @@ def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, ti
             "num_mve_tracks": int(summary.num_tracks), "invalid_mve_tracks": int(summary.num_invalid_tracks),
             "pair_status": status}
     builder.close()
-    m.close()
+    # the matcher's device memory (the bank, 16 GB of partial-result scratch) goes back on a thread of its
+    # own: freeing it takes 0.1 s that the pose estimation need not wait for
+    threading.Thread(target=m.close, daemon=True).start()
     return tt, info
 
 
@@ -569,7 +571,7 @@ def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2
             mask = np.zeros(tt.alive_t.shape[0], dtype=np.uint8)
             mask[tracks_subset] = 1
         obs_xy, obs_cam, obs_pt, uniq, _ = T.select_observations(tt.track_of, tt.cam_f, tt.live_f, tt.xy, track_mask=mask)
-        uniq = uniq.astype(np.int64)
+        uniq = uniq.astype(np.int64)                    # a copy: the selector's buffers are reused
         start = np.zeros((uniq.size, 4))
         start[:, 3] = 1.0
         prob = _problem(model, cams[aligned], const[aligned], W, H, start, obs_xy, obs_cam, obs_pt)

@@ -106,18 +106,29 @@ def compute_flat_ranges(view_sizes, colors, pairs, pair_starts, pair_counts, cor
             track_colors[:nt], summary)
 
 
+_SELECT_BUFFERS = {}
+
+
 def select_observations(track_of, cam_f, live, xy, track_mask=None, track_slot=None, want_features=False):
     """osfm_tracks_select_observations: (obs_xy, obs_camera, obs_point, tracks, feature_ids) of the live
     features whose view has a camera, optionally restricted to the tracks of a mask; obs_point numbers the
     tracks by track_slot when given, else densely in order of appearance (tracks = their ids)."""
     n = int(track_of.shape[0])
-    # a selection is rarely the whole table: size the outputs by what the mask can admit
+    # output buffers are kept between calls (fresh arrays of the table's size cost more in page faults than
+    # the pass itself); the slices returned are overwritten by the next call -- callers copy what they keep
+    # (FlatProblem does)
     cap = n
-    obs_xy = np.empty((cap, 2), dtype=np.float64)
-    obs_cam = np.empty(cap, dtype=np.int32)
-    obs_pt = np.empty(cap, dtype=np.int32)
-    tracks = np.empty(cap, dtype=np.int32) if track_slot is None else None
-    fids = np.empty(cap, dtype=np.int32) if want_features else None
+    buf = _SELECT_BUFFERS
+    if buf.get("cap", -1) < cap:
+        buf["cap"] = cap
+        buf["xy"] = np.empty((cap, 2), dtype=np.float64)
+        buf["cam"] = np.empty(cap, dtype=np.int32)
+        buf["pt"] = np.empty(cap, dtype=np.int32)
+        buf["tracks"] = np.empty(cap, dtype=np.int32)
+        buf["fids"] = np.empty(cap, dtype=np.int32)
+    obs_xy, obs_cam, obs_pt = buf["xy"], buf["cam"], buf["pt"]
+    tracks = buf["tracks"] if track_slot is None else None
+    fids = buf["fids"] if want_features else None
     nobs, nt = C.c_int64(), C.c_int64()
     live8 = live.view(np.uint8) if live.dtype == np.bool_ else live
     mask8 = None if track_mask is None else (track_mask.view(np.uint8) if track_mask.dtype == np.bool_ else track_mask)
