@@ -514,6 +514,20 @@ OSFM_API int osfm_tracks_builder_finish(const osfm_tracks_builder *b, const uint
     osfm_tracks_summary *summary);
 OSFM_API int osfm_tracks_builder_destroy(osfm_tracks_builder *b);
 
+/* The feature table the reconstruction works on, from the tracks (the conversion at the end of
+ * calculateTracksUsingMVE, matching_mve.cpp:455-466): for feature i of the tracks (track order,
+ * track_features = (view, feature) pairs as osfm_tracks_compute writes them) view_out[i], feat_out[i],
+ * xy_out[2i..] = the pixel position  float(image_width * (double(normalised) + 0.5))  for BOTH axes
+ * (stored as the double of that float: Feature::x/y are float, track.h:26-27), track_of_out[i]
+ * (may be NULL), and -- both or neither -- by_view_out (the feature indices grouped by view,
+ * ascending inside a view) with view_start_out[num_views + 1].  norm_positions[v] points to view v's
+ * [view_sizes[v]][2] normalised positions.  OSFM_E_RANGE for a feature outside its view. */
+OSFM_API int osfm_tracks_feature_table(int64_t num_tracks, const int64_t *track_offsets,
+    const int32_t *track_features, int32_t num_views, const int32_t *view_sizes,
+    const float *const *norm_positions, double image_width,
+    int32_t *view_out, int32_t *feat_out, double *xy_out, int32_t *track_of_out,
+    int64_t *by_view_out, int64_t *view_start_out);
+
 /* The observation arrays of an osfm_ba_problem from a scene's tracks in one pass -- what
  * runBundleAdjustment / triangulateOrthographicTracks build residual by residual from their
  * std::vector<Track> (bundle_adjustment.cpp:86-123, triangulation.cpp:43-93): features are in
@@ -524,6 +538,7 @@ OSFM_API int osfm_tracks_builder_destroy(osfm_tracks_builder *b);
  * well).  feature_ids (may be NULL) receives the taken feature indices.  *num_observations is always
  * set; OSFM_E_CAPACITY when it exceeds `capacity`. */
 OSFM_API int osfm_tracks_select_observations(int64_t num_features, const int32_t *track_of,
+    const int64_t *track_offsets /* [num_tracks + 1] or NULL: lets the pass jump over unselected tracks */,
     const int32_t *camera_of_feature, const uint8_t *live, const uint8_t *track_mask,
     const int32_t *track_slot, const double *xy, int64_t capacity, int32_t *feature_ids,
     double *obs_xy, int32_t *obs_camera, int32_t *obs_point, int32_t *tracks_out,

@@ -127,6 +127,7 @@ EXPORTS = [
     "osfm_tracks_compute", "osfm_tracks_compute_ranges", "osfm_build_groups",
     "osfm_tracks_builder_create", "osfm_tracks_builder_feed", "osfm_tracks_builder_finish", "osfm_tracks_builder_destroy",
     "osfm_tracks_select_observations",
+    "osfm_tracks_feature_table",
     "osfm_tracks_file_write", "osfm_tracks_file_read", "osfm_tracks_pairwise_files_write",
     "osfm_tracks_from_mve", "osfm_cameras_file_write", "osfm_cameras_file_read",
     "osfm_sparse_cloud_write", "osfm_time_measurements_write", "osfm_time_measurements_read",

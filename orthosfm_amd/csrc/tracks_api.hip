@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "osfm_common.h"
@@ -128,41 +129,101 @@ static int builder_finish(const osfm_tracks_builder *b, const uint8_t *colors,
     // track lie all over the feature array), and two walks -- validate, then write -- were most of
     // this function's time.  A track is written where it would go and discarded (the write position
     // rolls back) when a second feature of one view turns up.
+    //
+    // The walks of different tracks are independent, and each is bound by memory latency, so the
+    // tracks are cut into ranges of equal node counts, one per host thread: a thread walks its range
+    // into buffers of its own, and the ranges are then laid end to end (the order of the reference:
+    // tracks by id).
     const int64_t nt = (int64_t)head.size();
     std::vector<int32_t> map((size_t)nt, -1);
-    std::vector<int64_t> seen((size_t)num_views, -1);
+    int64_t total_nodes = 0;
+    for (int64_t t = 0; t < nt; ++t) total_nodes += size[t];
+    int workers = 1;
+    if (const char *e = getenv("OSFM_TRACKS_THREADS")) workers = std::max(1, std::min(64, atoi(e)));
+    else if (total_nodes >= (int64_t)1 << 16)
+        workers = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    struct Range {
+        int64_t t0 = 0, t1 = 0;
+        std::vector<int32_t> feats;          // (view, feature) of the kept tracks, in order
+        std::vector<int64_t> starts;         // per kept track: first feature in feats
+        std::vector<uint8_t> cols;
+        std::vector<int64_t> kept;           // ids of the kept tracks
+        int32_t invalid = 0;
+    };
+    std::vector<Range> ranges((size_t)workers);
+    {
+        int64_t t = 0, acc = 0;
+        for (int w = 0; w < workers; ++w) {
+            ranges[w].t0 = t;
+            const int64_t want = total_nodes * (w + 1) / workers;
+            while (t < nt && (acc < want || w == workers - 1)) acc += size[t++];
+            ranges[w].t1 = t;
+        }
+    }
+    auto walk = [&](Range &R) {
+        std::vector<int64_t> seen((size_t)num_views, -1);
+        int64_t cap = 0;
+        for (int64_t t = R.t0; t < R.t1; ++t) cap += size[t];
+        R.feats.resize((size_t)2 * cap);
+        int64_t nf = 0;
+        for (int64_t t = R.t0; t < R.t1; ++t) {
+            if (size[t] == 0) continue;
+            bool bad = twice[t] != 0;
+            const int64_t start = nf;
+            float col[4] = {0.0f, 0.0f, 0.0f, 0.0f};                                // :133-143
+            for (int64_t g = head[t]; g >= 0 && !bad; g = nxt[g]) {
+                // view of node g: the last voff entry <= g (views are few: binary search)
+                int lo = 0, hi = num_views - 1;
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (voff[mid] <= g) lo = mid; else hi = mid - 1; }
+                if (seen[lo] == t) { bad = true; break; }
+                seen[lo] = t;
+                R.feats[2 * nf] = lo;
+                R.feats[2 * nf + 1] = (int32_t)(g - voff[lo]);
+                ++nf;
+                for (int c = 0; c < 3; ++c) col[c] += colors ? (float)colors[3 * g + c] : 0.0f;
+                col[3] += 1.0f;
+            }
+            if (bad) { R.invalid++; nf = start; continue; }
+            R.starts.push_back(start);
+            for (int c = 0; c < 3; ++c) R.cols.push_back((uint8_t)(col[c] / col[3] + 0.5f));
+            R.kept.push_back(t);
+        }
+        R.feats.resize((size_t)2 * nf);
+    };
+    if (workers == 1) walk(ranges[0]);
+    else {
+        std::vector<std::thread> th;
+        for (int w = 1; w < workers; ++w) th.emplace_back([&, w] { walk(ranges[w]); });
+        walk(ranges[0]);
+        for (auto &x : th) x.join();
+    }
     int32_t invalid = 0, valid = 0;
     int64_t nf = 0;
-    bool overflow = false;
-    for (int64_t t = 0; t < nt; ++t) {
-        if (size[t] == 0) continue;
-        bool bad = twice[t] != 0;
-        const int64_t start = nf;
-        float col[4] = {0.0f, 0.0f, 0.0f, 0.0f};                                // :133-143
-        for (int64_t g = head[t]; g >= 0 && !bad; g = nxt[g]) {
-            // view of node g: the last voff entry <= g (views are few: binary search)
-            int lo = 0, hi = num_views - 1;
-            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (voff[mid] <= g) lo = mid; else hi = mid - 1; }
-            if (seen[lo] == t) { bad = true; break; }
-            seen[lo] = t;
-            if (nf < feature_capacity) {
-                track_features[2 * nf] = lo;
-                track_features[2 * nf + 1] = (int32_t)(g - voff[lo]);
-            } else {
-                overflow = true;
+    std::vector<int64_t> base_f((size_t)workers), base_t((size_t)workers);
+    for (int w = 0; w < workers; ++w) {
+        base_f[w] = nf; base_t[w] = valid;
+        nf += (int64_t)ranges[w].feats.size() / 2;
+        valid += (int32_t)ranges[w].kept.size();
+        invalid += ranges[w].invalid;
+    }
+    const bool overflow = valid > track_capacity || nf > feature_capacity;
+    if (!overflow) {
+        auto place = [&](int w) {
+            const Range &R = ranges[w];
+            if (!R.feats.empty()) memcpy(track_features + 2 * base_f[w], R.feats.data(), R.feats.size() * sizeof(int32_t));
+            for (size_t k = 0; k < R.kept.size(); ++k) {
+                track_offsets[base_t[w] + (int64_t)k] = base_f[w] + R.starts[k];
+                map[(size_t)R.kept[k]] = (int32_t)(base_t[w] + (int64_t)k);
             }
-            ++nf;
-            for (int c = 0; c < 3; ++c) col[c] += colors ? (float)colors[3 * g + c] : 0.0f;
-            col[3] += 1.0f;
+            if (!R.cols.empty()) memcpy(track_colors + 3 * base_t[w], R.cols.data(), R.cols.size());
+        };
+        if (workers == 1) place(0);
+        else {
+            std::vector<std::thread> th;
+            for (int w = 1; w < workers; ++w) th.emplace_back([&, w] { place(w); });
+            place(0);
+            for (auto &x : th) x.join();
         }
-        if (bad) { invalid++; nf = start; continue; }
-        if (valid < track_capacity) {
-            track_offsets[valid] = start;
-            for (int c = 0; c < 3; ++c) track_colors[3 * valid + c] = (uint8_t)(col[c] / col[3] + 0.5f);
-        } else {
-            overflow = true;
-        }
-        map[t] = valid++;
     }
     const int64_t kept_features = nf;
     if (track_ids)          // Viewport::track_ids (the builder's finish may leave them out)
@@ -247,7 +308,8 @@ int osfm_tracks_builder_destroy(osfm_tracks_builder *b)
 // (track_mask == NULL or track_mask[track_of[i]] != 0).  obs_point[k] = track_slot[track] when
 // track_slot is given (the caller's numbering of the parameter blocks), else the rank of the track
 // among the tracks that contributed a feature, whose ids then go to tracks_out.
-int osfm_tracks_select_observations(int64_t num_features, const int32_t *track_of, const int32_t *camera_of_feature,
+int osfm_tracks_select_observations(int64_t num_features, const int32_t *track_of, const int64_t *track_offsets,
+    const int32_t *camera_of_feature,
     const uint8_t *live, const uint8_t *track_mask, const int32_t *track_slot, const double *xy,
     int64_t capacity, int32_t *feature_ids, double *obs_xy, int32_t *obs_camera, int32_t *obs_point,
     int32_t *tracks_out, int64_t *num_observations, int64_t *num_tracks_out)
@@ -260,10 +322,39 @@ int osfm_tracks_select_observations(int64_t num_features, const int32_t *track_o
     }
     int64_t n = 0, nt = 0;
     int32_t last = -1;
+    if (track_offsets && capacity >= num_features && num_features > 0) {
+        // Track by track, without a branch per feature: whether a feature's view has a camera is as good
+        // as random along a track while half the views are aligned, and a mispredicted branch per feature
+        // was most of this pass.  Every feature is written to the next free slot and the slot is kept or
+        // not (n <= i < capacity, so the write is always inside the buffers).
+        const int32_t num_tracks = track_of[num_features - 1] + 1;
+        for (int32_t t = 0; t < num_tracks; ++t) {
+            if (track_mask && !track_mask[t]) continue;
+            const int64_t n0 = n;
+            const int32_t pt = track_slot ? track_slot[t] : (int32_t)nt;
+            for (int64_t i = track_offsets[t]; i < track_offsets[t + 1]; ++i) {
+                const int32_t c = camera_of_feature[i];
+                if (feature_ids) feature_ids[n] = (int32_t)i;
+                obs_xy[2 * n] = xy[2 * i]; obs_xy[2 * n + 1] = xy[2 * i + 1];
+                obs_camera[n] = c;
+                obs_point[n] = pt;
+                n += (int64_t)((live[i] != 0) & (c >= 0));
+            }
+            if (n != n0) { if (!track_slot && tracks_out) tracks_out[nt] = t; ++nt; }
+        }
+        *num_observations = n;
+        if (num_tracks_out) *num_tracks_out = nt;
+        return OSFM_OK;
+    }
     for (int64_t i = 0; i < num_features; ++i) {
-        if (!live[i] || camera_of_feature[i] < 0) continue;
         const int32_t t = track_of[i];
-        if (track_mask && !track_mask[t]) continue;
+        if (track_mask && !track_mask[t]) {
+            // features are in track order: skip the rest of an unselected track in one step when the
+            // caller's offsets are at hand, else feature by feature
+            if (track_offsets) i = track_offsets[t + 1] - 1;
+            continue;
+        }
+        if (!live[i] || camera_of_feature[i] < 0) continue;
         if (n < capacity) {
             if (feature_ids) feature_ids[n] = (int32_t)i;
             obs_xy[2 * n] = xy[2 * i]; obs_xy[2 * n + 1] = xy[2 * i + 1];
@@ -278,6 +369,89 @@ int osfm_tracks_select_observations(int64_t num_features, const int32_t *track_o
     if (n > capacity) {
         set_error("tracks_select_observations: %lld observations exceed the capacity %lld", (long long)n, (long long)capacity);
         return OSFM_E_CAPACITY;
+    }
+    return OSFM_OK;
+}
+
+// The feature table of the reconstruction from the tracks (calculateTracksUsingMVE's conversion,
+// matching_mve.cpp:455-466): per feature of every track its view, its index in the view, its pixel
+// position  float(imageWidth * (double(normalised) + 0.5))  for both axes, the track it belongs to, and
+// the features grouped by view (ascending inside a view).  One pass on several host threads; the
+// grouping is a stable counting sort with per-thread histograms.
+int osfm_tracks_feature_table(int64_t num_tracks, const int64_t *track_offsets, const int32_t *track_features,
+    int32_t num_views, const int32_t *view_sizes, const float *const *norm_positions, double image_width,
+    int32_t *view_out, int32_t *feat_out, double *xy_out, int32_t *track_of_out,
+    int64_t *by_view_out, int64_t *view_start_out)
+{
+    if (num_tracks < 0 || num_views < 0 || !track_offsets || (num_views > 0 && (!view_sizes || !norm_positions))) {
+        set_error("tracks_feature_table: bad arguments");
+        return OSFM_E_ARG;
+    }
+    const int64_t nf = track_offsets[num_tracks];
+    if (nf < 0 || (nf > 0 && (!track_features || !view_out || !feat_out || !xy_out))) {
+        set_error("tracks_feature_table: null array");
+        return OSFM_E_ARG;
+    }
+    if ((by_view_out && !view_start_out) || (view_start_out && !by_view_out && nf > 0)) {
+        set_error("tracks_feature_table: by_view and view_start go together");
+        return OSFM_E_ARG;
+    }
+    int workers = 1;
+    if (const char *e = getenv("OSFM_TRACKS_THREADS")) workers = std::max(1, std::min(64, atoi(e)));
+    else if (nf >= (int64_t)1 << 16)
+        workers = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<std::vector<int64_t>> hist((size_t)workers, std::vector<int64_t>((size_t)num_views + 1, 0));
+    std::vector<int64_t> bad((size_t)workers, -1);
+    auto run = [&](auto &&fn) {
+        if (workers == 1) { fn(0); return; }
+        std::vector<std::thread> th;
+        for (int w = 1; w < workers; ++w) th.emplace_back([&, w] { fn(w); });
+        fn(0);
+        for (auto &x : th) x.join();
+    };
+    run([&](int w) {
+        const int64_t i0 = nf * w / workers, i1 = nf * (w + 1) / workers;
+        // the track of feature i0: the last offset <= i0
+        int64_t t = 0;
+        if (track_of_out && num_tracks > 0) {
+            int64_t lo = 0, hi = num_tracks - 1;
+            while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if (track_offsets[mid] <= i0) lo = mid; else hi = mid - 1; }
+            t = lo;
+        }
+        auto &h = hist[(size_t)w];
+        for (int64_t i = i0; i < i1; ++i) {
+            const int32_t v = track_features[2 * i], f = track_features[2 * i + 1];
+            if (v < 0 || v >= num_views || f < 0 || f >= view_sizes[v] || !norm_positions[v]) { bad[(size_t)w] = i; return; }
+            view_out[i] = v; feat_out[i] = f;
+            const float *p = norm_positions[v] + 2 * (size_t)f;
+            xy_out[2 * i] = (double)(float)(image_width * ((double)p[0] + 0.5));
+            xy_out[2 * i + 1] = (double)(float)(image_width * ((double)p[1] + 0.5));
+            if (track_of_out) {
+                while (track_offsets[t + 1] <= i) ++t;
+                track_of_out[i] = (int32_t)t;
+            }
+            h[(size_t)v]++;
+        }
+    });
+    for (int w = 0; w < workers; ++w)
+        if (bad[(size_t)w] >= 0) {
+            set_error("tracks_feature_table: feature %lld names view %d / feature %d out of range", (long long)bad[(size_t)w],
+                track_features[2 * bad[(size_t)w]], track_features[2 * bad[(size_t)w] + 1]);
+            return OSFM_E_RANGE;
+        }
+    if (view_start_out) {
+        // first slot of (view, thread): views in order, threads in order inside a view
+        int64_t pos = 0;
+        for (int v = 0; v < num_views; ++v) {
+            view_start_out[v] = pos;
+            for (int w = 0; w < workers; ++w) { const int64_t c = hist[(size_t)w][(size_t)v]; hist[(size_t)w][(size_t)v] = pos; pos += c; }
+        }
+        view_start_out[num_views] = pos;
+        run([&](int w) {
+            const int64_t i0 = nf * w / workers, i1 = nf * (w + 1) / workers;
+            auto &h = hist[(size_t)w];
+            for (int64_t i = i0; i < i1; ++i) by_view_out[h[(size_t)view_out[i]]++] = i;
+        });
     }
     return OSFM_OK;
 }

@@ -63,14 +63,17 @@ class TrackTable:
     alive flags the filters clear (a filtered std::vector<Track> in the
     reference is the subset with both flags set here)."""
 
-    def __init__(self, offsets, view, feat, xy, num_views):
+    def __init__(self, offsets, view, feat, xy, num_views, _table=None):
         self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
-        self.view = np.ascontiguousarray(view, dtype=np.int32)
-        self.feat = np.ascontiguousarray(feat, dtype=np.int32)
-        self.xy = np.ascontiguousarray(xy, dtype=np.float32).astype(np.float64)
         self.num_views = int(num_views)
         T_ = self.offsets.shape[0] - 1
-        self.track_of = np.repeat(np.arange(T_, dtype=np.int32), np.diff(self.offsets))
+        if _table is not None:           # from_mve: everything per feature comes from one pass of the library
+            self.view, self.feat, self.xy, self.track_of, self.by_view, self.view_start = _table
+        else:
+            self.view = np.ascontiguousarray(view, dtype=np.int32)
+            self.feat = np.ascontiguousarray(feat, dtype=np.int32)
+            self.xy = np.ascontiguousarray(xy, dtype=np.float32).astype(np.float64)
+            self.track_of = np.repeat(np.arange(T_, dtype=np.int32), np.diff(self.offsets))
         self.point = np.zeros((T_, 4))
         self.has_point = np.zeros(T_, dtype=bool)
         self.alive_t = np.ones(T_, dtype=bool)
@@ -79,21 +82,18 @@ class TrackTable:
         self.live_f = np.ones(self.view.shape[0], dtype=bool)        # alive_f & alive_t[track_of]
         self.cam_f = np.full(self.view.shape[0], -1, dtype=np.int32)  # camera index of the feature's view, -1: not aligned
         self._lengths = np.diff(self.offsets).astype(np.int64)        # alive features per alive track
-        order = _stable_order_by_view(self.view, self.num_views)             # feature ids grouped by view, ascending inside
-        self.by_view = order
-        self.view_start = np.concatenate([[0], np.cumsum(np.bincount(self.view, minlength=self.num_views))]).astype(np.int64)
+        if _table is None:
+            self.by_view = _stable_order_by_view(self.view, self.num_views)       # feature ids grouped by view, ascending inside
+            self.view_start = np.concatenate([[0], np.cumsum(np.bincount(self.view, minlength=self.num_views))]).astype(np.int64)
 
     @classmethod
     def from_mve(cls, track_offsets, track_features, norm_positions, image_width, num_views):
         """matching_mve.cpp:455-466: pixel = imageWidth * (normalised + 0.5) for BOTH axes
         (double arithmetic, stored as float)."""
-        tf = np.asarray(track_features, dtype=np.int32).reshape(-1, 2)
-        view, feat = tf[:, 0], tf[:, 1]
-        voff = np.concatenate([[0], np.cumsum([len(p) for p in norm_positions])]).astype(np.int64)
-        pos_all = np.concatenate([np.asarray(p, dtype=np.float32).reshape(-1, 2) for p in norm_positions])
-        p = pos_all[voff[view] + feat].astype(np.float64)
-        xy = (float(image_width) * (p + 0.5)).astype(np.float32)
-        return cls(track_offsets, view, feat, xy, num_views)
+        if len(norm_positions) != num_views:
+            raise ValueError("from_mve: one position array per view")
+        table = T.feature_table(track_offsets, track_features, norm_positions, image_width)
+        return cls(track_offsets, None, None, None, num_views, _table=table)
 
     @property
     def num_tracks(self):
@@ -493,8 +493,19 @@ def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, ti
     builder.close()
     # the matcher's device memory (the bank, 16 GB of partial-result scratch) goes back on a thread of its
     # own: freeing it takes 0.1 s that the pose estimation need not wait for
-    threading.Thread(target=m.close, daemon=True).start()
+    closer = threading.Thread(target=m.close, daemon=True)
+    closer.start()
+    _background.append(closer)
     return tt, info
+
+
+_background = []
+
+
+def join_background():
+    """Wait for what earlier jobs left running beside the caller (the release of a matcher's device memory)."""
+    while _background:
+        _background.pop().join()
 
 
 def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2.0, off_perturb=0.01,
@@ -570,7 +581,7 @@ def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2
         if tracks_subset is not None:
             mask = np.zeros(tt.alive_t.shape[0], dtype=np.uint8)
             mask[tracks_subset] = 1
-        obs_xy, obs_cam, obs_pt, uniq, _ = T.select_observations(tt.track_of, tt.cam_f, tt.live_f, tt.xy, track_mask=mask)
+        obs_xy, obs_cam, obs_pt, uniq, _ = T.select_observations(tt.track_of, tt.cam_f, tt.live_f, tt.xy, track_mask=mask, track_offsets=tt.offsets)
         uniq = uniq.astype(np.int64)                    # a copy: the selector's buffers are reused
         start = np.zeros((uniq.size, 4))
         start[:, 3] = 1.0
@@ -718,7 +729,7 @@ def _global_ba(tt, model, cams, const, aligned, W, H, V, solve, kind, opt, tm):
     tsel = np.flatnonzero(with_point)
     slot = (np.cumsum(with_point) - 1).astype(np.int32)                  # track -> row of tsel
     obs_xy, obs_cam, obs_pt, _, _ = T.select_observations(tt.track_of, tt.cam_f, tt.live_f, tt.xy,
-                                                          track_mask=with_point, track_slot=slot)
+                                                          track_mask=with_point, track_slot=slot, track_offsets=tt.offsets)
     prob = _problem(model, cams[aligned], const[aligned], W, H, tt.point[tsel], obs_xy, obs_cam, obs_pt)
     tm.pose_host_s += time.perf_counter() - t0
     s, dt = solve(kind, prob, opt)
@@ -744,6 +755,7 @@ def reconstruct(iset, solver=0, matcher="exhaustive", device=0, verify=True, rot
     cams, aligned, groups, calls, captured = run_pose_estimation(
         tt, iset, model, device, rot_perturb_deg, off_perturb, seed, tm, capture, max_groups, verbose,
         euler_dof=euler_dof_of_solver(solver), check_incremental=check_incremental)
+    join_background()            # inside the clock: the matcher's memory is back when the job is done
     tm.total_s = time.perf_counter() - t_all
     return Result(cams, aligned, tt, groups, tm, calls, captured=captured, **info)
 

@@ -106,10 +106,35 @@ def compute_flat_ranges(view_sizes, colors, pairs, pair_starts, pair_counts, cor
             track_colors[:nt], summary)
 
 
+def feature_table(track_offsets, track_features, norm_positions, image_width, want_order=True):
+    """osfm_tracks_feature_table: (view, feat, xy, track_of, by_view, view_start) of the features of the tracks;
+    norm_positions[v] = view v's float32 [n_v, 2] normalised positions."""
+    offs = np.ascontiguousarray(track_offsets, dtype=np.int64)
+    tf = np.ascontiguousarray(track_features, dtype=np.int32).reshape(-1, 2)
+    V = len(norm_positions)
+    pos = [np.ascontiguousarray(p, dtype=np.float32).reshape(-1, 2) for p in norm_positions]
+    sizes = np.array([p.shape[0] for p in pos], dtype=np.int32)
+    ptrs = (C.c_void_p * max(V, 1))(*[p.ctypes.data for p in pos])
+    nt = offs.shape[0] - 1
+    nf = int(offs[-1]) if offs.size else 0
+    view = np.empty(nf, dtype=np.int32)
+    feat = np.empty(nf, dtype=np.int32)
+    xy = np.empty((nf, 2), dtype=np.float64)
+    track_of = np.empty(nf, dtype=np.int32)
+    by_view = np.empty(nf, dtype=np.int64) if want_order else None
+    view_start = np.empty(V + 1, dtype=np.int64) if want_order else None
+    capi.check(capi.lib.osfm_tracks_feature_table(
+        C.c_int64(nt), capi._ptr(offs, C.c_int64), capi._ptr(tf, C.c_int32), C.c_int32(V), capi._ptr(sizes, C.c_int32),
+        C.cast(ptrs, C.POINTER(C.POINTER(C.c_float))), C.c_double(float(image_width)),
+        capi._ptr(view, C.c_int32), capi._ptr(feat, C.c_int32), capi._ptr(xy, C.c_double), capi._ptr(track_of, C.c_int32),
+        capi._ptr(by_view, C.c_int64) if want_order else None, capi._ptr(view_start, C.c_int64) if want_order else None))
+    return view, feat, xy, track_of, by_view, view_start
+
+
 _SELECT_BUFFERS = {}
 
 
-def select_observations(track_of, cam_f, live, xy, track_mask=None, track_slot=None, want_features=False):
+def select_observations(track_of, cam_f, live, xy, track_mask=None, track_slot=None, want_features=False, track_offsets=None):
     """osfm_tracks_select_observations: (obs_xy, obs_camera, obs_point, tracks, feature_ids) of the live
     features whose view has a camera, optionally restricted to the tracks of a mask; obs_point numbers the
     tracks by track_slot when given, else densely in order of appearance (tracks = their ids)."""
@@ -133,7 +158,9 @@ def select_observations(track_of, cam_f, live, xy, track_mask=None, track_slot=N
     live8 = live.view(np.uint8) if live.dtype == np.bool_ else live
     mask8 = None if track_mask is None else (track_mask.view(np.uint8) if track_mask.dtype == np.bool_ else track_mask)
     capi.check(capi.lib.osfm_tracks_select_observations(
-        C.c_int64(n), capi._ptr(track_of, C.c_int32), capi._ptr(cam_f, C.c_int32), capi._ptr(live8, C.c_uint8),
+        C.c_int64(n), capi._ptr(track_of, C.c_int32),
+        capi._ptr(track_offsets, C.c_int64) if track_offsets is not None else None,
+        capi._ptr(cam_f, C.c_int32), capi._ptr(live8, C.c_uint8),
         capi._ptr(mask8, C.c_uint8) if mask8 is not None else None,
         capi._ptr(track_slot, C.c_int32) if track_slot is not None else None,
         capi._ptr(xy, C.c_double), C.c_int64(cap), capi._ptr(fids, C.c_int32) if fids is not None else None,

@@ -295,8 +295,9 @@ def test_work_arrays_are_cached_and_can_be_handed_back(ba):
     """The per-call work arrays come from a per-device cache (osfm_common.h: DevicePool):
     a second identical solve allocates nothing new, results do not depend on it, and
     osfm_trim_device_memory returns what is cached to the driver."""
-    from orthosfm_amd import capi
+    from orthosfm_amd import capi, pipeline
     sc = synth.make_ba_scene(synth.MODEL_QUATERNION, 12, 4000, config_id=1)
+    pipeline.join_background()               # a matcher an earlier job released on a thread is gone by now
     capi.trim_device_memory()
     free0, _ = capi.device_memory(0)
     a = ba.FlatProblem.from_scene(sc)

@@ -200,6 +200,51 @@ def test_tracks_builder_equals_one_shot():
     b.close()
 
 
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_finish_is_the_same_on_any_number_of_threads(threads, monkeypatch):
+    """The output walk of osfm_tracks_compute runs on several host threads (ranges of tracks laid end to
+    end): same arrays as the oracle for 1, 3 and 8 of them, invalid tracks and colours included."""
+    monkeypatch.setenv("OSFM_TRACKS_THREADS", str(threads))
+    m = track_cases.random_matching(num_views=11, feats_per_view=140, num_scene_points=220, p_seen=0.6, p_false=0.2, seed=23)
+    got, want = product(m), oracle_lib.oracle_tracks(**m)
+    same(got, want)
+    assert got["num_invalid"] == want["num_invalid"] and want["num_invalid"] > 0
+
+
+@pytest.mark.parametrize("threads", [1, 5])
+def test_feature_table_equals_numpy(threads, monkeypatch):
+    """osfm_tracks_feature_table against the array arithmetic it replaces (matching_mve.cpp:455-466: pixel =
+    float(imageWidth * (double(normalised) + 0.5)) for both axes), the features grouped by view in a stable
+    order; a feature outside its view is refused."""
+    from orthosfm_amd import capi, tracks as T
+    monkeypatch.setenv("OSFM_TRACKS_THREADS", str(threads))
+    r = np.random.default_rng(4)
+    V = 6
+    sizes = r.integers(5, 40, V)
+    pos = [r.uniform(-0.5, 0.5, (n, 2)).astype(np.float32) for n in sizes]
+    lens = r.integers(2, V + 1, 200)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    tf = np.zeros((int(offs[-1]), 2), np.int32)
+    for t in range(200):
+        vs = r.choice(V, lens[t], replace=False)
+        tf[offs[t]:offs[t + 1], 0] = vs
+        tf[offs[t]:offs[t + 1], 1] = [r.integers(0, sizes[v]) for v in vs]
+    view, feat, xy, track_of, by_view, view_start = T.feature_table(offs, tf.reshape(-1), pos, 2048)
+    voff = np.concatenate([[0], np.cumsum(sizes)])
+    p = np.concatenate(pos)[voff[tf[:, 0]] + tf[:, 1]].astype(np.float64)
+    want = (2048.0 * (p + 0.5)).astype(np.float32).astype(np.float64)
+    assert np.array_equal(view, tf[:, 0]) and np.array_equal(feat, tf[:, 1]) and np.array_equal(xy, want)
+    assert np.array_equal(track_of, np.repeat(np.arange(200), lens))
+    assert np.array_equal(by_view, np.argsort(tf[:, 0], kind="stable"))
+    assert np.array_equal(view_start, np.concatenate([[0], np.cumsum(np.bincount(tf[:, 0], minlength=V))]))
+    tf[7, 1] = sizes[tf[7, 0]]
+    with pytest.raises(capi.OsfmError):
+        T.feature_table(offs, tf.reshape(-1), pos, 2048)
+    # no tracks at all
+    view, feat, xy, track_of, by_view, view_start = T.feature_table(np.zeros(1, np.int64), np.zeros(0, np.int32), pos, 2048)
+    assert view.size == 0 and np.array_equal(view_start, np.zeros(V + 1, np.int64))
+
+
 def test_select_observations_equals_numpy():
     """osfm_tracks_select_observations against the index arithmetic it replaces: live features whose view has
     a camera, optionally of masked tracks; points numbered by a slot table or densely in order of appearance."""
@@ -213,18 +258,23 @@ def test_select_observations_equals_numpy():
     xy = r.normal(size=(n, 2))
     mask = r.random(300) < 0.5
     # dense numbering, no mask / with mask
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    # (with the track offsets the pass goes track by track, without them feature by feature)
     for m in (None, mask):
-        sel = live & (cam_f >= 0) & (True if m is None else m[track_of])
-        ids = np.flatnonzero(sel)
-        uniq, inv = np.unique(track_of[ids], return_inverse=True)
-        oxy, ocam, opt, tracks, fids = T.select_observations(track_of, cam_f, live, xy, track_mask=m, want_features=True)
-        assert np.array_equal(fids, ids) and np.array_equal(oxy, xy[ids]) and np.array_equal(ocam, cam_f[ids])
-        assert np.array_equal(tracks, uniq) and np.array_equal(opt, inv)
+        for o in (None, offs):
+            sel = live & (cam_f >= 0) & (True if m is None else m[track_of])
+            ids = np.flatnonzero(sel)
+            uniq, inv = np.unique(track_of[ids], return_inverse=True)
+            oxy, ocam, opt, tracks, fids = T.select_observations(track_of, cam_f, live, xy, track_mask=m, want_features=True,
+                                                                 track_offsets=o)
+            assert np.array_equal(fids, ids) and np.array_equal(oxy, xy[ids]) and np.array_equal(ocam, cam_f[ids])
+            assert np.array_equal(tracks, uniq) and np.array_equal(opt, inv)
     # the caller's numbering
     slot = (np.cumsum(mask) - 1).astype(np.int32)
     sel = live & (cam_f >= 0) & mask[track_of]
-    oxy, ocam, opt, tracks, _ = T.select_observations(track_of, cam_f, live, xy, track_mask=mask, track_slot=slot)
-    assert tracks is None and np.array_equal(opt, slot[track_of[sel]]) and np.array_equal(oxy, xy[sel])
+    for o in (None, offs):
+        oxy, ocam, opt, tracks, _ = T.select_observations(track_of, cam_f, live, xy, track_mask=mask, track_slot=slot, track_offsets=o)
+        assert tracks is None and np.array_equal(opt, slot[track_of[sel]]) and np.array_equal(oxy, xy[sel])
     # nothing selected
     oxy, ocam, opt, tracks, _ = T.select_observations(track_of, np.full(n, -1, np.int32), live, xy)
     assert oxy.shape == (0, 2) and tracks.size == 0

@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Where a bundle adjustment call spends its wall time outside the LM loop (osfm_ba_options.verbose = 2
+prints a lap per stage to stderr): a global-adjustment shape of the 200-view job (200 cameras, 2500
+tracks of 60..100 views) and a local one (3 cameras)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from orthosfm_amd import ba, synth
+for name, C, M, lo, hi in (("global", 200, 2500, 60, 100), ("local", 3, 2500, 3, 3)):
+    sc = synth.make_ba_scene(synth.MODEL_EULER, C, M, config_id=4, min_len=lo, max_len=hi)
+    for rep in range(3):
+        fp = ba.FlatProblem.from_scene(sc)
+        t0 = time.perf_counter()
+        s = ba.solve(fp, ba.default_options(verbose=2 if rep == 2 else 0, max_num_iterations=10))
+        dt = (time.perf_counter() - t0) * 1e3
+        print(f"{name} rep {rep}: call {dt:.2f} ms, solve_ms {s.solve_ms:.2f}, lm_loop_ms {s.lm_loop_ms:.2f}, it {s.num_iterations}, obs {fp.obs_camera.shape[0]}", file=sys.stderr)
