@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Where a bundle adjustment call spends its wall time outside the LM loop (osfm_ba_options.verbose = 2
-prints a lap per stage to stderr): a global-adjustment shape of the 200-view job (200 cameras, 2500
-tracks of 60..100 views) and a local one (3 cameras)."""
+prints a lap per stage to stderr): BASELINE config 4 (200 cameras, 100k tracks of 3..12 views), a
+global-adjustment shape of the 200-view job (200 cameras, 2500 tracks of 60..100 views) and a local one
+(3 cameras)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from orthosfm_amd import ba, synth
-for name, C, M, lo, hi in (("global", 200, 2500, 60, 100), ("local", 3, 2500, 3, 3)):
-    sc = synth.make_ba_scene(synth.MODEL_EULER, C, M, config_id=4, min_len=lo, max_len=hi)
+cases = (("config4", synth.MODEL_QUATERNION, 200, 100000, 3, 12), ("global", synth.MODEL_EULER, 200, 2500, 60, 100),
+         ("local", synth.MODEL_EULER, 3, 2500, 3, 3))
+for name, model, C, M, lo, hi in cases:
+    sc = synth.make_ba_scene(model, C, M, config_id=4, min_len=lo, max_len=hi)
     for rep in range(3):
         fp = ba.FlatProblem.from_scene(sc)
         t0 = time.perf_counter()
