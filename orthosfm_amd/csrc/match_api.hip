@@ -235,7 +235,7 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
     res->plans.assign(num_pairs, PairPlan());
     res->counts.assign(num_pairs, 0);
     std::vector<MatchProblem> probs[2];
-    std::vector<SpecialJob> spjobs;
+    std::vector<SpecialJob> spjobs, spjobs_wide;
     struct SpEntry { int problem, side, view, units, nchunk; };
     std::vector<SpEntry> spentries;
     int64_t sp_recs = 0, sp_cols = 0;
@@ -320,10 +320,14 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
                 for (int side = 0; side < 2; ++side) {
                     const int ns = side == 0 ? pr.nsA : pr.nsB, no = side == 0 ? pr.n2 : pr.n1;
                     if (ns == 0) continue;
-                    const int nchunk = (no + kSpChunk - 1) / kSpChunk;
+                    // more than kSpSlots units: the wide kernel (smaller chunks, shared through LDS)
+                    const int units = (ns + 31) / 32;
+                    pr.sp_wide[side] = units > kSpSlots ? 1 : 0;
+                    const int chunk_cols = pr.sp_wide[side] ? kSpWideChunk : kSpChunk;
+                    const int nchunk = (no + chunk_cols - 1) / chunk_cols;
                     pr.sp_row_off[side] = sp_recs; sp_recs += (int64_t)nchunk * round_up(ns, 32);
                     pr.sp_col_off[side] = sp_cols; sp_cols += round_up(no, 32);
-                    spentries.push_back({(int)probs[type].size(), side, side == 0 ? pl.v2 : pl.v1, (ns + 31) / 32, nchunk});
+                    spentries.push_back({(int)probs[type].size(), side, side == 0 ? pl.v2 : pl.v1, units, nchunk});
                 }
             }
             if (!empty && !limited) (pr.c0 ? any_c0 : any_corrected)[type] = true;
@@ -408,6 +412,13 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
         SpecialJob j;
         memset(&j, 0, sizeof(j));
         const SpEntry &f = spentries[e];
+        if (f.units > kSpSlots) {
+            // the wide kernel: one job per chunk of kSpWideChunk candidates
+            j.problem[0] = f.problem; j.side[0] = f.side; j.count = 0;
+            for (int c = 0; c < f.nchunk; ++c) { j.chunk = c; spjobs_wide.push_back(j); }
+            ++e;
+            continue;
+        }
         if (f.units > 1) {
             j.problem[0] = f.problem; j.side[0] = f.side; j.count = 0;
             ++e;
@@ -421,10 +432,13 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
         for (int c = 0; c < f.nchunk; ++c) { j.chunk = c; spjobs.push_back(j); }
     }
     OSFM_RETURN_IF(m->sp_col.reserve((size_t)std::max<int64_t>(sp_cols, 1) * 4));
-    OSFM_RETURN_IF(m->d_spjobs.reserve(std::max<size_t>(spjobs.size(), 1) * sizeof(SpecialJob)));
+    OSFM_RETURN_IF(m->d_spjobs.reserve(std::max<size_t>(spjobs.size() + spjobs_wide.size(), 1) * sizeof(SpecialJob)));
     if (!spjobs.empty())
         OSFM_HIP_CHECK(hipMemcpyAsync(m->d_spjobs.ptr, spjobs.data(), spjobs.size() * sizeof(SpecialJob),
             hipMemcpyHostToDevice, s));
+    if (!spjobs_wide.empty())
+        OSFM_HIP_CHECK(hipMemcpyAsync(m->d_spjobs.as<SpecialJob>() + spjobs.size(), spjobs_wide.data(),
+            spjobs_wide.size() * sizeof(SpecialJob), hipMemcpyHostToDevice, s));
     int32_t *d_out = m->out.as<int32_t>();
     OSFM_HIP_CHECK(hipMemsetAsync(d_out, 0xff, (size_t)std::max<int64_t>(out_ints, 4) * 4, s));
 
@@ -470,10 +484,12 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
                 any_corrected[type], dp, np, total_blocks[type],
                 m->rowparts.as<RowPart>(), m->colparts.as<ColPart>(), s, probe);
             if (timed[type]) OSFM_HIP_CHECK(hipEventRecord(m->ev[type][1], s));
-            if (type == 0 && !spjobs.empty()) {
+            if (type == 0 && !(spjobs.empty() && spjobs_wide.empty())) {
                 OSFM_HIP_CHECK(hipEventRecord(m->ev_sp[0], s));
                 launch_match_special(dp, m->d_spjobs.as<SpecialJob>(), (int)spjobs.size(), m->sp_parts.as<RowPart>(),
                     m->sp_col.as<int32_t>(), s);
+                launch_match_special_wide(dp, m->d_spjobs.as<SpecialJob>() + spjobs.size(), (int)spjobs_wide.size(),
+                    m->sp_parts.as<RowPart>(), m->sp_col.as<int32_t>(), s);
                 OSFM_HIP_CHECK(hipEventRecord(m->ev_sp[1], s));
             }
             launch_match_finish(dp, np, max_n[type], m->rowparts.as<RowPart>(),
@@ -526,7 +542,7 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
             m->stats.tile_kernel_launches += 1;
         }
     }
-    if (!spjobs.empty()) {
+    if (!(spjobs.empty() && spjobs_wide.empty())) {
         float ms = 0.f;
         OSFM_HIP_CHECK(hipEventElapsedTime(&ms, m->ev_sp[0], m->ev_sp[1]));
         m->stats.special_kernel_ms += ms;

@@ -67,6 +67,9 @@ struct MatchProblem {
     const int32_t *special_slot_B;     // [n2] slot of a column or -1
     int64_t sp_row_off[2];
     int64_t sp_col_off[2];
+    // sp_wide[side] != 0: this side has more than kSpSlots units of special descriptors and went through
+    // match_special_wide_kernel: chunks of kSpWideChunk candidates, streams at a stride of 32 (RowPart.pad = 4)
+    int32_t sp_wide[2];
     // cascade hashing mode (cashash_kernels.h): hash data of set 1 / set 2
     const void *cas_rec[2];          // CasRecord[n]: hash words + packed bucket ids
     const int32_t *cas_start[2];
@@ -106,6 +109,13 @@ constexpr int kSpChunk = 4096;
 constexpr int kSpSlots = 2;             // units of 32 special rows a workgroup carries through one pass over a chunk
 struct SpecialJob { int32_t problem[4], side[4]; int32_t count, chunk, pad0, pad1; };
 void launch_match_special(const MatchProblem *d_problems, const SpecialJob *d_jobs, int num_jobs,
+    RowPart *sp_parts, int32_t *sp_col, hipStream_t s);
+// Entries with more than kSpSlots units (more than 64 special descriptors on a side): one workgroup per
+// (entry, chunk of kSpWideChunk candidates), the chunk staged through LDS once and shared by four waves
+// that carry two units each (jobs: problem[0], side[0], chunk).
+constexpr int kSpWideChunk = 1024;
+constexpr int kSpWideUnits = 8;         // units per pass of a workgroup
+void launch_match_special_wide(const MatchProblem *d_problems, const SpecialJob *d_jobs, int num_jobs,
     RowPart *sp_parts, int32_t *sp_col, hipStream_t s);
 
 // any_special: some problem has row blocks behind nrb_main (gathered special rows);

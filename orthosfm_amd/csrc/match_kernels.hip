@@ -724,9 +724,10 @@ rescan_groups(const MatchProblem &pd, const int (&q)[2], const int (&idx1)[2], c
         for (int j = 0; j < J; ++j) {
             const int n = j * CPL + k;
             int cd;
-            if (kind[u] == 3) {
-                // a special query's winning stream (match_special_kernel): 32 candidates at a stride of 128
-                cd = idx1[u] + 128 * n;
+            if (kind[u] >= 3) {
+                // a special query's winning stream: 32 candidates at a stride of 128 (match_special_kernel,
+                // kind 3) or of 32 (match_special_wide_kernel, kind 4)
+                cd = idx1[u] + (kind[u] == 3 ? 128 : 32) * n;
                 if (cd >= (DIR == 0 ? pd.n2 : pd.n1)) cd = -1;
             } else if (DIR == 0) {
                 cd = base0 + (n >> 1) * kTileCols + (n & 1) * 32 + lr;
@@ -738,7 +739,7 @@ rescan_groups(const MatchProblem &pd, const int (&q)[2], const int (&idx1)[2], c
             }
             cand[u][j] = cd;
         }
-        if (DIR == 1 && kind[u] != 3 && idx1[u] >= pd.nrb_main) {
+        if (DIR == 1 && kind[u] < 3 && idx1[u] >= pd.nrb_main) {
             // a block of gathered special rows (uniform, rare): back to the original rows,
             // all look-ups of the query together and BEFORE any descriptor load -- a
             // look-up between the loads makes the compiler drain the load counter at
@@ -869,14 +870,15 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
         if (ns_mine > 0) sp_slot = (dir == 0 ? pd.special_slot : pd.special_slot_B)[q];
         if (sp_slot >= 0) {
             const int ns_pad = (ns_mine + 31) & ~31;
-            const int nchunk = (nc + kSpChunk - 1) / kSpChunk;
+            const int chunk_cols = pd.sp_wide[dir] ? kSpWideChunk : kSpChunk;
+            const int nchunk = (nc + chunk_cols - 1) / chunk_cols;
             const RowPart *rp0 = sp_parts + pd.sp_row_off[dir] + sp_slot;
             for (int c = 0; c < nchunk; ++c) {
                 const RowPart p = rp0[(int64_t)c * ns_pad];
                 ip2 = max(max(ip2, p.ip_second), min(ip1, p.ip_best));
                 if (p.ip_best >= ip1 && p.ip_best != INT_MIN) { ip1 = p.ip_best; idx1 = p.idx_best; }   // later chunk wins ties
             }
-            kind1 = 3;
+            kind1 = pd.sp_wide[dir] ? 4 : 3;
         }
     }
     // an ordinary query whose best candidate is (or ties with) a special descriptor of the other set:

@@ -90,9 +90,10 @@ def test_product_does_not_touch_the_oracle():
 
 
 def test_m0_is_written_only_by_hand_in_the_pipe_kernels():
-    """The correction-free tile kernels set m0 inside an asm statement (hipcc rejects m0 as a clobber: a reserved
-    register).  That is sound only while nothing else in those kernels uses m0; tools/check_m0.sh disassembles
-    match_kernels.hip for gfx950 and fails when a C0 instantiation holds any other m0 instruction."""
+    """The correction-free tile kernels and match_special_wide_kernel set m0 inside an asm statement (hipcc rejects
+    m0 as a clobber: a reserved register).  That is sound only while nothing else in those kernels uses m0;
+    tools/check_m0.sh disassembles match_kernels.hip and match_special.hip for gfx950 and fails when one of them
+    holds any other m0 instruction."""
     import os
     import shutil
     import subprocess
@@ -102,4 +103,5 @@ def test_m0_is_written_only_by_hand_in_the_pipe_kernels():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([os.path.join(root, "tools", "check_m0.sh")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count("[C0]") >= 2 and "0 other than s_mov_b32 m0 [C0]" in out.stdout
+    assert out.stdout.count("[hand-written m0]") >= 3 and "0 other than s_mov_b32 m0 [hand-written m0]" in out.stdout
+    assert "match_special_wide_kernel" in out.stdout
