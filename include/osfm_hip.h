@@ -538,7 +538,8 @@ OSFM_API int osfm_tracks_feature_table(int64_t num_tracks, const int64_t *track_
  * well).  feature_ids (may be NULL) receives the taken feature indices.  *num_observations is always
  * set; OSFM_E_CAPACITY when it exceeds `capacity`. */
 OSFM_API int osfm_tracks_select_observations(int64_t num_features, const int32_t *track_of,
-    const int64_t *track_offsets /* [num_tracks + 1] or NULL: lets the pass jump over unselected tracks */,
+    const int64_t *track_offsets /* NULL, or the first feature of every track, [largest track id + 2] entries (features
+                                    are in track order): the pass then goes track by track and jumps over unselected ones */,
     const int32_t *camera_of_feature, const uint8_t *live, const uint8_t *track_mask,
     const int32_t *track_slot, const double *xy, int64_t capacity, int32_t *feature_ids,
     double *obs_xy, int32_t *obs_camera, int32_t *obs_point, int32_t *tracks_out,

@@ -8,6 +8,7 @@
 // the larger one in O(1) after relabelling its nodes, and nothing is
 // reallocated.  The output order is the reference's, element for element.
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <thread>
@@ -190,13 +191,17 @@ static int builder_finish(const osfm_tracks_builder *b, const uint8_t *colors,
         }
         R.feats.resize((size_t)2 * nf);
     };
-    if (workers == 1) walk(ranges[0]);
+    // (an allocation failure inside a thread must come back as a status, not end the process)
+    std::atomic<bool> failed{false};
+    auto guarded = [&](auto &&fn) { try { fn(); } catch (...) { failed = true; } };
+    if (workers == 1) guarded([&] { walk(ranges[0]); });
     else {
         std::vector<std::thread> th;
-        for (int w = 1; w < workers; ++w) th.emplace_back([&, w] { walk(ranges[w]); });
-        walk(ranges[0]);
+        for (int w = 1; w < workers; ++w) th.emplace_back([&, w] { guarded([&] { walk(ranges[w]); }); });
+        guarded([&] { walk(ranges[0]); });
         for (auto &x : th) x.join();
     }
+    if (failed) { set_error("tracks_compute: out of host memory while writing the tracks"); return OSFM_E_STATE; }
     int32_t invalid = 0, valid = 0;
     int64_t nf = 0;
     std::vector<int64_t> base_f((size_t)workers), base_t((size_t)workers);
@@ -392,6 +397,12 @@ int osfm_tracks_feature_table(int64_t num_tracks, const int64_t *track_offsets, 
         set_error("tracks_feature_table: null array");
         return OSFM_E_ARG;
     }
+    if (track_offsets[0] != 0) { set_error("tracks_feature_table: track_offsets[0] must be 0"); return OSFM_E_ARG; }
+    for (int64_t t = 0; t < num_tracks; ++t)
+        if (track_offsets[t + 1] < track_offsets[t]) {
+            set_error("tracks_feature_table: track_offsets decrease at track %lld", (long long)t);
+            return OSFM_E_ARG;
+        }
     if ((by_view_out && !view_start_out) || (view_start_out && !by_view_out && nf > 0)) {
         set_error("tracks_feature_table: by_view and view_start go together");
         return OSFM_E_ARG;

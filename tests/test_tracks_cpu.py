@@ -240,6 +240,10 @@ def test_feature_table_equals_numpy(threads, monkeypatch):
     tf[7, 1] = sizes[tf[7, 0]]
     with pytest.raises(capi.OsfmError):
         T.feature_table(offs, tf.reshape(-1), pos, 2048)
+    tf[7, 1] = 0
+    bad = offs.copy(); bad[3] = bad[5] + 1                     # offsets that go down again
+    with pytest.raises(capi.OsfmError):
+        T.feature_table(bad, tf.reshape(-1), pos, 2048)
     # no tracks at all
     view, feat, xy, track_of, by_view, view_start = T.feature_table(np.zeros(1, np.int64), np.zeros(0, np.int32), pos, 2048)
     assert view.size == 0 and np.array_equal(view_start, np.zeros(V + 1, np.int64))
