@@ -291,7 +291,7 @@ def test_special_rows_large_values(hm):
         m.close()
 
 
-@pytest.mark.parametrize("k", [1, 20, 200, 600])
+@pytest.mark.parametrize("k", [1, 20, 65, 200, 300, 500, 600])
 def test_special_descriptors_few_per_view(hm, k):
     """The case real SIFT data produces (sift.cc:830-839 renormalises after the clamp): k
     descriptors per view with bytes > 127, built like MVE builds them.  Up to
@@ -299,7 +299,10 @@ def test_special_descriptors_few_per_view(hm, k):
     descriptor stays on the correction-free tile kernel; more (600), or a negative option,
     select the per-view operand forms.  Both against the oracle, all three pair
     orientations (special rows only in set 1, only in set 2, in both), 5000 features per
-    view = two candidate chunks of the special kernel, k = 200 / 600 = several units."""
+    view = two candidate chunks of the special kernel.  k <= 64 (two units of 32) runs
+    match_special_kernel, 65 .. 512 match_special_wide_kernel (five chunks of 1024 candidates,
+    the last one ragged; 65 = three units, one wave with a dead unit; 300 = ten units = two
+    passes, the second with idle waves; 500 (+ 2 doubled rows) = sixteen units, two full passes)."""
     from orthosfm_amd import capi
     iset = synth.make_image_set(3, 5000, config_id=31)
     rows = synth.add_peaky_rows(iset, k)
