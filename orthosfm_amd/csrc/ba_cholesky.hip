@@ -238,7 +238,7 @@ chol_small_kernel(const double *A, int ld, int n, double *Ldiag, double *x, int 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // a failed factorisation is noticed by ba_lm_decide (chol_info); the candidates it then
     // ignores are written all the same, like the general path does
-    double *cams_out = d.cams2[d.lm->cur ^ 1];
+    double *cams_out = d.lm->cur ? d.cams2[0] : d.cams2[1];
     for (int c = lane; c < d.C; c += 64) cam_update_one(d, xs, cams_out, partials_cam, c);
 }
 

@@ -63,9 +63,11 @@ __device__ __forceinline__ bool lm_resolve(BaDev &d)
 {
     if (!d.lm) return true;
     if (d.lm->stop) return false;
+    // selects, not d.cams2[cur]: a kernel argument indexed with a run-time value is copied to scratch
+    // memory as a whole (184 bytes per lane), and every field read after that comes from there
     const int cur = d.lm->cur;
-    d.cams = d.cams2[cur];
-    d.points = d.points2[cur];
+    d.cams = cur ? d.cams2[1] : d.cams2[0];
+    d.points = cur ? d.points2[1] : d.points2[0];
     return true;
 }
 

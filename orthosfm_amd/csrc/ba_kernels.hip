@@ -496,7 +496,7 @@ __global__ void
 ba_cam_update_kernel(BaDev d, const double *y_c, double *cams_out, double *partials_cam)
 {
     if (!lm_resolve(d)) return;
-    if (d.lm) { if (d.lm->lin_failed) return; cams_out = d.cams2[d.lm->cur ^ 1]; }
+    if (d.lm) { if (d.lm->lin_failed) return; cams_out = d.lm->cur ? d.cams2[0] : d.cams2[1]; }
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.C) return;
     cam_update_one(d, y_c, cams_out, partials_cam, c);
@@ -516,7 +516,7 @@ ba_back_pass_kernel(BaDev dg, BackPassArgs a, int staged)
     extern __shared__ __attribute__((aligned(16))) char cam_lds[];
     __shared__ double sh[4];
     if (!lm_resolve(dg)) return;
-    if (dg.lm) { if (dg.lm->lin_failed) return; a.points_out = dg.points2[dg.lm->cur ^ 1]; }
+    if (dg.lm) { if (dg.lm->lin_failed) return; a.points_out = dg.lm->cur ? dg.points2[0] : dg.points2[1]; }
     const double *cams = dg.cams;
     const BaDev d = stage_cameras(dg, cam_lds, staged != 0, cams, &a.y_c);
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
@@ -600,7 +600,7 @@ ba_cost_pass_kernel(BaDev dg, const double *cams, const double *points, double *
     if (dg.lm) {
         // LM solve: the cost of the CANDIDATE (the iterate buffer that is not current)
         if (dg.lm->stop || dg.lm->lin_failed) return;
-        cams = dg.cams2[dg.lm->cur ^ 1]; points = dg.points2[dg.lm->cur ^ 1];
+        cams = dg.lm->cur ? dg.cams2[0] : dg.cams2[1]; points = dg.lm->cur ? dg.points2[0] : dg.points2[1];
     }
     const BaDev d = stage_cameras(dg, cam_lds, staged != 0, cams, nullptr);
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
