@@ -424,22 +424,26 @@ cam_update_one(const BaDev &d, const double *y_c, double *cams_out, double *part
     const int n = d.cam_ldim[c], off = d.cam_off[c];
     double dl[6];
     for (int t = 0; t < 6; ++t) dl[t] = t < n ? -y_c[off + t] * d.scale_c[off + t] : 0.0;
-    int t = 0;
-    if (d.model == kModelQuat && n > 0 && d.cam_colmap[6 * c] == 0) { quat_plus(cam, dl, out); t = 3; }
-    for (; t < n; ++t) {
-        const int f = d.cam_colmap[6 * c + t];
-        const int slot = d.model == kModelQuat ? f + 1 : f;
-        out[slot] = cam[slot] + dl[t];
-    }
+    int t0 = 0;
+    if (d.model == kModelQuat && n > 0 && d.cam_colmap[6 * c] == 0) { quat_plus(cam, dl, out); t0 = 3; }
+    // unrolled with selects: out[slot] / act[f] with a run-time index would put the arrays into scratch memory
     // norms over the ambient coordinates of the non-constant blocks
     double sn = 0.0, xn = 0.0;
     bool act[7] = { false, false, false, false, false, false, false };
-    for (int tt = 0; tt < n; ++tt) {
-        const int f = d.cam_colmap[6 * c + tt];
-        if (d.model == kModelQuat) {
-            if (f < 3) { act[0] = act[1] = act[2] = act[3] = true; } else act[f + 1] = true;
-        } else act[f] = true;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const bool live = t < n;
+        const int f = live ? (int)d.cam_colmap[6 * c + t] : 99;
+        const int slot = d.model == kModelQuat ? f + 1 : f;
+        const double moved = dl[t];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            out[i] = (live && t >= t0 && i == slot) ? cam[i] + moved : out[i];
+            const bool on = d.model == kModelQuat ? (f < 3 ? i < 4 : i == f + 1) : i == f;
+            act[i] = act[i] || (live && on);
+        }
     }
+#pragma unroll
     for (int i = 0; i < 7; ++i) {
         cams_out[7 * c + i] = out[i];
         if (act[i]) { sn += (cam[i] - out[i]) * (cam[i] - out[i]); xn += cam[i] * cam[i]; }

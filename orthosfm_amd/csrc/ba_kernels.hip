@@ -492,7 +492,7 @@ void launch_pair_pass(const BaDev &d, const PairPassArgs &a, hipStream_t s)
 // ---------------------------------------------------------------------------
 // candidate cameras: x+ = Plus(x, scale * step), step = -y
 // ---------------------------------------------------------------------------
-__global__ void
+__global__ __launch_bounds__(128) void
 ba_cam_update_kernel(BaDev d, const double *y_c, double *cams_out, double *partials_cam)
 {
     if (!lm_resolve(d)) return;
