@@ -16,6 +16,7 @@ constexpr int kObsRec = 26;
 // the a side of an off-diagonal pair reads (18 of the 26 doubles each)
 constexpr int kRecJp = 0, kRecJc = 6, kRecQ = 18, kRecR = 24;
 
+
 // lanes per track in the per-point kernels (point / back / cost pass): their grids are
 // ceil(M * kPointLanes / 256) workgroups of 256 threads, and so are their partials
 constexpr int kPointLanes = 4;
@@ -38,6 +39,11 @@ constexpr int kPairChunkSmall = 256;       // kPairChunkSmallLimit entries (few 
 constexpr int kPairChunkSmallLimit = 1 << 20;
 constexpr int kPairSums = 54;     // sums a pair-pass wave leaves per chunk: 6x6 block, 6 diagonal, 6 rhs, 6 gradient
 
+// What a wave of the pair pass needs before its first entry: found through chunk_pair -> chunk_start /
+// pair_start / pair_key it was three dependent memory latencies in front of the two the entries and
+// their records cost anyway.  nchunks == 0: no work (the tail of the launch).
+struct PairChunkDesc { int32_t pi, e0, e1, nchunks, c1, c2, pad0, pad1; };
+
 struct PairPassArgs {
     int mode, update_diag, want_gradient;
     double radius, min_diag, max_diag;
@@ -47,6 +53,7 @@ struct PairPassArgs {
     const uint64_t *entries;         // (obs a << 32) | obs b, grouped by pair, track order inside
     const int32_t *chunk_start;      // [num_pairs + 1] first chunk (= wave) of each pair
     const int32_t *chunk_pair;       // [chunk_start[num_pairs]] pair of each chunk
+    const struct PairChunkDesc *chunk_desc;   // [max_chunks] everything a pair-pass wave needs to start, in ONE load
     int max_chunks;                  // waves to launch (upper bound of chunk_start[num_pairs])
     int chunk;                       // entries per chunk
     double *chunk_partials;          // [max_chunks][kPairSums] sums of the chunks of multi-chunk pairs
@@ -113,7 +120,7 @@ void launch_triangulate(const BaDev &d, double *points_out, uint8_t *valid, hipS
 // camera-pair lists built on the device (ba_pairs.hip)
 struct PairListsDev {
     PooledBuffer counts, offsets, keys_in, keys, vals_in, entries, unique, runs, starts, scalars, temp;
-    PooledBuffer chunk_start, chunk_pair, chunk_partials, multi_pairs;
+    PooledBuffer chunk_start, chunk_pair, chunk_partials, multi_pairs, chunk_desc;
     int num_pairs = 0;
     int num_entries = 0;
     int max_chunks = 0;
@@ -122,7 +129,7 @@ struct PairListsDev {
     ~PairListsDev()
     {
         PooledBuffer *b[] = {&counts, &offsets, &keys_in, &keys, &vals_in, &entries, &unique, &runs, &starts, &scalars, &temp,
-                             &chunk_start, &chunk_pair, &chunk_partials, &multi_pairs};
+                             &chunk_start, &chunk_pair, &chunk_partials, &multi_pairs, &chunk_desc};
         for (auto *x : b) x->release();
     }
 };

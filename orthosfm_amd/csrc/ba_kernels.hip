@@ -33,6 +33,52 @@ __device__ __forceinline__ double wave_max(double v)
     return v;
 }
 
+// ---- the 54 sums of a pair-pass wave ---------------------------------------------
+// Every lane holds a partial of each of the 54 quantities; lane v ends up with the wave's total of
+// quantity v.  Recursive halving: at the level with lane mask m a lane keeps the half of its live
+// quantities whose index has bit m like its own lane number, hands the other half to lane ^ m and adds
+// what it receives -- 32 + 16 + 8 + 4 + 2 + 1 exchanges in all, where folding every quantity over the
+// whole wave on its own (six xor-shuffles each) was 324 additions and 648 ds_bpermute instructions per
+// wave: the LDS crossbar, not the gathers, set the pace of the pair pass.  The two upper levels are
+// v_permlane32_swap / v_permlane16_swap (register halves / odd and even rows trade places: no select, no
+// LDS); the order of the additions is fixed, so repeats stay bit-identical.
+__device__ __forceinline__ double swap_add(double a, double b, bool level32)
+{
+    const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    double x0, x1;
+    if (level32) {
+        // a' = { a[0..31], b[0..31] }, b' = { a[32..63], b[32..63] }
+        const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        x0 = __hiloint2double((int)hi[0], (int)lo[0]); x1 = __hiloint2double((int)hi[1], (int)lo[1]);
+    } else {
+        // rows of 16 lanes: a' = { a.r0, b.r0, a.r2, b.r2 }, b' = { a.r1, b.r1, a.r3, b.r3 }
+        const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        x0 = __hiloint2double((int)hi[0], (int)lo[0]); x1 = __hiloint2double((int)hi[1], (int)lo[1]);
+    }
+    return x0 + x1;
+}
+
+// s[0..53] -> the total of quantity `lane` (0 for lanes 54..63)
+__device__ __forceinline__ double wave_reduce_54(const double (&s)[54], int lane)
+{
+    double w[32], x[16], y[8], z[4], q[2];
+#pragma unroll
+    for (int v = 0; v < 32; ++v) w[v] = swap_add(s[v], v + 32 < 54 ? s[v + 32] : 0.0, true);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) x[v] = swap_add(w[v], w[v + 16], false);
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) y[v] = (b3 ? x[v + 8] : x[v]) + __shfl_xor(b3 ? x[v] : x[v + 8], 8);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) z[v] = (b2 ? y[v + 4] : y[v]) + __shfl_xor(b2 ? y[v] : y[v + 4], 4);
+#pragma unroll
+    for (int v = 0; v < 2; ++v) q[v] = (b1 ? z[v + 2] : z[v]) + __shfl_xor(b1 ? z[v] : z[v + 2], 2);
+    return (b0 ? q[1] : q[0]) + __shfl_xor(b0 ? q[0] : q[1], 1);
+}
+
 // The per-point kernels give every track kPointLanes neighbouring lanes (observation
 // k0 + lane, k0 + lane + 4, ...): one thread per track left 1.5 waves per SIMD to
 // hide a chain of dependent loads per observation.  Sums over a track are folded
@@ -274,11 +320,10 @@ __device__ __forceinline__ double lane_value(double v, int src)
 // The sums of a camera pair, complete: block of S, LM diagonal, reduced rhs, and for a
 // diagonal pair the camera's gradient norm.  One lane.
 __device__ __forceinline__ void
-pair_finish(const BaDev &d, const PairPassArgs &a, int c1, int c2, double (&acc)[6][6], const double (&U)[6],
-    const double (&rhs)[6], const double (&g)[6])
+pair_finish(const BaDev &d, const PairPassArgs &a, int c1, int c2, int n1, int n2, int o1, int o2,
+    double (&acc)[6][6], const double (&U)[6], const double (&rhs)[6], const double (&g)[6])
 {
-    const int n1 = d.cam_ldim[c1], n2 = d.cam_ldim[c2];
-    const int o1 = d.cam_off[c1], o2 = d.cam_off[c2];
+    // n1, n2, o1, o2: cam_ldim / cam_off of the two cameras, loaded by the caller in front of its sums
     const bool diag_pair = c1 == c2;
     // fully unrolled with predicates: a loop bounded by n1 / n2 would index the
     // accumulators dynamically and push all 36 of them into scratch memory
@@ -327,7 +372,7 @@ pair_finish(const BaDev &d, const PairPassArgs &a, int c1, int c2, double (&acc)
     }
 }
 
-__global__ __launch_bounds__(256) void
+__global__ __launch_bounds__(256, 2) void
 ba_pair_pass_kernel(BaDev d, PairPassArgs a)
 {
     if (!lm_resolve(d)) return;
@@ -339,13 +384,19 @@ ba_pair_pass_kernel(BaDev d, PairPassArgs a)
     // camera c1 serve ~200 pairs in a row and stay in that XCD's L2 (round robin over the XCDs
     // put 15 cameras' worth of them in front of every L2: 25 % hits)
     const int wave = xcd_remap_blocks((int)blockIdx.x, (int)gridDim.x) * 4 + (int)(threadIdx.x >> 6);
+    if (wave >= a.max_chunks) return;
+    // A wave's life is a chain of memory latencies -- descriptor, entries, records, camera layout -- a few
+    // times over; everything that can be asked for early is: the descriptor is one load, the camera layout
+    // is requested right behind it, the entries of the next round while the records of this one are awaited.
+    const PairChunkDesc dsc = a.chunk_desc[wave];
+    if (dsc.nchunks == 0) return;
     PairChunk w;
-    if (!locate_pair_chunk(a, wave, w)) return;
-    const int pi = w.pi;
-    const int c1 = (int)(a.pair_key[pi] / (uint32_t)d.C), c2 = (int)(a.pair_key[pi] % (uint32_t)d.C);
+    w.pi = dsc.pi; w.e0 = dsc.e0; w.e1 = dsc.e1; w.nchunks = dsc.nchunks; w.chunk = 0;
+    const int c1 = dsc.c1, c2 = dsc.c2;
     const int e0 = w.e0, e1 = w.e1;
     const bool diag_pair = c1 == c2;
     if (a.mode == kPassScaleInit && !diag_pair) return;
+    const int n1 = d.cam_ldim[c1], n2 = d.cam_ldim[c2], o1 = d.cam_off[c1], o2 = d.cam_off[c2];
 
     double acc[6][6];      // - sum Z_a W_b^T  (+ sum Jc^T Jc on the diagonal pair)
     double U[6];           // diagonal of sum Jc^T Jc (for the LM diagonal)
@@ -357,17 +408,53 @@ ba_pair_pass_kernel(BaDev d, PairPassArgs a)
 #pragma unroll
         for (int y = 0; y < 6; ++y) acc[x][y] = 0.0;
     }
-    for (int e = e0 + lane; e < e1; e += 64) {
-        const uint64_t ent = a.entries[e];
+    // The records of a round of 64 entries come through LDS: a lane loading its own record with nine 16-byte
+    // loads makes every load instruction touch 64 different cache lines, and the pass ran at the rate the
+    // vector cache looks up tags (36 such instructions per round), not at any bandwidth.  Here the 64 records
+    // of a side are 576 pieces of 16 bytes that the lanes fetch in piece order -- seven records, about
+    // fourteen lines per instruction -- by DMA (global_load_lds: no registers in between) into a block of
+    // the wave's own, record after record (144 B apart: the lanes' 16-byte reads of their own records then
+    // fall on different banks).  No barrier: one wave's LDS operations execute in order.
+    __shared__ int2 ent_lds[4][64];
+    __shared__ __attribute__((aligned(16))) double rec_lds[4][2][64 * 18];
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    const int wv = (int)(threadIdx.x >> 6);
+    const int wv_s = __builtin_amdgcn_readfirstlane(wv);
+    uint64_t ent_next = a.entries[min(e0 + lane, e1 - 1)];
+    for (int eb = e0; eb < e1; eb += 64) {
+        const int e = eb + lane;
+        const bool valid = e < e1;                    // lanes past the end repeat the last entry and add nothing
+        const uint64_t ent = ent_next;
+        if (eb + 64 < e1) ent_next = a.entries[min(e + 64, e1 - 1)];
         const int ka = (int)(ent >> 32), kb = (int)(ent & 0xffffffffu);
-        // 16-byte loads; of record a only Jc and Q (18 doubles at [kRecJc, kRecR)) -- the residual
-        // is read by the diagonal entries alone, Jp comes with record b
-        double ra[kObsRec];
-        {
-            const double2 *src = reinterpret_cast<const double2 *>(a.obsrec + (size_t)ka * kObsRec);
+        const bool with_b = d.pdim && a.mode != kPassScaleInit;
+        ent_lds[wv][lane] = make_int2(ka, kb);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // of record a only Jc and Q (18 doubles at [kRecJc, kRecR)) -- the residual is read by the diagonal
+        // entries alone; of record b only Jp and Jc (18 doubles at [0, kRecQ)).  Piece p = i * 64 + lane is
+        // chunk p % 9 of the record of lane p / 9.
 #pragma unroll
-            for (int i = kRecJc / 2; i < kRecR / 2; ++i) { const double2 v = src[i]; ra[2 * i] = v.x; ra[2 * i + 1] = v.y; }
+        for (int i = 0; i < 9; ++i) {
+            const int pz = i * 64 + lane, rec = (pz * 7282) >> 16, ch = pz - 9 * rec;      // pz / 9 for pz < 576
+            const int2 kk = ent_lds[wv][rec];
+            __builtin_amdgcn_global_load_lds((glb_void *)(a.obsrec + (size_t)kk.x * kObsRec + kRecJc + 2 * ch),
+                (lds_void *)(uintptr_t)(&rec_lds[wv_s][0][i * 128]), 16, 0, 0);
+            if (with_b)
+                __builtin_amdgcn_global_load_lds((glb_void *)(a.obsrec + (size_t)kk.y * kObsRec + 2 * ch),
+                    (lds_void *)(uintptr_t)(&rec_lds[wv_s][1][i * 128]), 16, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        double ra[kObsRec];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const double2 v = *reinterpret_cast<const double2 *>(&rec_lds[wv][0][lane * 18 + 2 * i]);
+            ra[kRecJc + 2 * i] = v.x; ra[kRecJc + 2 * i + 1] = v.y;
+        }
+        // record b stays where it is and is read as it is used (36 registers less across the products below);
+        // the next round's DMA cannot overtake these reads: they are consumed in this round
+        const double *rb = &rec_lds[wv][1][lane * 18];
+        if (!valid) continue;
         double Ja[2][6];
 #pragma unroll
         for (int x = 0; x < 6; ++x) { Ja[0][x] = ra[kRecJc + x]; Ja[1][x] = ra[kRecJc + 6 + x]; }
@@ -392,12 +479,6 @@ ba_pair_pass_kernel(BaDev d, PairPassArgs a)
         }
         if (d.pdim && a.mode != kPassScaleInit) {
             // Z_a W_b^T = Jc_a^T (Q_a Jp_b^T) Jc_b; of record b only Jc and Jp (18 doubles)
-            double rb[kRecQ];
-            {
-                const double2 *src = reinterpret_cast<const double2 *>(a.obsrec + (size_t)kb * kObsRec);
-#pragma unroll
-                for (int i = 0; i < kRecQ / 2; ++i) { const double2 v = src[i]; rb[2 * i] = v.x; rb[2 * i + 1] = v.y; }
-            }
             double M[2][2];
 #pragma unroll
             for (int r1 = 0; r1 < 2; ++r1)
@@ -415,30 +496,31 @@ ba_pair_pass_kernel(BaDev d, PairPassArgs a)
             }
         }
     }
-    // fixed-order wave reduction
-#pragma unroll
-    for (int x = 0; x < 6; ++x) {
-        U[x] = wave_sum(U[x]);
-        rhs[x] = wave_sum(rhs[x]);
-        if (diag_pair) g[x] = wave_sum(g[x]);
-#pragma unroll
-        for (int y = 0; y < 6; ++y) acc[x][y] = wave_sum(acc[x][y]);
-    }
-    if (w.nchunks > 1) {
-        // lane v takes sum v (36 block entries, 6 diagonal sums, 6 rhs entries, 6 gradient entries)
-        double mine = 0.0;
+    // fixed-order wave reduction: lane v ends up with sum v (36 block entries, 6 diagonal sums, 6 rhs entries,
+    // 6 gradient entries)
+    double mine;
+    {
+        double s[kPairSums];
 #pragma unroll
         for (int x = 0; x < 6; ++x) {
 #pragma unroll
-            for (int y = 0; y < 6; ++y) mine = lane == x * 6 + y ? acc[x][y] : mine;
-            mine = lane == 36 + x ? U[x] : mine;
-            mine = lane == 42 + x ? rhs[x] : mine;
-            mine = lane == 48 + x ? g[x] : mine;
+            for (int y = 0; y < 6; ++y) s[x * 6 + y] = acc[x][y];
+            s[36 + x] = U[x]; s[42 + x] = rhs[x]; s[48 + x] = g[x];
         }
+        mine = wave_reduce_54(s, lane);
+    }
+    if (w.nchunks > 1) {
         if (lane < kPairSums) a.chunk_partials[(size_t)wave * kPairSums + lane] = mine;
         return;
     }
-    if (lane == 0) pair_finish(d, a, c1, c2, acc, U, rhs, g);
+    // a pair with one chunk is finished here: the sums back into every lane (v_readlane: scalar registers)
+#pragma unroll
+    for (int x = 0; x < 6; ++x) {
+#pragma unroll
+        for (int y = 0; y < 6; ++y) acc[x][y] = lane_value(mine, x * 6 + y);
+        U[x] = lane_value(mine, 36 + x); rhs[x] = lane_value(mine, 42 + x); g[x] = lane_value(mine, 48 + x);
+    }
+    if (lane == 0) pair_finish(d, a, c1, c2, n1, n2, o1, o2, acc, U, rhs, g);
 }
 
 // second launch of the pair pass: the pairs with more than one chunk
@@ -477,7 +559,7 @@ ba_pair_join_kernel(BaDev d, PairPassArgs a)
         rhs[x] = lane_value(total, 42 + x);
         g[x] = lane_value(total, 48 + x);
     }
-    if (lane == 0) pair_finish(d, a, c1, c2, acc, U, rhs, g);
+    if (lane == 0) pair_finish(d, a, c1, c2, d.cam_ldim[c1], d.cam_ldim[c2], d.cam_off[c1], d.cam_off[c2], acc, U, rhs, g);
 }
 
 void launch_pair_pass(const BaDev &d, const PairPassArgs &a, hipStream_t s)

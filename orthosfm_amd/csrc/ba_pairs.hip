@@ -72,11 +72,22 @@ pair_chunk_count_kernel(const int32_t *runs, int num_pairs, int chunk, int32_t *
 
 // chunk (= wave) -> pair, so that a pair-pass wave finds its work with one load
 __global__ void
-pair_chunk_fill_kernel(const int32_t *chunk_start, int num_pairs, int32_t *chunk_pair)
+pair_chunk_fill_kernel(const int32_t *chunk_start, int num_pairs, int32_t *chunk_pair, const int32_t *pair_start,
+    const uint32_t *pair_key, int num_cameras, int chunk, PairChunkDesc *desc)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= num_pairs) return;
-    for (int c = chunk_start[i]; c < chunk_start[i + 1]; ++c) chunk_pair[c] = i;
+    const int c0 = chunk_start[i], c1 = chunk_start[i + 1];
+    const int p0 = pair_start[i], p1 = pair_start[i + 1];
+    const uint32_t key = pair_key[i];
+    for (int c = c0; c < c1; ++c) {
+        chunk_pair[c] = i;
+        PairChunkDesc dsc;
+        dsc.pi = i; dsc.e0 = p0 + (c - c0) * chunk; dsc.e1 = min(p1, dsc.e0 + chunk); dsc.nchunks = c1 - c0;
+        dsc.c1 = (int)(key / (uint32_t)num_cameras); dsc.c2 = (int)(key % (uint32_t)num_cameras);
+        dsc.pad0 = dsc.pad1 = 0;
+        desc[c] = dsc;
+    }
 }
 
 // the pairs with more than one chunk, in any order (each is finished on its own)
@@ -171,8 +182,13 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
     int32_t *multi_count = out->scalars.as<int32_t>() + 4;
     OSFM_HIP_CHECK(hipMemsetAsync(multi_count, 0, 4, s));
     OSFM_RETURN_IF(out->chunk_pair.reserve((size_t)(out->max_chunks + 1) * 4));
+    // the launch has max_chunks waves (an upper bound known without a read-back): descriptors past the real
+    // chunks stay zero, nchunks == 0 = nothing to do
+    OSFM_RETURN_IF(out->chunk_desc.reserve((size_t)(out->max_chunks + 4) * sizeof(PairChunkDesc)));
+    OSFM_HIP_CHECK(hipMemsetAsync(out->chunk_desc.ptr, 0, (size_t)(out->max_chunks + 4) * sizeof(PairChunkDesc), s));
     hipLaunchKernelGGL(pair_chunk_fill_kernel, dim3((h_runs + 255) / 256), dim3(256), 0, s,
-        out->chunk_start.as<int32_t>(), h_runs, out->chunk_pair.as<int32_t>());
+        out->chunk_start.as<int32_t>(), h_runs, out->chunk_pair.as<int32_t>(), out->starts.as<int32_t>(),
+        out->unique.as<uint32_t>(), d.C, out->chunk, out->chunk_desc.as<PairChunkDesc>());
     hipLaunchKernelGGL(pair_multi_list_kernel, dim3((h_runs + 255) / 256), dim3(256), 0, s,
         out->chunk_start.as<int32_t>(), h_runs, out->multi_pairs.as<int32_t>(), multi_count);
     int32_t h_multi = 0;
