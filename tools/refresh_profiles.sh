@@ -11,7 +11,8 @@ python $R/bench.py > $R/gpurun_out/bench_$tag.log 2>&1
 grep "^{" $R/gpurun_out/bench_$tag.log | tail -1 > $R/gpurun_out/${round}_bench_$tag.json
 rm -rf $R/gpurun_out/prof_$tag
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -- python $R/bench.py --steps 5 --warmup 2 --no-e2e --no-cpu-baseline > $R/gpurun_out/prof_$tag.log 2>&1
-db=$(find $R/gpurun_out/prof_$tag -name "*.db" | head -1)
+# (one database per traced process: bench.py's drop-in leg runs a host program of its own -- all of them are summed)
+db=$(find $R/gpurun_out/prof_$tag -name "*.db" | tr '\n' ' ')
 if [ -n "$db" ]; then
   python $R/tools/rocpd_stats.py $db > $R/gpurun_out/${round}_bench_kernel_stats_$tag.csv
 else
@@ -24,7 +25,7 @@ rm -rf $R/gpurun_out/prof_$tag        # the trace itself is large; the summary i
 # IS roofline.avg_launch_ms of the line printed by the same command.
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_h_$tag -- python $R/bench.py --steps 10 --warmup 2 --no-ba --no-verify --no-e2e --no-cpu-baseline --no-realistic > $R/gpurun_out/prof_h_$tag.log 2>&1
 grep "^{" $R/gpurun_out/prof_h_$tag.log | tail -1 > $R/gpurun_out/${round}_bench_headline_only_$tag.json
-db=$(find $R/gpurun_out/prof_h_$tag -name "*.db" | head -1)
+db=$(find $R/gpurun_out/prof_h_$tag -name "*.db" | tr '\n' ' ')
 if [ -n "$db" ]; then
   python $R/tools/rocpd_stats.py $db > $R/gpurun_out/${round}_bench_headline_only_kernel_stats_$tag.csv
 else
