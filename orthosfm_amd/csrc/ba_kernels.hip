@@ -295,20 +295,6 @@ __device__ __forceinline__ int xcd_remap_blocks(int bid, int total)
     return base + slot;
 }
 
-// wave -> (pair, chunk); false when the wave has no work
-__device__ __forceinline__ bool locate_pair_chunk(const PairPassArgs &a, int wave, PairChunk &w)
-{
-    if (wave >= a.max_chunks || wave >= a.chunk_start[a.num_pairs]) return false;
-    const int pi = a.chunk_pair[wave];
-    w.pi = pi;
-    w.chunk = wave - a.chunk_start[pi];
-    w.nchunks = a.chunk_start[pi + 1] - a.chunk_start[pi];
-    const int p0 = a.pair_start[pi], p1 = a.pair_start[pi + 1];
-    w.e0 = p0 + w.chunk * a.chunk;
-    w.e1 = min(p1, w.e0 + a.chunk);
-    return true;
-}
-
 __device__ __forceinline__ double lane_value(double v, int src)
 {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
