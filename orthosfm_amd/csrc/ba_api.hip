@@ -302,6 +302,7 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     qa.chunk_start = PL.chunk_start.as<int32_t>(); qa.max_chunks = PL.max_chunks; qa.chunk = PL.chunk;
     qa.chunk_pair = PL.chunk_pair.as<int32_t>();
     qa.chunk_desc = PL.chunk_desc.as<PairChunkDesc>();
+    qa.pair_ticket = PL.pair_ticket.as<int32_t>();
     qa.chunk_partials = PL.chunk_partials.as<double>();
     qa.multi_pairs = PL.multi_pairs.as<int32_t>(); qa.num_multi = PL.num_multi;
     qa.gmax_out = gmax_cam.as<double>();

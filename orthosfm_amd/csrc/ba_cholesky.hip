@@ -84,17 +84,7 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// store that another workgroup of the SAME launch may read (global_store ... sc1: write-through)
-__device__ __forceinline__ void store_sc1(double *p, double v)
-{
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
-        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double load_sc1(const double *p)
-{
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
-        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
+// (store_sc1 / load_sc1: ba_device.h)
 
 template <bool SC1 = false>
 __device__ __forceinline__ void

@@ -57,6 +57,18 @@ struct BaDev {
     double huber;
 };
 
+// store that another workgroup of the SAME launch may read (global_store ... sc1: write-through)
+__device__ __forceinline__ void store_sc1(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_sc1(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
 // The iterate the LM state points at (kernels of the solve call this first; a stopped solve
 // makes them return at once: the host enqueues one iteration ahead of what it knows).
 __device__ __forceinline__ bool lm_resolve(BaDev &d)

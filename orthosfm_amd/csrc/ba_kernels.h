@@ -42,7 +42,7 @@ constexpr int kPairSums = 54;     // sums a pair-pass wave leaves per chunk: 6x6
 // What a wave of the pair pass needs before its first entry: found through chunk_pair -> chunk_start /
 // pair_start / pair_key it was three dependent memory latencies in front of the two the entries and
 // their records cost anyway.  nchunks == 0: no work (the tail of the launch).
-struct PairChunkDesc { int32_t pi, e0, e1, nchunks, c1, c2, pad0, pad1; };
+struct PairChunkDesc { int32_t pi, e0, e1, nchunks, c1, c2, first, pad1; };     // first: the pair's first chunk (= wave)
 
 struct PairPassArgs {
     int mode, update_diag, want_gradient;
@@ -57,7 +57,8 @@ struct PairPassArgs {
     int max_chunks;                  // waves to launch (upper bound of chunk_start[num_pairs])
     int chunk;                       // entries per chunk
     double *chunk_partials;          // [max_chunks][kPairSums] sums of the chunks of multi-chunk pairs
-    const int32_t *multi_pairs;      // [num_multi] pairs with more than one chunk (finished by the join launch)
+    const int32_t *multi_pairs;      // [num_multi] pairs with more than one chunk
+    int32_t *pair_ticket;            // [num_pairs] zero between launches: chunks of a multi-chunk pair that have left their sums
     int num_multi;
     double *gmax_out;                // [C] camera gradient norms (diagonal pairs; may be null)
     const double *vinv, *ge;
@@ -120,7 +121,7 @@ void launch_triangulate(const BaDev &d, double *points_out, uint8_t *valid, hipS
 // camera-pair lists built on the device (ba_pairs.hip)
 struct PairListsDev {
     PooledBuffer counts, offsets, keys_in, keys, vals_in, entries, unique, runs, starts, scalars, temp;
-    PooledBuffer chunk_start, chunk_pair, chunk_partials, multi_pairs, chunk_desc;
+    PooledBuffer chunk_start, chunk_pair, chunk_partials, multi_pairs, chunk_desc, pair_ticket;
     int num_pairs = 0;
     int num_entries = 0;
     int max_chunks = 0;
@@ -129,7 +130,7 @@ struct PairListsDev {
     ~PairListsDev()
     {
         PooledBuffer *b[] = {&counts, &offsets, &keys_in, &keys, &vals_in, &entries, &unique, &runs, &starts, &scalars, &temp,
-                             &chunk_start, &chunk_pair, &chunk_partials, &multi_pairs, &chunk_desc};
+                             &chunk_start, &chunk_pair, &chunk_partials, &multi_pairs, &chunk_desc, &pair_ticket};
         for (auto *x : b) x->release();
     }
 };

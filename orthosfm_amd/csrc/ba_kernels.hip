@@ -278,8 +278,7 @@ void launch_point_pass(const BaDev &d, const PointPassArgs &a, int blocks, hipSt
 // A pair with one chunk is finished by its wave.  The chunks of a longer list -- the
 // diagonal pair of a camera holds all its observations, and a 3-camera local problem
 // has six pairs with every track in each -- leave their sums in a scratch row each, and
-// a second launch (ba_pair_join_kernel, one wave per such pair) adds the rows in chunk
-// order.  No fences, no atomics: the launches are ordered by the stream.
+// the chunk that arrives last (a ticket per pair) adds the rows in chunk order.
 // The camera part of the gradient-norm test rides along on the diagonal pairs:
 // g_c = sum_a Jc_a^T r_a (unscaled), |Plus(x, -g) - x|_inf per camera.
 // ---------------------------------------------------------------------------
@@ -496,8 +495,30 @@ ba_pair_pass_kernel(BaDev d, PairPassArgs a)
         mine = wave_reduce_54(s, lane);
     }
     if (w.nchunks > 1) {
-        if (lane < kPairSums) a.chunk_partials[(size_t)wave * kPairSums + lane] = mine;
-        return;
+        // A longer list: every chunk leaves its sums in a row of its own (write-through stores: the reader is
+        // on another CU, maybe another XCD) and takes a ticket; the chunk that takes the last one adds the rows
+        // -- in chunk order, whichever chunk it is -- and finishes the pair.  (This was a second launch, 17-25 us
+        // of a 0.8 ms iteration for two hundred waves of work.)
+        if (lane < kPairSums) store_sc1(a.chunk_partials + (size_t)wave * kPairSums + lane, mine);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(a.pair_ticket + w.pi, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket != w.nchunks - 1) return;
+        if (lane == 0) __hip_atomic_store(a.pair_ticket + w.pi, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+        const double *row = a.chunk_partials + (size_t)dsc.first * kPairSums + lane;
+        double total = 0.0;
+        if (lane < kPairSums) {
+            // four rows per round, loads first (a plain loop is one memory latency per row)
+            int c = 0;
+            for (; c + 4 <= w.nchunks; c += 4) {
+                const double v0 = load_sc1(row + (size_t)c * kPairSums), v1 = load_sc1(row + (size_t)(c + 1) * kPairSums);
+                const double v2 = load_sc1(row + (size_t)(c + 2) * kPairSums), v3 = load_sc1(row + (size_t)(c + 3) * kPairSums);
+                total += v0; total += v1; total += v2; total += v3;
+            }
+            for (; c < w.nchunks; ++c) total += load_sc1(row + (size_t)c * kPairSums);
+        }
+        mine = total;
     }
     // a pair with one chunk is finished here: the sums back into every lane (v_readlane: scalar registers)
 #pragma unroll
@@ -509,52 +530,11 @@ ba_pair_pass_kernel(BaDev d, PairPassArgs a)
     if (lane == 0) pair_finish(d, a, c1, c2, n1, n2, o1, o2, acc, U, rhs, g);
 }
 
-// second launch of the pair pass: the pairs with more than one chunk
-__global__ __launch_bounds__(256) void
-ba_pair_join_kernel(BaDev d, PairPassArgs a)
-{
-    if (!lm_resolve(d)) return;
-    if (d.lm && a.mode == kPassNormal) {
-        a.radius = d.lm->radius; a.update_diag = d.lm->update_diag; a.want_gradient = d.lm->want_gradient;
-    }
-    const int lane = threadIdx.x & 63;
-    const int mi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (mi >= a.num_multi) return;
-    const int pi = a.multi_pairs[mi];
-    const int c1 = (int)(a.pair_key[pi] / (uint32_t)d.C), c2 = (int)(a.pair_key[pi] % (uint32_t)d.C);
-    if (a.mode == kPassScaleInit && c1 != c2) return;
-    const int w0 = a.chunk_start[pi], nch = a.chunk_start[pi + 1] - w0;
-    const double *row = a.chunk_partials + (size_t)w0 * kPairSums + lane;
-    double total = 0.0;
-    if (lane < kPairSums) {
-        // four rows per round, loads first (a plain loop is one memory latency per row)
-        int c = 0;
-        for (; c + 4 <= nch; c += 4) {
-            const double v0 = row[(size_t)c * kPairSums], v1 = row[(size_t)(c + 1) * kPairSums];
-            const double v2 = row[(size_t)(c + 2) * kPairSums], v3 = row[(size_t)(c + 3) * kPairSums];
-            total += v0; total += v1; total += v2; total += v3;
-        }
-        for (; c < nch; ++c) total += row[(size_t)c * kPairSums];
-    }
-    double acc[6][6], U[6], rhs[6], g[6];
-#pragma unroll
-    for (int x = 0; x < 6; ++x) {
-#pragma unroll
-        for (int y = 0; y < 6; ++y) acc[x][y] = lane_value(total, x * 6 + y);
-        U[x] = lane_value(total, 36 + x);
-        rhs[x] = lane_value(total, 42 + x);
-        g[x] = lane_value(total, 48 + x);
-    }
-    if (lane == 0) pair_finish(d, a, c1, c2, d.cam_ldim[c1], d.cam_ldim[c2], d.cam_off[c1], d.cam_off[c2], acc, U, rhs, g);
-}
-
 void launch_pair_pass(const BaDev &d, const PairPassArgs &a, hipStream_t s)
 {
     if (a.num_pairs <= 0) return;
     const int blocks = (a.max_chunks + 3) / 4;
     hipLaunchKernelGGL(ba_pair_pass_kernel, dim3(blocks), dim3(256), 0, s, d, a);
-    if (a.num_multi > 0)
-        hipLaunchKernelGGL(ba_pair_join_kernel, dim3((a.num_multi + 3) / 4), dim3(256), 0, s, d, a);
 }
 
 // ---------------------------------------------------------------------------

@@ -85,7 +85,7 @@ pair_chunk_fill_kernel(const int32_t *chunk_start, int num_pairs, int32_t *chunk
         PairChunkDesc dsc;
         dsc.pi = i; dsc.e0 = p0 + (c - c0) * chunk; dsc.e1 = min(p1, dsc.e0 + chunk); dsc.nchunks = c1 - c0;
         dsc.c1 = (int)(key / (uint32_t)num_cameras); dsc.c2 = (int)(key % (uint32_t)num_cameras);
-        dsc.pad0 = dsc.pad1 = 0;
+        dsc.first = c0; dsc.pad1 = 0;
         desc[c] = dsc;
     }
 }
@@ -184,6 +184,8 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
     OSFM_RETURN_IF(out->chunk_pair.reserve((size_t)(out->max_chunks + 1) * 4));
     // the launch has max_chunks waves (an upper bound known without a read-back): descriptors past the real
     // chunks stay zero, nchunks == 0 = nothing to do
+    OSFM_RETURN_IF(out->pair_ticket.reserve((size_t)(h_runs + 1) * 4));
+    OSFM_HIP_CHECK(hipMemsetAsync(out->pair_ticket.ptr, 0, (size_t)(h_runs + 1) * 4, s));
     OSFM_RETURN_IF(out->chunk_desc.reserve((size_t)(out->max_chunks + 4) * sizeof(PairChunkDesc)));
     OSFM_HIP_CHECK(hipMemsetAsync(out->chunk_desc.ptr, 0, (size_t)(out->max_chunks + 4) * sizeof(PairChunkDesc), s));
     hipLaunchKernelGGL(pair_chunk_fill_kernel, dim3((h_runs + 255) / 256), dim3(256), 0, s,
