@@ -304,7 +304,6 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     qa.chunk_desc = PL.chunk_desc.as<PairChunkDesc>();
     qa.pair_ticket = PL.pair_ticket.as<int32_t>();
     qa.chunk_partials = PL.chunk_partials.as<double>();
-    qa.multi_pairs = PL.multi_pairs.as<int32_t>(); qa.num_multi = PL.num_multi;
     qa.gmax_out = gmax_cam.as<double>();
     qa.vinv = vinv.as<double>(); qa.ge = ge.as<double>(); qa.obsrec = obsrec.as<double>();
     qa.diag_c = diag_c.as<double>(); qa.scale_c_out = D.scale_c.as<double>();

@@ -57,9 +57,7 @@ struct PairPassArgs {
     int max_chunks;                  // waves to launch (upper bound of chunk_start[num_pairs])
     int chunk;                       // entries per chunk
     double *chunk_partials;          // [max_chunks][kPairSums] sums of the chunks of multi-chunk pairs
-    const int32_t *multi_pairs;      // [num_multi] pairs with more than one chunk
     int32_t *pair_ticket;            // [num_pairs] zero between launches: chunks of a multi-chunk pair that have left their sums
-    int num_multi;
     double *gmax_out;                // [C] camera gradient norms (diagonal pairs; may be null)
     const double *vinv, *ge;
     const double *obsrec;     // [O][kObsRec]
@@ -121,16 +119,15 @@ void launch_triangulate(const BaDev &d, double *points_out, uint8_t *valid, hipS
 // camera-pair lists built on the device (ba_pairs.hip)
 struct PairListsDev {
     PooledBuffer counts, offsets, keys_in, keys, vals_in, entries, unique, runs, starts, scalars, temp;
-    PooledBuffer chunk_start, chunk_pair, chunk_partials, multi_pairs, chunk_desc, pair_ticket;
+    PooledBuffer chunk_start, chunk_pair, chunk_partials, chunk_desc, pair_ticket;
     int num_pairs = 0;
     int num_entries = 0;
     int max_chunks = 0;
     int chunk = kPairChunk;
-    int num_multi = 0;
     ~PairListsDev()
     {
         PooledBuffer *b[] = {&counts, &offsets, &keys_in, &keys, &vals_in, &entries, &unique, &runs, &starts, &scalars, &temp,
-                             &chunk_start, &chunk_pair, &chunk_partials, &multi_pairs, &chunk_desc, &pair_ticket};
+                             &chunk_start, &chunk_pair, &chunk_partials, &chunk_desc, &pair_ticket};
         for (auto *x : b) x->release();
     }
 };

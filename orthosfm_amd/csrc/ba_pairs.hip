@@ -90,15 +90,6 @@ pair_chunk_fill_kernel(const int32_t *chunk_start, int num_pairs, int32_t *chunk
     }
 }
 
-// the pairs with more than one chunk, in any order (each is finished on its own)
-__global__ void
-pair_multi_list_kernel(const int32_t *chunk_start, int num_pairs, int32_t *multi, int32_t *count)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= num_pairs) return;
-    if (chunk_start[i + 1] - chunk_start[i] > 1) multi[atomicAdd(count, 1)] = i;
-}
-
 int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, PairListsDev *out, hipStream_t s)
 {
     const int M = d.O;          // the lists are generated per observation
@@ -171,7 +162,6 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
     out->chunk = E < kPairChunkSmallLimit ? kPairChunkSmall : kPairChunk;
     out->max_chunks = h_runs + E / out->chunk;
     OSFM_RETURN_IF(out->chunk_start.reserve((size_t)(h_runs + 1) * 4));
-    OSFM_RETURN_IF(out->multi_pairs.reserve((size_t)(h_runs + 1) * 4));
     OSFM_RETURN_IF(out->chunk_partials.reserve((size_t)out->max_chunks * kPairSums * sizeof(double)));
     // the run lengths are not needed after this: the chunk counts take their place
     hipLaunchKernelGGL(pair_chunk_count_kernel, dim3((h_runs + 256) / 256), dim3(256), 0, s,
@@ -179,8 +169,6 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
     tb = out->temp.bytes;
     OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(out->temp.ptr, tb, out->counts.as<int32_t>(),
         out->chunk_start.as<int32_t>(), h_runs + 1, s));
-    int32_t *multi_count = out->scalars.as<int32_t>() + 4;
-    OSFM_HIP_CHECK(hipMemsetAsync(multi_count, 0, 4, s));
     OSFM_RETURN_IF(out->chunk_pair.reserve((size_t)(out->max_chunks + 1) * 4));
     // the launch has max_chunks waves (an upper bound known without a read-back): descriptors past the real
     // chunks stay zero, nchunks == 0 = nothing to do
@@ -191,12 +179,8 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
     hipLaunchKernelGGL(pair_chunk_fill_kernel, dim3((h_runs + 255) / 256), dim3(256), 0, s,
         out->chunk_start.as<int32_t>(), h_runs, out->chunk_pair.as<int32_t>(), out->starts.as<int32_t>(),
         out->unique.as<uint32_t>(), d.C, out->chunk, out->chunk_desc.as<PairChunkDesc>());
-    hipLaunchKernelGGL(pair_multi_list_kernel, dim3((h_runs + 255) / 256), dim3(256), 0, s,
-        out->chunk_start.as<int32_t>(), h_runs, out->multi_pairs.as<int32_t>(), multi_count);
-    int32_t h_multi = 0;
-    OSFM_HIP_CHECK(hipMemcpyAsync(&h_multi, multi_count, 4, hipMemcpyDeviceToHost, s));
-    OSFM_HIP_CHECK(hipStreamSynchronize(s));
-    out->num_multi = h_multi;
+    // (nothing more to read back: the pairs with several chunks finish themselves, by ticket, inside the pair pass)
+    OSFM_HIP_CHECK(hipGetLastError());
     return OSFM_OK;
 }
 
