@@ -620,7 +620,8 @@ def end_to_end_bench(args, device_index, cpu_pairs_per_s, cpu_ransac_s_per_pair,
     gpu_total = tm.total_s
     calls = r.ba_calls
     job = {"gpu_wall_s": gpu_total,
-           "stages_s": {"descriptor_upload": tm.upload_s, "matching_with_ransac": tm.matching_s, "tracks": tm.tracks_s,
+           "stages_s": {"descriptor_upload": tm.upload_s, "matching_with_ransac": tm.matching_s,
+                        "of_which_matcher_and_page_locked_buffers": tm.setup_s, "tracks": tm.tracks_s,
                         "track_conversion": tm.convert_s, "group_ordering": tm.groups_s,
                         "pose_estimation": tm.pose_s,
                         "pose_parts": {"local_ba": tm.local_ba_s, "reprojection_filter": tm.local_filter_s,

@@ -309,6 +309,7 @@ def align_to_global(model, local, global_):
 @dataclass
 class Timings:
     upload_s: float = 0.0
+    setup_s: float = 0.0          # inside matching_s: creating the matcher, waiting for the page-locked list buffers
     matching_s: float = 0.0
     tracks_s: float = 0.0
     tracks_busy_s: float = 0.0
@@ -360,15 +361,15 @@ def _problem(model, cams, const, width, height, points, xy, obs_cam, obs_pt):
 _LIST_BUFFERS = []
 
 
-def _list_buffers(rows, n):
-    """n page-locked (rows, 2) int32 list buffers, kept for the process (page-locked memory is
-    expensive to allocate and capi.pinned_rows never frees): grown when a job needs more."""
-    while len(_LIST_BUFFERS) < n:
+def _list_buffer(k, rows):
+    """Page-locked (rows, 2) int32 list buffer number k, kept for the process (page-locked memory is
+    expensive to allocate -- 0.1 to 0.5 s for the 200 MB of a 200-view job, depending on the host -- and
+    capi.pinned_rows never frees): grown when a job needs more."""
+    while len(_LIST_BUFFERS) <= k:
         _LIST_BUFFERS.append(None)
-    for k in range(n):
-        if _LIST_BUFFERS[k] is None or _LIST_BUFFERS[k].shape[0] < rows:
-            _LIST_BUFFERS[k] = capi.pinned_rows(rows)
-    return [_LIST_BUFFERS[k][:rows] for k in range(n)]
+    if _LIST_BUFFERS[k] is None or _LIST_BUFFERS[k].shape[0] < rows:
+        _LIST_BUFFERS[k] = capi.pinned_rows(rows)
+    return _LIST_BUFFERS[k][:rows]
 
 
 def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, timings=None, pairs=None):
@@ -382,6 +383,7 @@ def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, ti
     import threading
     t0 = time.perf_counter()
     m = cls(V, device=device, options=o, copy_results=False)
+    tm.setup_s = time.perf_counter() - t0
     norm = [None] * V
     W, H = iset.width, iset.height
     # The views go up on a thread of their own (the library gives uploads their own stream and lock): the
@@ -429,14 +431,22 @@ def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, ti
     # it takes them as they come; both are C calls that release the interpreter lock).  Two list
     # buffers alternate: a batch's lists stay where they are until the merge has read them.
     builder = T.TracksBuilder(sizes)
-    n_batches = max(1, min(16, pf.shape[0] // 512))
+    n_batches = max(1, min(32, pf.shape[0] // 512))
     bounds = np.linspace(0, pf.shape[0], n_batches + 1).astype(np.int64)
     pair_cap = np.minimum(sizes[pf[:, 0]], sizes[pf[:, 1]]).astype(np.int64) if pf.shape[0] else np.zeros(0, np.int64)
     max_cap = max(int(max((pair_cap[bounds[k]:bounds[k + 1]].sum() for k in range(n_batches)), default=1)), 1)
-    bufs = _list_buffers(max_cap, 2 if n_batches > 1 else 1)
+    # The two list buffers are page-locked on a thread of their own: the first is there when the first views
+    # are (the uploads run meanwhile), the second while the first batch is matched.
     free = queue.Queue()
-    for b_ in bufs:
-        free.put(b_)
+
+    def buffer_worker():
+        for k in range(2 if n_batches > 1 else 1):
+            try:
+                free.put(_list_buffer(k, max_cap))
+            except Exception as e:      # raised by the main thread when it takes the item
+                free.put(e)
+
+    threading.Thread(target=buffer_worker, daemon=True).start()
     work = queue.Queue()
     tracks_busy = [0.0]
     err = []
@@ -463,7 +473,12 @@ def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, ti
         t1 = time.perf_counter()
         wait_for_views(int(sub.max()) + 1 if sub.size else 0)
         upload_wait += time.perf_counter() - t1
+        t1 = time.perf_counter()
         buf = free.get()
+        if isinstance(buf, Exception):
+            raise buf
+        if k < 2:
+            tm.setup_s += time.perf_counter() - t1        # waiting for page-locked memory (later waits: for the merge)
         m.use_result_buffer(buf)
         ra, corr_buf = m.compute_arrays(sub, capacity=max_cap)
         status[bounds[k]:bounds[k + 1]] = ra["status"]
