@@ -109,22 +109,31 @@ struct DeviceProblem {
     BaDev dev;
 };
 
-int upload_problem(const osfm_ba_problem *p, const Layout &L, double huber, int pdim, hipStream_t s,
-    DeviceProblem *D)
+// the caller's arrays: queued before the layout is derived on the host, so that the 24 bytes per observation
+// cross PCIe while the host counts them
+int upload_caller_arrays(const osfm_ba_problem *p, hipStream_t s, DeviceProblem *D)
 {
     const int C = p->num_cameras, M = p->num_points, O = p->num_observations;
-    OSFM_RETURN_IF(upload(D->cams[0], p->cam_params, (size_t)7 * C, s));
-    OSFM_RETURN_IF(D->cams[1].alloc((size_t)7 * C * 8));
-    OSFM_RETURN_IF(upload(D->points[0], p->points, (size_t)4 * M, s));
-    OSFM_RETURN_IF(D->points[1].alloc((size_t)4 * M * 8));
     OSFM_RETURN_IF(upload(D->obs_xy, p->obs_xy, (size_t)2 * O, s));
     OSFM_RETURN_IF(upload(D->obs_cam, p->obs_camera, (size_t)O, s));
+    OSFM_RETURN_IF(upload(D->points[0], p->points, (size_t)4 * M, s));
+    OSFM_RETURN_IF(upload(D->cams[0], p->cam_params, (size_t)7 * C, s));
+    OSFM_RETURN_IF(upload(D->img_w, p->img_width, (size_t)C, s));
+    OSFM_RETURN_IF(upload(D->img_h, p->img_height, (size_t)C, s));
+    return OSFM_OK;
+}
+
+int upload_problem(const osfm_ba_problem *p, const Layout &L, double huber, int pdim, hipStream_t s,
+    DeviceProblem *D, bool caller_arrays_queued = false)
+{
+    const int C = p->num_cameras, M = p->num_points, O = p->num_observations;
+    if (!caller_arrays_queued) OSFM_RETURN_IF(upload_caller_arrays(p, s, D));
+    OSFM_RETURN_IF(D->cams[1].alloc((size_t)7 * C * 8));
+    OSFM_RETURN_IF(D->points[1].alloc((size_t)4 * M * 8));
     OSFM_RETURN_IF(upload(D->pt_start, L.pt_start.data(), (size_t)M + 1, s));
     // obs_point is validated non-decreasing, i.e. it is the expansion of pt_start
     OSFM_RETURN_IF(D->obs_pt.alloc((size_t)O * sizeof(int32_t)));
     launch_expand_points(D->pt_start.as<int32_t>(), M, D->obs_pt.as<int32_t>(), s);
-    OSFM_RETURN_IF(upload(D->img_w, p->img_width, (size_t)C, s));
-    OSFM_RETURN_IF(upload(D->img_h, p->img_height, (size_t)C, s));
     OSFM_RETURN_IF(upload(D->cam_ldim, L.cam_ldim.data(), (size_t)C, s));
     OSFM_RETURN_IF(upload(D->cam_off, L.cam_off.data(), (size_t)C, s));
     OSFM_RETURN_IF(upload(D->colmap, L.colmap.data(), (size_t)6 * C, s));
@@ -212,23 +221,25 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     const auto t_begin = std::chrono::steady_clock::now();
 
     const int C = p->num_cameras, M = p->num_points;
-    Layout L;
-    build_layout(p, &L);
-    const int pdim = o.optimize_points ? 3 : 0;
-    const int nc = L.nc;
     auto lap = [&](const char *what) {
         if (o.verbose >= 2)
             fprintf(stderr, "[osfm ba] %-18s %8.3f ms\n", what,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     };
-    lap("layout");
-
     StreamGuard sg;
     OSFM_RETURN_IF(sg.acquire());
     hipStream_t s = sg.s;
 
+    // (D is declared before L: the transfers queued from L's vectors are waited for before either goes)
     DeviceProblem D;
-    OSFM_RETURN_IF(upload_problem(p, L, o.huber_delta, pdim, s, &D));
+    OSFM_RETURN_IF(upload_caller_arrays(p, s, &D));
+    lap("caller arrays queued");
+    Layout L;
+    build_layout(p, &L);
+    const int pdim = o.optimize_points ? 3 : 0;
+    const int nc = L.nc;
+    lap("layout");
+    OSFM_RETURN_IF(upload_problem(p, L, o.huber_delta, pdim, s, &D, true));
     BaDev &d = D.dev;
     // the points the optimisation starts from (tracksBackup, bundle_adjustment.cpp:99)
     std::vector<double> pts0((size_t)4 * M);
