@@ -38,11 +38,15 @@ __device__ __forceinline__ double readlane_d(double x, int l)
 // instructions (a sqrt and a divide are ~70) is what the panel kernel waits for.
 __device__ __forceinline__ double rsqrt_newton(double d)
 {
-    const double h = 0.5 * d;
-    double y = __builtin_amdgcn_rsq(d);
-    y = fma(y, fma(-h * y, y, 0.5), y);
-    y = fma(y, fma(-h * y, y, 0.5), y);
-    return y;
+    // One third-order step instead of two Newton steps: with e = 1 - d y^2, y (1 + e / 2 + 3 e^2 / 8) leaves
+    // an error of 5/16 e^3.  v_rsq_f64 is good to 2^-24 (tools/micro/rsq_precision.hip: 5.2e-8; one Newton
+    // step 4.2e-15, two 1.4e-16), so the cubic step lands within an ulp as the two Newton steps did -- in a
+    // chain of four dependent operations (t, e, {p, r}, result) instead of six.
+    const double y = __builtin_amdgcn_rsq(d);
+    const double e = fma(-(d * y), y, 1.0);
+    const double p = fma(0.375, e, 0.5);
+    const double r = y * e;
+    return fma(r, p, y);
 }
 
 // 1 / d to double precision: v_rcp_f64 seed and two Newton steps (four dependent operations)
