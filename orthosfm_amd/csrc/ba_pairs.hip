@@ -103,15 +103,17 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
                   "lengths) exceed the supported 2^31 - 1", (long long)max_entries);
         return OSFM_E_RANGE;
     }
-    OSFM_RETURN_IF(out->counts.reserve((size_t)(std::max<int64_t>(M, max_entries) + 1) * 4));   // later: chunk counts per pair
+    // Count first, allocate what the count says: the bound (sum of squared track lengths) is twice the number
+    // of entries (pairs with cam(a) >= cam(b) only), and the arrays it would size are the gigabytes of this
+    // build on a 500-view job -- reallocated whenever the growing problem crossed a size class of the block
+    // cache (0.65 s per event: a dozen of them were half of that job's global adjustments).  The runs of the
+    // sorted keys are camera pairs: at most C (C + 1) / 2 of them, however many entries there are.
+    const int64_t max_runs = std::min<int64_t>(max_entries, (int64_t)d.C * ((int64_t)d.C + 1) / 2) + 1;
+    OSFM_RETURN_IF(out->counts.reserve((size_t)(std::max<int64_t>(M, max_runs) + 1) * 4));   // later: chunk counts per pair
     OSFM_RETURN_IF(out->offsets.reserve((size_t)(M + 1) * 4));
-    OSFM_RETURN_IF(out->keys_in.reserve((size_t)max_entries * 4));
-    OSFM_RETURN_IF(out->keys.reserve((size_t)max_entries * 4));
-    OSFM_RETURN_IF(out->vals_in.reserve((size_t)max_entries * 8));
-    OSFM_RETURN_IF(out->entries.reserve((size_t)max_entries * 8));
-    OSFM_RETURN_IF(out->unique.reserve((size_t)max_entries * 4 + 16));
-    OSFM_RETURN_IF(out->runs.reserve((size_t)max_entries * 4 + 16));
-    OSFM_RETURN_IF(out->starts.reserve((size_t)max_entries * 4 + 16));
+    OSFM_RETURN_IF(out->unique.reserve((size_t)max_runs * 4 + 16));
+    OSFM_RETURN_IF(out->runs.reserve((size_t)max_runs * 4 + 16));
+    OSFM_RETURN_IF(out->starts.reserve((size_t)max_runs * 4 + 16));
     OSFM_RETURN_IF(out->scalars.reserve(64));
 
     const int blocks = (M + 255) / 256;
@@ -119,30 +121,34 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
         out->counts.as<int32_t>());
     size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     int32_t *counts = out->counts.as<int32_t>(), *offsets = out->offsets.as<int32_t>();
-    uint32_t *kin = out->keys_in.as<uint32_t>(), *kout = out->keys.as<uint32_t>();
-    uint64_t *vin = out->vals_in.as<uint64_t>(), *vout = out->entries.as<uint64_t>();
     int bits = 1;
     while ((1ull << bits) < (unsigned long long)d.C * (unsigned long long)d.C) ++bits;
     OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, t1, counts, offsets, M, s));
-    OSFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, t2, kin, kout, vin, vout, (int)max_entries, 0, bits, s));
-    OSFM_HIP_CHECK(hipcub::DeviceRunLengthEncode::Encode(nullptr, t3, kout, out->unique.as<uint32_t>(),
-        out->runs.as<int32_t>(), out->scalars.as<int32_t>(), (int)max_entries, s));
-    OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, t4, out->runs.as<int32_t>(), out->starts.as<int32_t>(),
-        (int)max_entries, s));
-    OSFM_RETURN_IF(out->temp.reserve(std::max(std::max(t1, t2), std::max(t3, t4)) + 256));
-
+    OSFM_RETURN_IF(out->temp.reserve(t1 + 256));
     size_t tb = out->temp.bytes;
     OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(out->temp.ptr, tb, counts, offsets, M, s));
     // total = offsets[M-1] + counts[M-1]
     int32_t h_last[2] = { 0, 0 };
     OSFM_HIP_CHECK(hipMemcpyAsync(&h_last[0], offsets + (M - 1), 4, hipMemcpyDeviceToHost, s));
     OSFM_HIP_CHECK(hipMemcpyAsync(&h_last[1], counts + (M - 1), 4, hipMemcpyDeviceToHost, s));
-    hipLaunchKernelGGL(pair_fill_kernel, dim3(blocks), dim3(256), 0, s, d, with_points ? 1 : 0, offsets, kin, vin);
     OSFM_HIP_CHECK(hipStreamSynchronize(s));
     const int E = h_last[0] + h_last[1];
     if (E > max_entries) { set_error("pair lists: %d entries exceed the bound %lld", E, (long long)max_entries); return OSFM_E_ARG; }
     out->num_entries = E;
     if (E == 0) return OSFM_OK;
+    OSFM_RETURN_IF(out->keys_in.reserve((size_t)E * 4));
+    OSFM_RETURN_IF(out->keys.reserve((size_t)E * 4));
+    OSFM_RETURN_IF(out->vals_in.reserve((size_t)E * 8));
+    OSFM_RETURN_IF(out->entries.reserve((size_t)E * 8));
+    uint32_t *kin = out->keys_in.as<uint32_t>(), *kout = out->keys.as<uint32_t>();
+    uint64_t *vin = out->vals_in.as<uint64_t>(), *vout = out->entries.as<uint64_t>();
+    OSFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, t2, kin, kout, vin, vout, E, 0, bits, s));
+    OSFM_HIP_CHECK(hipcub::DeviceRunLengthEncode::Encode(nullptr, t3, kout, out->unique.as<uint32_t>(),
+        out->runs.as<int32_t>(), out->scalars.as<int32_t>(), E, s));
+    OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, t4, out->runs.as<int32_t>(), out->starts.as<int32_t>(),
+        (int)max_runs, s));
+    OSFM_RETURN_IF(out->temp.reserve(std::max(std::max(t1, t2), std::max(t3, t4)) + 256));
+    hipLaunchKernelGGL(pair_fill_kernel, dim3(blocks), dim3(256), 0, s, d, with_points ? 1 : 0, offsets, kin, vin);
     tb = out->temp.bytes;
     OSFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(out->temp.ptr, tb, kin, kout, vin, vout, E, 0, bits, s));
     tb = out->temp.bytes;

@@ -71,7 +71,7 @@ struct DeviceBuffer {
 // given out again; osfm_trim_device_memory() returns them to the driver.  What is kept is
 // bounded (kPoolKeepBytes per device); beyond it a block is freed at once.
 struct DevicePool {
-    static constexpr size_t kPoolKeepBytes = (size_t)8 << 30;
+    static constexpr size_t kPoolKeepBytes = (size_t)48 << 30;   // of 288 GB: the work arrays of a 500-view global adjustment are ~6 GB
     struct Block { void *ptr; size_t bytes; };
     std::mutex mutex;
     std::unordered_map<int, std::multimap<size_t, void *>> free_blocks;    // device -> size class -> blocks
