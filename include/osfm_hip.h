@@ -49,12 +49,18 @@ OSFM_API int osfm_device_memory(int device, uint64_t *free_bytes, uint64_t *tota
  * (may be NULL) reports how much that was. */
 OSFM_API int osfm_trim_device_memory(int device, uint64_t *released_bytes);
 /* Diagnostic: the one-launch Cholesky of osfm_ba_solve leaves 16 stamps per diagonal workgroup of
- * its most recent factorisation: stamps[65][16], read by tools/chol_flow_trace.py (100 MHz
+ * its most recent factorisation: stamps[161][32] (one row per block row), read by tools/chol_flow_trace.py (100 MHz
  * counter: start, L of the last column published, factor started, inverse published; shader
  * cycles of the pivot loop and of the factor; how the inverse arrived: 1 = sc1 copy, 2 =
  * same-XCD mailbox).  enable != 0 switches the recording on
  * (current device) and returns what was recorded so far; 0 returns it and switches it off. */
 OSFM_API int osfm_ba_debug_chol_trace(int enable, int64_t *stamps);
+
+/* Test hook: the number of polls a wait of the one-launch Cholesky makes before it gives the launch up
+ * (<= 0: the default, 2^21).  A launch given up is repeated by osfm_ba_solve in the launch-per-column
+ * form and counted in osfm_ba_summary.flow_fallbacks; set small, every wait that is not satisfied at
+ * once takes that path. */
+OSFM_API int osfm_ba_debug_flow_spin_limit(int limit);
 
 /* Diagnostic of the RANSAC-F scoring loop.  Its Sampson tests are pre-classified in packed
  * single precision; a test only counts when the float result is out of reach of its error
@@ -398,6 +404,10 @@ typedef struct osfm_ba_summary {
     int32_t num_pair_entries;         /* observation pairs in the Schur complement lists */
     double lm_loop_ms;                /* wall time of the LM iterations alone (host control included;
                                        * problem upload, pair lists and the first linearisation are not) */
+    int32_t flow_fallbacks;           /* factorisations whose one-launch form gave its launch up (its workgroups
+                                       * were not all resident: the device was shared) and that were repeated in
+                                       * the launch-per-column form; the results do not depend on it */
+    int32_t reserved0;
 } osfm_ba_summary;
 
 OSFM_API int osfm_ba_options_default(osfm_ba_options *opts);

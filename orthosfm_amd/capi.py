@@ -109,12 +109,13 @@ class BaSummary(C.Structure):
                 ("pair_pass_ms", C.c_double), ("cholesky_ms", C.c_double),
                 ("back_pass_ms", C.c_double),
                 ("linearizations", C.c_int32), ("num_pair_entries", C.c_int32),
-                ("lm_loop_ms", C.c_double)]
+                ("lm_loop_ms", C.c_double),
+                ("flow_fallbacks", C.c_int32), ("reserved0", C.c_int32)]
 
 
 # every symbol include/osfm_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = [
-    "osfm_last_error", "osfm_version", "osfm_device_count", "osfm_device_memory", "osfm_trim_device_memory", "osfm_ransac_selfcheck", "osfm_ba_debug_chol_trace",
+    "osfm_last_error", "osfm_version", "osfm_device_count", "osfm_device_memory", "osfm_trim_device_memory", "osfm_ransac_selfcheck", "osfm_ba_debug_chol_trace", "osfm_ba_debug_flow_spin_limit",
     "osfm_match_options_default", "osfm_match_create", "osfm_match_create_multi", "osfm_match_get_devices", "osfm_match_destroy",
     "osfm_quantize_sift", "osfm_quantize_surf",
     "osfm_match_set_view", "osfm_match_set_view_float", "osfm_match_view_size", "osfm_match_set_positions",

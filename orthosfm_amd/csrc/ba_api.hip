@@ -181,8 +181,14 @@ int osfm_ba_debug_chol_trace(int enable, int64_t *stamps)
     OSFM_HIP_CHECK(hipDeviceSynchronize());
     long long *buf = chol_flow_trace_buffer(1);
     if (!buf) { set_error("ba_debug_chol_trace: no memory for the trace"); return OSFM_E_DEVICE; }
-    if (stamps) OSFM_HIP_CHECK(hipMemcpy(stamps, buf, 65 * 16 * 8, hipMemcpyDeviceToHost));
+    if (stamps) OSFM_HIP_CHECK(hipMemcpy(stamps, buf, 161 * 32 * 8, hipMemcpyDeviceToHost));
     if (!enable) chol_flow_trace_buffer(0);
+    return OSFM_OK;
+}
+
+int osfm_ba_debug_flow_spin_limit(int limit)
+{
+    chol_flow_set_spin_limit(limit);
     return OSFM_OK;
 }
 
@@ -415,12 +421,14 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     const bool eager = N / 32 <= 4;
     LmDev fin;
     memset(&fin, 0, sizeof(fin));
+    bool flow_now = use_flow;            // the one-launch Cholesky, until a launch of it had to be given up
+    int restarts = 0;
     for (int it = 0; it < max_slots - 2; ++it) {
         const int slot = it + 1;          // h_state[slot]: the state this iteration leaves
         OSFM_RETURN_IF(tic(2));
         if (small) launch_small_solve(S.as<double>(), nc, Ldiag.as<double>(), y_c.as<double>(), info.as<int>(), d, part_cam.as<double>(), s);
         else if (nc > 0) launch_cholesky_solve(S.as<double>(), Lmat.as<double>(), nc, Ldiag.as<double>(), y_c.as<double>(), info.as<int>(), lm, s,
-            use_flow ? flow_flags.as<int>() : nullptr, ++flow_epoch, use_flow ? flow_mailbox.as<double>() : nullptr);
+            flow_now ? flow_flags.as<int>() : nullptr, ++flow_epoch, flow_now ? flow_mailbox.as<double>() : nullptr);
         OSFM_RETURN_IF(toc());
         OSFM_RETURN_IF(tic(3));
         if (!small) launch_cam_update(d, y_c.as<double>(), nullptr, part_cam.as<double>(), s);
@@ -436,17 +444,34 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
         OSFM_RETURN_IF(linearize(!small));
         launch_lm_post(lm, prm, sc, 0, eager ? &h_state[slot] : nullptr, s);
         OSFM_HIP_CHECK(hipGetLastError());
+        int seen = -1;                    // the slot whose state the host has read in this round
         if (eager) {
             OSFM_HIP_CHECK(hipEventRecord(evs[slot], s));
             if (it >= 1) {
                 // what iteration it - 1 left behind (this iteration is already queued after it)
                 OSFM_HIP_CHECK(hipEventSynchronize(evs[slot - 1]));
-                if (h_state[slot - 1].stop) break;
+                seen = slot - 1;
             }
         } else {
             OSFM_HIP_CHECK(hipEventSynchronize(evs[slot]));
-            if (h_state[slot].stop) break;
+            seen = slot;
         }
+        if (seen >= 0 && h_state[seen].flow_aborted) {
+            // The one-launch factorisation of iteration seen - 1 gave up (a wait outlasted its spin limit: its
+            // workgroups were not all resident).  Nothing was decided from it -- ba_lm_decide left the state as
+            // it was and every kernel behind it returned at once (the reset of the system excepted) -- so the
+            // system is linearised again at the same iterate, with the same diagonal, and the iteration is
+            // repeated in the launch-per-column form, like the rest of the solve.
+            if (!flow_now || ++restarts > 1) { set_error("ba_solve: the Cholesky launch was given up twice (device busy?)"); return OSFM_E_DEVICE; }
+            flow_now = false;
+            sum->flow_fallbacks++;
+            OSFM_HIP_CHECK(hipStreamSynchronize(s));
+            launch_lm_clear_abort(lm, s);
+            OSFM_RETURN_IF(linearize(!small));
+            it = seen - 2;                // the loop's increment makes it seen - 1: that iteration again
+            continue;
+        }
+        if (seen >= 0 && h_state[seen].stop) break;
     }
     OSFM_HIP_CHECK(hipMemcpyAsync(&h_state[max_slots - 1], lm, sizeof(LmDev), hipMemcpyDeviceToHost, s));
     OSFM_HIP_CHECK(hipStreamSynchronize(s));

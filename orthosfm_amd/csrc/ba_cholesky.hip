@@ -16,6 +16,7 @@
 //                   solves A_ik <- A_ik L_kk^-T for 64 rows of the panel
 //   chol_update(k): A_ij -= L_ik L_jk^T for k < j <= i (incl. the rhs row)
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 
 #include "ba_kernels.h"
@@ -60,26 +61,6 @@ __device__ __forceinline__ double rcp_newton(double d)
     return y;
 }
 
-// Factor of one 32 x 32 diagonal block by ONE wave, then inv(L_kk) for the neighbours'
-// triangular solves and the backward substitution.  The pivots form a serial chain, so
-// what counts is the latency of one link and the instructions hanging off it.  Lane r (and
-// its twin r + 32, which does the same work: no divergent code anywhere) holds row r in
-// registers.  Link j: the pivot comes by v_readlane, enters as a reciprocal square root
-// (v_rsq_f64 + two Newton steps; a sqrt and a divide are ~70 dependent instructions), the
-// scaled column goes to LDS once and comes back as broadcast ds_read_b128s, two
-// multipliers each (one v_readlane pair per multiplier was 2.5x the instructions).
-// Msrc: the block, row-major with leading dimension lds_ld, in LDS.  All 64 lanes of one
-// wave call this; workgroup barriers around it are the caller's.
-__device__ __forceinline__ double swap_halves(double v)
-{
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const auto a = __builtin_amdgcn_permlane32_swap((unsigned)lo, (unsigned)lo, false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap((unsigned)hi, (unsigned)hi, false, false);
-    // lanes 0-31 receive what lanes 32-63 held and vice versa
-    const int lane_hi = (int)(threadIdx.x & 63) >> 5;
-    return __hiloint2double(lane_hi ? (int)b[0] : (int)b[1], lane_hi ? (int)a[0] : (int)a[1]);
-}
-
 // Workgroup barrier that only orders LDS traffic.  __syncthreads() also drains the
 // vector-memory counter, which would expose the latency of every prefetch and of every
 // result store (2-3 us for a write-through store) once per step of a chain.
@@ -90,110 +71,217 @@ __device__ __forceinline__ void lds_barrier()
 
 // (store_sc1 / load_sc1: ba_device.h)
 
-template <bool SC1 = false>
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// Factor of one 32 x 32 diagonal block as eight rank-4 panels on the f64 matrix cores, by TWO waves, with inv(L)
+// -- what the neighbours' triangular solves and the backward substitution multiply by -- riding along.
+//
+// Round 3's form kept a row per lane of one wave and ran 32 scalar pivots, each with ~15 trailing FMAs and eight
+// LDS reads hanging off it: 410 cycles per pivot for a dependency chain of ~106 (a wave issues in order).  Here the
+// trailing matrix lives in the accumulator layout of v_mfma_f64_16x16x4_f64 (lane = (c, g) = (lane & 15,
+// lane >> 4), register e: element (g + 4 e, c) of a 16 x 16 quadrant), three quadrants C00, C01, C11 -- the
+// matrix is symmetric, and that is what makes the scheme cheap: rows 4p .. 4p+3 of the quadrants are register
+// p & 3 of every lane, and read as COLUMNS 4p .. 4p+3 they are the panel in the A/B OPERAND layout of the same
+// instruction (lane (c, g) holds X[c][g]) without moving a byte.  Per panel:
+//   1. the 4 x 4 diagonal block comes out by v_readlane (10 values) and is factored, and inverted, uniformly in
+//      every lane -- the only serial part.  Its four pivots are taken as two PAIRS: with det = a00 a11 - a10^2
+//      the second pivot of a pair is det / a00, so 1 / sqrt(d1) = sqrt(a00) * rsqrt(det) and the two reciprocal
+//      square roots (v_rsq_f64 + a third-order step: five dependent operations each) run side by side instead
+//      of one behind the other; det carries the rounding error a11 - l10^2 would (eps a10^2 in both).  18
+//      dependent operations per panel instead of 36;
+//   2. W = inv(L_pp), padded to 16 x 4, is the A operand of one MFMA per 16 panel rows whose B operand is the raw
+//      panel: register 0 of the result is the finished panel L[:, 4p .. 4p+3], again in operand layout (TRSM as a product);
+//   3. trailing update C -= L_p L_p^T: one MFMA per live quadrant with K = 4, the panel width.
+// The inverse: E starts as the identity, is kept TRANSPOSED in the same layout (quadrants T00, T10, T11; E^T so
+// that its panel, too, is a register in operand layout) and takes the same two steps -- Y_p = E_p W^T is rows
+// 4p .. 4p+3 of inv(L), final at once and stored from there; E^T -= L_p Y_p^T.  Exact zeros stay exact (the
+// upper triangle of inv(L) is read by the tile products as zeros).
+// Why two waves: on gfx950 one v_mfma_f64_16x16x4_f64 occupies its SIMD's matrix pipe for ~64 cycles and returns
+// after ~95 (tools/micro/factor_bench.hip), and a wave issues in order -- with the inverse in the same wave the
+// 48 products of a block took 9.4k cycles of which the chain is 6.0k.  So wave 0 runs the chain -- pivots, the
+// panel, the updates of A -- and publishes (W, L_p) per panel through LDS; wave 1, on another SIMD with a matrix
+// pipe of its own, does the inverse and all the stores.  (A third wave for the rows 16 .. 31 of the first four
+// panels, taking the chain over at panel 4, was measured: the hand-over costs more than the three products per
+// panel it takes out of wave 0's stream, which fit behind the update the next panel waits for.)
+// A pivot that is not positive raises info (kblock * 32 + the first row of its panel + 1, the largest such) and
+// leaves NaNs behind: whoever reads info discards the factor.
+// Msrc: the block (lower triangle valid), row-major with leading dimension lds_ld, in LDS.  The first two waves
+// of the workgroup call this (128 threads); workgroup barriers around it are the caller's.  comm_ab (8 KB), comm_l1
+// (2 KB): LDS scratch; prog: one LDS word, zero on entry, zero again on return.  nvalid: rows / columns from there
+// on are identity padding (workgroup-uniform): their panels are skipped.  Msrc may be linv_lds: wave 0 has the
+// block in registers before the first panel is published, and the inverse is stored behind that.
+//
+// The progress word lives in LDS; the pointer arrives as a generic one (through a struct, in the flow kernel), and a
+// volatile access through a generic pointer is a flat instruction followed by s_waitcnt vmcnt(0) -- on the chain
+// that waited for every global store in flight.  Hence the explicit address space.
+typedef __attribute__((address_space(3))) int lds_int_t;
+__device__ __forceinline__ void factor_post(int *word, int value)
+{
+    asm volatile("" ::: "memory");
+    *(volatile lds_int_t *)(lds_int_t *)word = value;       // the LDS runs one wave's operations in order: data first, then this
+}
+__device__ __forceinline__ void factor_wait(const int *word, int want)
+{
+    while (*(const volatile lds_int_t *)(const lds_int_t *)word < want) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
+// FINE (tools/micro/factor_bench.hip only): dbg[64 + 4 p + i] = cycles at the pivots done / A operand ready / panel out / update back
+template <bool SC1 = false, bool FINE = false>
 __device__ __forceinline__ void
-factor_diag_block(const double *Msrc, int lds_ld, double (*LsT)[NB], int kblock, double *Ldiag, int *info,
+factor_diag_block(const double *Msrc, int lds_ld, int kblock, double *Ldiag, int *info, double *comm_ab, double *comm_l1, int *prog,
     double *linv_lds = nullptr, int linv_ld = 0, int nvalid = NB, bool ldiag_is_block = false, long long *dbg = nullptr)
 {
     const long long dbg_t0 = dbg ? (long long)clock64() : 0;
-    // nvalid: rows / columns from there on are identity padding (wave-uniform); their pivot
-    // steps and inverse rows change nothing and are skipped -- the chain is serial, so a
-    // 17-unknown system (three cameras) is done in half the time of a full block
-    __shared__ __attribute__((aligned(16))) double colbuf[2][2 * NB];  // [pivot parity][lane]: column j of L in [0, NB)
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    // Lanes 0..31: row r of the block, turning into row r of L.  Lanes 32..63: e_r, turning
-    // into column r of inv(L) (L x = e_r, column-oriented: once x[j] is final every later
-    // entry takes L[i][j] x[j]).  Both are the SAME instructions -- v[j] *= 1/L[j][j], then
-    // v[c] -= v[j] * L[c][j] for c > j -- so the inverse costs nothing beyond the lanes that
-    // used to mirror the factorisation, and its chain hangs off the pivot chain instead of
-    // forming a second one of 32 links behind it.
-    double v[NB];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+    if (wave == 0) {
+        // ---- the chain ----
+        __builtin_amdgcn_s_setprio(3);
+        v4d C00, C01, C11;
 #pragma unroll
-    for (int c = 0; c < NB; ++c) v[c] = h == 0 ? Msrc[r * lds_ld + c] : (c == r ? 1.0 : 0.0);
-    int bad = 0;
-    // (Measured and not kept: the elimination in LDL^T form on unscaled columns -- the column goes
-    //  to LDS and lane j+1's entry comes by v_readlane before anything is computed from the pivot,
-    //  the link is d -> 1/d (v_rcp_f64 + two Newton steps) -> t -> fma -> v_readlane, the Cholesky
-    //  scale 1/sqrt(d) applied off the chain: 370 instead of 410 cycles per pivot, but the 32
-    //  square-root iterations pile up behind the loop and the block takes 15.5k cycles instead of
-    //  14.3k.  One wave issues in order: a pivot costs the SUM of its chain stalls, its ~15 trailing
-    //  FMAs and its LDS reads, not the longest of them.)
-    // Pivot j: only column j + 1 has to be final before pivot j + 1 can start, so that
-    // column takes its multiplier L[j+1][j] by v_readlane right away and the next pivot's
-    // reciprocal square root (the longest link of the chain) is started at once; the other
-    // columns take their multipliers from LDS (broadcast ds_read_b128, two each) -- a round
-    // trip of > 100 cycles -- with the reads issued in front of that chain and consumed
-    // behind it.
-    double d = nvalid > 0 ? readlane_d(v[0], 0) : 1.0;
-    if (!(d > 0.0)) { d = 1.0; bad = 1; }
-    double rinv = rsqrt_newton(d);
+        for (int e = 0; e < 4; ++e) {
+            const int i = g + 4 * e, hi = max(i, c), lo = min(i, c);
+            C00[e] = Msrc[hi * lds_ld + lo];
+            C01[e] = Msrc[(16 + c) * lds_ld + i];
+            C11[e] = Msrc[(16 + hi) * lds_ld + 16 + lo];
+        }
+        // weights of the ten entries of W in this lane's slot of the A operand: (row, column) at lane row + 16 column
+        double mk[10];
+        {
+            const int at[10] = {0, 1, 17, 2, 18, 34, 3, 19, 35, 51};       // r0 w10 r1 w20 w21 r2 w30 w31 w32 r3
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        if (j >= nvalid) continue;          // identity rows: nothing to eliminate, x[j] stays e_r[j]
-        const double vj = (lane == j && bad == j + 1) ? 1.0 : v[j] * rinv;   // lane j: d / sqrt(d) = sqrt(d)
-        v[j] = vj;
-        if (j + 1 < NB) {
-            colbuf[j & 1][lane] = vj;           // lanes 0..31: column j of L (the rest is not read)
-            // The LDS executes one wave's operations in order, so no wait is needed -- but the
-            // COMPILER must be told that other lanes wrote what this lane is about to read
-            // (without the fence it re-used values a lane had loaded two pivots earlier)
-            asm volatile("" ::: "memory");
-            double col[NB];
+            for (int k = 0; k < 10; ++k) mk[k] = lane == at[k] ? 1.0 : 0.0;
+        }
+        int bad = 0;
 #pragma unroll
-            for (int c = j + 2; c < NB; ++c) col[c] = colbuf[j & 1][c];
-            __builtin_amdgcn_sched_barrier(0);
-            v[j + 1] = fma(-vj, readlane_d(vj, j + 1), v[j + 1]);
-            if (j + 1 < nvalid) {
-                d = readlane_d(v[j + 1], j + 1);
-                if (!(d > 0.0)) { d = 1.0; bad = j + 2; }
-                rinv = rsqrt_newton(d);
+        for (int p = 0; p < NB / 4; ++p) {
+            const int qi = p >> 2, e = p & 3, b0 = 4 * e;
+            if (4 * p >= nvalid) break;
+            const double ad = qi ? C11[e] : C00[e];          // panel rows of the quadrant that holds its diagonal block
+            // ---- the 4 x 4 diagonal block, the same in every lane ----
+            const double a00 = readlane_d(ad, b0), a10 = readlane_d(ad, b0 + 1), a11 = readlane_d(ad, b0 + 17);
+            const double a20 = readlane_d(ad, b0 + 2), a30 = readlane_d(ad, b0 + 3), a21 = readlane_d(ad, b0 + 18), a31 = readlane_d(ad, b0 + 19);
+            const double a22 = readlane_d(ad, b0 + 34), a32 = readlane_d(ad, b0 + 35), a33 = readlane_d(ad, b0 + 51);
+            // first pair of pivots: a00 and det / a00
+            const double det1 = fma(a00, a11, -(a10 * a10));
+            const double r0 = rsqrt_newton(a00), z1 = rsqrt_newton(det1);
+            const double r1 = (a00 * r0) * z1;
+            const double l10 = a10 * r0, l20 = a20 * r0, l30 = a30 * r0;
+            const double l21 = fma(-l20, l10, a21) * r1, l31 = fma(-l30, l10, a31) * r1;
+            // Schur complement of the pair, second pair of pivots
+            const double b22 = fma(-l21, l21, fma(-l20, l20, a22));
+            const double b32 = fma(-l31, l21, fma(-l30, l20, a32));
+            const double b33 = fma(-l31, l31, fma(-l30, l30, a33));
+            const double det2 = fma(b22, b33, -(b32 * b32));
+            const double r2 = rsqrt_newton(b22), z3 = rsqrt_newton(det2);
+            const double r3 = (b22 * r2) * z3;
+            const double l32 = b32 * r2;
+            // all four pivots positive?  (the inputs are finite, so a NaN only follows a value that fails this test)
+            if (!(fmin(fmin(a00, det1), fmin(b22, det2)) > 0.0)) bad = max(bad, 4 * p + 1);
+            if (FINE) { asm volatile("" :: "v"(r3)); if (lane == 0) dbg[64 + 4 * p] = (long long)clock64() - dbg_t0; }
+            // W = inv(L_pp): W[j][k] = -r_j sum_{k <= m < j} L[j][m] W[m][k]
+            const double w10 = -(l10 * r0) * r1, w21 = -(l21 * r1) * r2, w32 = -(l32 * r2) * r3;
+            const double w20 = -fma(l21, w10, l20 * r0) * r2, w31 = -fma(l32, w21, l31 * r1) * r3;
+            const double w30 = -fma(l32, w20, fma(l31, w10, l30 * r0)) * r3;
+            // lane (c, g) of the A operand: W[c][g] for g <= c < 4, else 0 -- as a sum over the ten entries with 0 / 1
+            // weights per lane (at most one is 1): ten FMAs, the last row's four two operations deep, instead of ten
+            // compares and twenty selects in a wave that is bound by its issue slots
+            const double early = fma(mk[5], r2, fma(mk[4], w21, fma(mk[3], w20, fma(mk[2], r1, fma(mk[1], w10, mk[0] * r0)))));
+            const double wop = fma(mk[6], w30, early) + fma(mk[9], r3, fma(mk[8], w32, mk[7] * w31));
+            if (FINE) { asm volatile("" :: "v"(wop)); if (lane == 0) dbg[64 + 4 * p + 1] = (long long)clock64() - dbg_t0; }
+            // ---- the panel: L[:, 4p .. 4p+3] = P W^T, register 0 of W_op x P^T; rows above the diagonal are zero ----
+            double Ld = __builtin_amdgcn_mfma_f64_16x16x4f64(wop, ad, zero4, 0, 0, 0)[0];
+            double L1 = 0.0;
+            if (qi == 0) L1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wop, C01[e], zero4, 0, 0, 0)[0];     // rows 16 .. 31
+            Ld = c >= b0 + g ? Ld : 0.0;
+            if (FINE) { asm volatile("" :: "v"(Ld)); if (lane == 0) dbg[64 + 4 * p + 2] = (long long)clock64() - dbg_t0; }
+            // ---- trailing updates, the one the next panel waits for first ----
+            if (qi == 0) {
+                if (e < 3) C00 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ld, Ld, C00, 0, 0, 0);
+                C11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-L1, L1, C11, 0, 0, 0);
+                if (e < 3) C01 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ld, L1, C01, 0, 0, 0);
+                comm_l1[p * 64 + lane] = L1;
+            } else if (e < 3) {
+                C11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ld, Ld, C11, 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = j + 2; c < NB; ++c) v[c] = fma(-vj, col[c], v[c]);    // L: meaningful for r >= c
+            comm_ab[(2 * p) * 64 + lane] = wop;
+            comm_ab[(2 * p + 1) * 64 + lane] = Ld;
+            factor_post(prog, p + 1);                       // every lane writes the same word: no branch around it
+            if (dbg && lane == 0) dbg[15 + p] = (long long)clock64() - dbg_t0;
+            if (FINE && p < 7) { asm volatile("" :: "v"(p < 3 ? C00[(e + 1) & 3] : C11[(e + 1) & 3])); if (lane == 0) dbg[64 + 4 * p + 3] = (long long)clock64() - dbg_t0; }
         }
-    }
-    if (dbg && (threadIdx.x & 63) == 0) dbg[0] = (long long)clock64() - dbg_t0;
-    if (bad && lane == 0) atomicMax(info, kblock * NB + bad);
-    // L itself, transposed (LsT[c][i] = L[i][c], zero above the diagonal), for a caller that
-    // wants to look at it: lane r writes element r of every row, consecutive addresses
-    if (LsT && h == 0) {
+        __builtin_amdgcn_s_setprio(0);
+        if (bad && lane == 0) atomicMax(info, kblock * NB + bad);
+    } else if (wave == 1) {
+        // ---- the inverse ----
+        v4d T00, T10, T11;
 #pragma unroll
-        for (int c = 0; c < NB; ++c) LsT[c][r] = c <= r ? v[c] : 0.0;
-    }
-    if (h == 1) {
+        for (int e = 0; e < 4; ++e) { T00[e] = g + 4 * e == c ? 1.0 : 0.0; T11[e] = T00[e]; T10[e] = 0.0; }
         double *Lk = Ldiag + (ldiag_is_block ? 0 : (size_t)kblock * NB * NB);   // [i][j] = inv(L)[i][j]
+        // (Msrc == linv_lds is safe: the first rows of the inverse are stored behind the wait for panel 0, which wave 0
+        //  publishes with the whole block in its registers)
 #pragma unroll
-        for (int i = 0; i < NB; ++i) { if (SC1) store_sc1(&Lk[i * NB + r], v[i]); else Lk[i * NB + r] = v[i]; }
-        // a copy in LDS for a caller that goes on to use it (Msrc itself may be the target:
-        // the block was read into registers at the top)
-        if (linv_lds) {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) linv_lds[i * linv_ld + r] = v[i];
+        for (int p = 0; p < NB / 4; ++p) {
+            const int qi = p >> 2, e = p & 3;
+            const double E0 = qi ? T10[e] : T00[e];          // panel of E, rows 0 .. 15
+            double Y0 = E0, Y1 = qi ? T11[e] : 0.0;          // rows 4p .. 4p+3 of inv(L): columns 0 .. 15, 16 .. 31
+            if (4 * p < nvalid) {
+                factor_wait(prog, p + 1);
+                const double wop = comm_ab[(2 * p) * 64 + lane], nLd = -comm_ab[(2 * p + 1) * 64 + lane];
+                Y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wop, E0, zero4, 0, 0, 0)[0];
+                if (qi == 0) {
+                    if (e < 3) T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(nLd, Y0, T00, 0, 0, 0);
+                    T10 = __builtin_amdgcn_mfma_f64_16x16x4f64(-comm_l1[p * 64 + lane], Y0, T10, 0, 0, 0);
+                } else {
+                    Y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wop, T11[e], zero4, 0, 0, 0)[0];
+                    if (e < 3) {
+                        T10 = __builtin_amdgcn_mfma_f64_16x16x4f64(nLd, Y0, T10, 0, 0, 0);
+                        T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(nLd, Y1, T11, 0, 0, 0);
+                    }
+                }
+            }
+            // rows 4p .. 4p+3 of inv(L) are final: lane (c, g) holds [4p + g][c] and [4p + g][16 + c]
+            double *row = Lk + (4 * p + g) * NB;
+            if (SC1) { store_sc1(row + c, Y0); store_sc1(row + 16 + c, Y1); }
+            else { row[c] = Y0; row[16 + c] = Y1; }
+            if (linv_lds) { linv_lds[(4 * p + g) * linv_ld + c] = Y0; linv_lds[(4 * p + g) * linv_ld + 16 + c] = Y1; }
+            if (dbg && lane == 0) dbg[23 + p] = (long long)clock64() - dbg_t0;
         }
+        if (lane == 0) factor_post(prog, 0);
+        if (dbg && lane == 0) dbg[0] = (long long)clock64() - dbg_t0;
     }
 }
 
+// LDS scratch of factor_diag_block: (W, L_p) of the eight panels, L_p's rows 16 .. 31 of the first four, progress words
+struct FactorComm {
+    double ab[8 * 2 * 64];
+    double l1[4 * 64];
+    int prog[2];
+};
+
 // Block 0: nothing to update, just the factor.
-__global__ __launch_bounds__(64, 1) void
+__global__ __launch_bounds__(128, 1) void
 chol_first_kernel(const double *A, int ld, double *Ldiag, int *info, const LmDev *lm)
 {
-    if (lm && (lm->stop || lm->lin_failed)) return;
+    if (lm && (lm->stop || lm->lin_failed || lm->flow_aborted)) return;
     __shared__ __attribute__((aligned(16))) double M[NB][NB + 1];
+    __shared__ __attribute__((aligned(16))) FactorComm fc;
     const int lane = threadIdx.x, r = lane & 31;
     if (lane < NB) {
 #pragma unroll
         for (int c = 0; c < NB; ++c) M[r][c] = A[(size_t)r * ld + c];
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    factor_diag_block(&M[0][0], NB + 1, nullptr, 0, Ldiag, info);
+    if (lane == 64) { fc.prog[0] = 0; fc.prog[1] = 0; }
+    __syncthreads();
+    factor_diag_block(&M[0][0], NB + 1, 0, Ldiag, info, fc.ab, fc.l1, fc.prog);
 }
 
 // A system of one block (n <= 32: the three-camera adjustments of the incremental
 // reconstruction) start to finish in one launch of one wave: factor, y = inv(L) b,
 // x = inv(L)^T y, and the candidate cameras Plus(x, -step) that the next kernel needs --
-// four launches of a latency-bound chain in one.
-__global__ __launch_bounds__(64, 1) void
+// four launches of a latency-bound chain in one.  (Two waves for the factor, one for the rest.)
+__global__ __launch_bounds__(128, 1) void
 chol_small_kernel(const double *A, int ld, int n, double *Ldiag, double *x, int *info, BaDev d,
     double *partials_cam)
 {
@@ -201,6 +289,7 @@ chol_small_kernel(const double *A, int ld, int n, double *Ldiag, double *x, int 
     if (d.lm == nullptr || d.lm->lin_failed) return;      // this kernel writes the candidate cameras of an LM solve: no state, nothing to do
     __shared__ __attribute__((aligned(16))) double M[NB][NB + 1];
     __shared__ double ys[NB], xs[NB];
+    __shared__ __attribute__((aligned(16))) FactorComm fc;
     const int lane = threadIdx.x, r = lane & 31;
     double b = 0.0;
     if (lane < NB) {
@@ -208,8 +297,11 @@ chol_small_kernel(const double *A, int ld, int n, double *Ldiag, double *x, int 
         for (int c = 0; c < NB; ++c) M[r][c] = A[(size_t)r * ld + c];
         b = A[(size_t)NB * ld + r];
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    factor_diag_block(&M[0][0], NB + 1, nullptr, 0, Ldiag, info, &M[0][0], NB + 1, n);  // M := inv(L)
+    if (lane == 64) { fc.prog[0] = 0; fc.prog[1] = 0; }
+    __syncthreads();
+    factor_diag_block(&M[0][0], NB + 1, 0, Ldiag, info, fc.ab, fc.l1, fc.prog, &M[0][0], NB + 1, n);  // M := inv(L)
+    __syncthreads();
+    if (lane >= 64) return;                  // the substitutions and the camera update are one wave's work
     if (lane < NB) ys[lane] = b;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     double acc = 0.0;
@@ -247,7 +339,7 @@ chol_small_kernel(const double *A, int ld, int n, double *Ldiag, double *x, int 
 __global__ __launch_bounds__(256) void
 chol_step_kernel(double *A, double *Lout, int ld, int nblk, int k, double *Ldiag, int *info, const LmDev *lm)
 {
-    if (lm && (lm->stop || lm->lin_failed)) return;
+    if (lm && (lm->stop || lm->lin_failed || lm->flow_aborted)) return;
     const int j = k + 1 + blockIdx.x;
     const int i = k + 1 + blockIdx.y;
     if (j > i || j >= nblk) return;
@@ -306,8 +398,11 @@ chol_step_kernel(double *A, double *Lout, int ld, int nblk, int k, double *Ldiag
         if (next_diag) Ai[r][c0 + c] = cur[c];
     }
     if (!next_diag) return;
+    __shared__ int prog[2];
+    if (tid == 0) { prog[0] = 0; prog[1] = 0; }
     __syncthreads();
-    if (tid < 64) factor_diag_block(&Ai[0][0], NB + 1, nullptr, k + 1, Ldiag, info);
+    // (Xi / Xj were last read in front of that barrier: they are the factor's scratch now)
+    if (tid < 128) factor_diag_block(&Ai[0][0], NB + 1, k + 1, Ldiag, info, &Xi[0][0], &Xj[0][0], prog);
 }
 
 
@@ -316,23 +411,30 @@ chol_step_kernel(double *A, double *Lout, int ld, int nblk, int k, double *Ldiag
 // as ONE launch of persistent workgroups that hand tiles to each other: the launch-per-
 // block-column form above spends 15.6 us per column of which 2.7 are the pivot chain.
 //
-// Every workgroup owns tiles of the lower triangle for the whole factorisation and keeps them
-// in registers (right-looking updates as the panels of earlier columns appear):
-//   D_r, r = 0 .. nblk: the last kFlowW + 1 tiles of block row r -- (r, r-kFlowW) .. (r, r) --,
-//        i.e. the diagonal tile and its left neighbours.  For a column k it owns it turns its
-//        tile into L_rk itself as soon as inv(L_kk) appears, applies it to its tiles right of k,
-//        and after the last column factors its diagonal tile and publishes inv(L_rr).
-//        D_nblk is the tail of the right-hand side row (no diagonal tile).
-//   P_(i,j), i - j > kFlowW (the right-hand side row i = nblk included): updates, then
-//        L_ij = tile * inv(L_jj)^T once that inverse appears.
+// Roles (all workgroups resident for the whole launch):
+//   D workgroups own block rows: D_w takes rows w, w + num_d, w + 2 num_d, ... one after the other (every
+//        system of BASELINE's configs has a D of its own per row; beyond ~80 rows they are shared, so that the
+//        grid fits the device whatever the size).  For its row r a D holds the last kFlowW + 1 tiles
+//        (r, r-kFlowW) .. (r, r) in registers -- the diagonal tile and its left neighbours -- and applies the
+//        panels of earlier columns as they appear (right-looking).  For a column k it owns it turns its tile
+//        into L_rk itself as soon as inv(L_kk) appears, applies it to its tiles right of k, and after the last
+//        column factors its diagonal tile and publishes inv(L_rr).  Row nblk is the tail of the right-hand side.
+//   P workgroups own the tiles (i, j), i - j > kFlowW (the right-hand side row i = nblk included): the
+//        column-major list of them is dealt round robin, P_w takes tiles w, w + num_p, ...  A tile is done
+//        left-looking, start to finish: all updates of the columns before j, then L_ij = tile * inv(L_jj)^T
+//        once that inverse appears.  (Round 3 gave every tile a workgroup of its own, which stopped at ~38
+//        block columns: the 500-view problem of BASELINE configs[4] has 78.)  A workgroup's tiles come in
+//        column order and every dependency of a tile lies in an earlier column (or is a D product of the row's
+//        own columns), so the earliest unfinished tile of the whole grid can always proceed: no cycle of waits.
+//        Catching up on the columns that were finished while the workgroup was busy elsewhere is what a tile
+//        mostly does, so it probes up to 16 steps ahead with one poll and fetches two steps per round.
 // Why the band: POTRF(j) -> TRSM(j+1, j) -> SYRK -> POTRF(j+1) is the critical path, and row
 // j+1 enters it with everything the columns before j did to it.  A tile handed from one
 // workgroup to another costs a round trip through memory (sc1 store, drain, flag, poll, sc1
-// load: ~5.5 us measured here, 2x the pivot chain of a block), so the hand-offs on that path
-// must be few and the others need slack: with the diagonal tile alone per workgroup the loop
-// inverse(j-1) -> P computes L(j+1, j-1) -> D_(j+1) updates paced the whole thing at 10 us per
-// column.  With the band, a P tile's result is needed kFlowW columns after the inverse it
-// waited for.
+// load: ~5.5 us measured here), so the hand-offs on that path must be few and the others need
+// slack: with the diagonal tile alone per workgroup the loop inverse(j-1) -> P computes
+// L(j+1, j-1) -> D_(j+1) updates paced the whole thing at 10 us per column.  With the band, a P
+// tile's result is needed kFlowW columns after the inverse it waited for.
 // The D workgroups talk to each other through their XCD's L2 where they can: the blocks with
 // blockIdx % 8 == 0 are the D's (observed placement: round robin over the XCDs -- speed only),
 // every payload is published twice -- plain stores into a mailbox + a flag that carries the
@@ -341,15 +443,20 @@ chol_step_kernel(double *A, double *Lout, int ld, int nblk, int k, double *Ldiag
 // own XCD (one L2: the plain stores are there once their vmcnt has drained; the reads bypass
 // L1).  Everybody else, and a D on another XCD, takes the sc1 copy as MI355X_MICROARCH.md
 // ("Valid forms") prescribes: every byte stored sc1 and loaded sc1, each storing wave drains
-// its stores before one lane stores the flag behind a workgroup barrier, one lane polls, the
-// others load behind the barrier it joins.  Flags hold the launch's epoch (no reset between
-// factorisations).  All workgroups must be resident (checked against the occupancy query,
-// else the launch-per-column form runs); a poll that outlasts kFlowSpinLimit raises the abort
-// word, which every poll loop watches, and the factorisation is reported as failed (info)
-// instead of hanging the device.
+// its stores before one lane stores the flag behind a workgroup barrier, the lanes of ONE wave
+// poll, the others load behind the barrier it joins.  Flags hold the launch's epoch (no reset
+// between factorisations).  All workgroups must be resident (the grid is sized by the occupancy
+// query with a margin); a poll that outlasts spin_limit raises the abort word, which every poll
+// loop watches: the launch drains, info carries kFlowAborted, and the CALLER repeats the
+// factorisation in the launch-per-column form (ba_api.hip) -- a scheduling condition, e.g. a
+// foreign kernel holding CUs, must not look like a matrix that is not positive definite.
 // ---------------------------------------------------------------------------
-constexpr int kFlowSpinLimit = 1 << 21;
+constexpr int kFlowSpinLimitDefault = 1 << 21;
 constexpr int kFlowW = 3;                 // left neighbours of the diagonal tile a D workgroup owns
+constexpr int kFlowMaxD = 56;             // D workgroups of a launch (one XCD holds 64 workgroups of this kernel)
+constexpr int kFlowMaxBlocks = 160;       // block columns the one-launch form takes (5120 unknowns)
+constexpr int kFlowTraceStride = 32;      // int64 stamps per block row of the diagnostic trace
+constexpr int kFlowProbe = 16;            // steps a P tile looks ahead with one poll
 
 struct CholFlow {
     const double *A;      // (N + 32) x N reduced system, rhs in row N
@@ -361,6 +468,9 @@ struct CholFlow {
     const LmDev *lm;
     double *x;            // solution of the reduced system (n entries used), written by the backward phase; null: factor only
     int ld, nblk, epoch;
+    int num_d, num_p;     // D / P workgroups of the launch
+    int num_tiles;        // P tiles
+    int spin_limit;
     long long *trace;     // diagnostics (tools/chol_flow_trace.py): [nblk + 1][16] wall_clock64 stamps of the D's, or null
 };
 
@@ -383,14 +493,22 @@ __device__ __forceinline__ void store_flag_plain(int *p, int v)
 }
 
 struct FlowWaiter {
-    int *lds_word;        // verdict: 0 aborted, 1 sc1 copy, 2 mailbox copy
+    int *how;             // LDS, 2 x 8 words: verdict of lane l's payload -- 0 aborted, 1 sc1 copy, 2 mailbox copy.  Two sets, used
+                          // alternately: a wave may still be reading the verdicts of one wait while wave 0 writes those of the next
+                          // (every wait holds a barrier, so nobody lags two waits behind)
+    int *word;            // LDS, one word (probe results)
+    int *prog;            // LDS, two words, zero between uses: progress of the diagonal factor's waves
+    int phase;            // verdict set of the most recent wait
     int pending_flag;     // sc1 flag to store once this workgroup's sc1 stores have drained (-1: none)
 };
+__device__ __forceinline__ int flow_how(const FlowWaiter &w, int lane) { return w.how[w.phase * 8 + lane]; }
 
-// Waits until the payload behind (slow_flag) or -- D to D only -- (box_flag) is published.
-// One lane polls; every thread drains its own stores first (a pending sc1 publication of this
-// workgroup becomes visible here, for free: the waves would idle at the barrier anyway).
-__device__ __forceinline__ int flow_wait(const CholFlow &f, FlowWaiter &w, int slow_flag, int box_flag)
+// Waits until every payload that a lane of wave 0 names is published: (slow_flag) the sc1 copy, or -- D to D
+// only -- (box_flag) the mailbox copy where the producer shares this workgroup's L2.  slow_flag < 0: the lane
+// names nothing.  All threads call it; the arguments of the threads beyond wave 0 are ignored.  Every thread
+// drains its own stores first (a pending sc1 publication of this workgroup becomes visible here, for free:
+// the waves would idle at the barrier anyway).  Returns false when the launch was aborted.
+__device__ __forceinline__ bool flow_wait_lanes(const CholFlow &f, FlowWaiter &w, int slow_flag, int box_flag)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (w.pending_flag >= 0) {
@@ -398,32 +516,46 @@ __device__ __forceinline__ int flow_wait(const CholFlow &f, FlowWaiter &w, int s
         if (threadIdx.x == 0) __hip_atomic_store(f.flags + w.pending_flag, f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         w.pending_flag = -1;
     }
-    if (threadIdx.x == 0) {
-        int verdict = 0;
-        const int *ps = f.flags + slow_flag, *pb = f.flags + (box_flag >= 0 ? box_flag : slow_flag), *pab = f.flags + flow_abort_flag(f);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int verdict = slow_flag < 0 ? 1 : 0;
+        bool ok = true;
+        const int *ps = f.flags + max(slow_flag, 0), *pb = f.flags + max(box_flag, 0), *pab = f.flags + flow_abort_flag(f);
         const int want_box = f.epoch | ((flow_xcc() + 1) << 24);
         for (int spins = 0;; ++spins) {
-            if (box_flag >= 0 && __hip_atomic_load(pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want_box) { verdict = 2; break; }
-            if (__hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f.epoch) { verdict = 1; break; }
-            if ((spins & 15) == 15 && __hip_atomic_load(pab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f.epoch) break;
-            if (spins > kFlowSpinLimit) {
-                __hip_atomic_store(f.flags + flow_abort_flag(f), f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!verdict) {
+                if (box_flag >= 0 && __hip_atomic_load(pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want_box) verdict = 2;
+                else if (__hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f.epoch) verdict = 1;
+            }
+            if (__ballot(verdict == 0) == 0) break;
+            if ((spins & 15) == 15 && __hip_atomic_load(pab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f.epoch) { ok = false; break; }
+            if (spins > f.spin_limit) {
+                if (lane == 0) __hip_atomic_store(f.flags + flow_abort_flag(f), f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
         }
-        if (!verdict) atomicMax(f.info, 1 << 20);      // reported as a failed factorisation
-        *w.lds_word = verdict;
+        if (!ok && lane == 0) atomicMax(f.info, kFlowAborted);      // the caller repeats the factorisation launch by launch
+        if (lane < 8) w.how[(w.phase ^ 1) * 8 + lane] = ok ? verdict : 0;
     }
+    w.phase ^= 1;
     lds_barrier();
-    return *w.lds_word;
+    return flow_how(w, 0) != 0;
+}
+
+// one payload, named by every thread alike; returns its verdict (0 aborted, 1 sc1 copy, 2 mailbox copy)
+__device__ __forceinline__ int flow_wait(const CholFlow &f, FlowWaiter &w, int slow_flag, int box_flag)
+{
+    const bool first = threadIdx.x == 0;
+    flow_wait_lanes(f, w, first ? slow_flag : -1, first ? box_flag : -1);
+    return flow_how(w, 0);
 }
 
 // Thread <-> tile element map of the flow kernel: the accumulator layout of
 // v_mfma_f64_16x16x4_f64 (cdna_hip_programming.md: col = lane & 15, row = (lane >> 4) + 4 * reg),
 // wave w holding the 16 x 16 quadrant (w >> 1, w & 1) of the 32 x 32 tile: element e of a thread
 // is (tr0 + 4 e, tc).
-typedef double v4d __attribute__((ext_vector_type(4)));
 struct FlowPos { int tr0, tc, ar, ak; };    // ar / ak: row inside a quadrant and k offset of the MFMA A / B operand
 __device__ __forceinline__ FlowPos flow_pos()
 {
@@ -435,14 +567,24 @@ __device__ __forceinline__ FlowPos flow_pos()
     return p;
 }
 
-// a published 32 x 32 tile (row-major, leading dimension ld) into LDS; sc1 loads (L1 bypass)
+// a published 32 x 32 tile (row-major, leading dimension ld): sc1 loads (L1 bypass) into registers, then into LDS --
+// in two steps so that a caller can have the loads of several tiles in flight before the first LDS write waits
+struct FlowTile { double v[4]; };
+__device__ __forceinline__ FlowTile flow_fetch_tile(const double *G, int ld, const FlowPos &p)
+{
+    FlowTile t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t.v[e] = load_sc1(G + (size_t)(p.tr0 + 4 * e) * ld + p.tc);
+    return t;
+}
+__device__ __forceinline__ void flow_put_tile(const FlowTile &t, double (*dst)[NB + 1], const FlowPos &p)
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dst[p.tr0 + 4 * e][p.tc] = t.v[e];
+}
 __device__ __forceinline__ void flow_load_tile(const double *G, int ld, double (*dst)[NB + 1], const FlowPos &p)
 {
-    double v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = load_sc1(G + (size_t)(p.tr0 + 4 * e) * ld + p.tc);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) dst[p.tr0 + 4 * e][p.tc] = v[e];
+    flow_put_tile(flow_fetch_tile(G, ld, p), dst, p);
 }
 
 // acc (+/-)= X Y^T on the matrix cores: D[i][j] += sum_m X[i][m] Y[j][m], eight k-steps of four.
@@ -464,74 +606,83 @@ __device__ __forceinline__ void flow_mma(double (&acc)[4], const double (*X)[NB 
     for (int e = 0; e < 4; ++e) acc[e] = c[e];
 }
 
-__global__ __launch_bounds__(256, 3) void       // three workgroups per CU: the whole grid has to be resident
-chol_flow_kernel(CholFlow f)
-{
-    if (f.lm && (f.lm->stop || f.lm->lin_failed)) return;
-    __shared__ __attribute__((aligned(16))) double Xr[NB][NB + 1];
-    __shared__ __attribute__((aligned(16))) double Xc[NB][NB + 1];
-    __shared__ __attribute__((aligned(16))) double Li[NB][NB + 1];
-    __shared__ __attribute__((aligned(16))) double Mt[NB][NB + 1];
-    __shared__ int lds_word;
-    __shared__ double sv[NB], xv[NB];
-    const int nblk = f.nblk, ld = f.ld;
-    const int tid = threadIdx.x;
-    const FlowPos p = flow_pos();
-    FlowWaiter w;
-    w.lds_word = &lds_word; w.pending_flag = -1;
+typedef double (*FlowLds)[NB + 1];
 
-    // workgroup -> role: blocks 0, 8, 16, ... are D_0, D_1, ... (one XCD under round-robin placement);
-    // the others take the P tiles, column by column
-    const int b = blockIdx.x;
-    const bool is_d = (b & 7) == 0 && (b >> 3) <= nblk;
-    if (!is_d) {
-        // ---- P_(i,j), i - j > kFlowW -------------------------------------------------
-        int idx = b - min((b + 7) >> 3, nblk + 1);          // P index: blocks below b that are not D's
-        int j = 0;
-        // column j holds rows j + kFlowW + 1 .. nblk: nblk - j - kFlowW tiles
-        while (j < nblk && idx >= nblk - j - kFlowW) { idx -= max(nblk - j - kFlowW, 0); ++j; }
-        if (j >= nblk || nblk - j - kFlowW <= 0) return;    // surplus block of the grid
-        const int i = j + kFlowW + 1 + idx;
-        double acc[4];
-        const double *Aij = f.A + (size_t)(i * NB) * ld + j * NB;
+// One P tile (i, j), i - j > kFlowW, start to finish.  Returns false when the launch was aborted.
+__device__ __forceinline__ bool
+flow_p_tile(const CholFlow &f, FlowWaiter &w, const FlowPos &p, int i, int j, FlowLds Xr, FlowLds Xc, FlowLds Li, FlowLds Mt)
+{
+    const int ld = f.ld, tid = threadIdx.x;
+    double acc[4];
+    const double *Aij = f.A + (size_t)(i * NB) * ld + j * NB;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = Aij[(size_t)(p.tr0 + 4 * e) * ld + p.tc];
-        for (int k = 0; k < j; ++k) {
-            if (!flow_wait(f, w, flow_tile_flag(f, i, k), -1)) return;
-            flow_load_tile(f.Lmat + (size_t)(i * NB) * ld + k * NB, ld, Xr, p);
-            if (!flow_wait(f, w, flow_tile_flag(f, j, k), -1)) return;
-            flow_load_tile(f.Lmat + (size_t)(j * NB) * ld + k * NB, ld, Xc, p);
+    for (int e = 0; e < 4; ++e) acc[e] = Aij[(size_t)(p.tr0 + 4 * e) * ld + p.tc];
+    int k = 0;
+    while (k < j) {
+        // how many of the steps k, k + 1, ... have both their operands -- L(i, .) and L(j, .) -- published already?
+        // (lane 2 m: tile (i, k + m), lane 2 m + 1: tile (j, k + m); one load per lane, no waiting)
+        if (tid < 64) {
+            const int m = tid >> 1, kk = k + m;
+            bool missing = false;
+            if (m < kFlowProbe && kk < j)
+                missing = __hip_atomic_load(f.flags + flow_tile_flag(f, (tid & 1) ? j : i, kk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != f.epoch;
+            const unsigned long long mm = __ballot(missing);
+            const int ready = mm ? (int)(__builtin_ctzll(mm) >> 1) : min(kFlowProbe, j - k);
+            if (tid == 0) *w.word = ready;
+        }
+        lds_barrier();
+        int ready = *w.word;
+        if (ready == 0) {
+            // the step the factorisation is at: wait for both operands (polled side by side)
+            if (!flow_wait_lanes(f, w, tid == 0 ? flow_tile_flag(f, i, k) : tid == 1 ? flow_tile_flag(f, j, k) : -1, -1)) return false;
+            ready = 1;
+        }
+        for (int m = 0; m < ready; m += 2) {
+            const bool two = m + 1 < ready;
+            const FlowTile t0 = flow_fetch_tile(f.Lmat + (size_t)(i * NB) * ld + (k + m) * NB, ld, p);
+            const FlowTile t1 = flow_fetch_tile(f.Lmat + (size_t)(j * NB) * ld + (k + m) * NB, ld, p);
+            if (two) {
+                const FlowTile t2 = flow_fetch_tile(f.Lmat + (size_t)(i * NB) * ld + (k + m + 1) * NB, ld, p);
+                const FlowTile t3 = flow_fetch_tile(f.Lmat + (size_t)(j * NB) * ld + (k + m + 1) * NB, ld, p);
+                flow_put_tile(t0, Xr, p); flow_put_tile(t1, Xc, p); flow_put_tile(t2, Li, p); flow_put_tile(t3, Mt, p);
+            } else {
+                flow_put_tile(t0, Xr, p); flow_put_tile(t1, Xc, p);
+            }
             lds_barrier();
             flow_mma<true>(acc, Xr, Xc, p);
+            if (two) flow_mma<true>(acc, Li, Mt, p);
+            lds_barrier();          // the buffers are rewritten by the next round
         }
-        if (!flow_wait(f, w, flow_inv_flag(f, j), -1)) return;
-        flow_load_tile(f.Ldiag + (size_t)j * NB * NB, NB, Li, p);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Mt[p.tr0 + 4 * e][p.tc] = acc[e];
-        lds_barrier();
-        // L_ij = tile * inv(L_jj)^T (inv(L) is lower triangular: zeros above the diagonal)
-        double x[4] = {0, 0, 0, 0};
-        flow_mma<false>(x, Mt, Li, p);
-        double *Lij = f.Lmat + (size_t)(i * NB) * ld + j * NB;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) store_sc1(Lij + (size_t)(p.tr0 + 4 * e) * ld + p.tc, x[e]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(f.flags + flow_tile_flag(f, i, j), f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
+        k += ready;
     }
+    if (!flow_wait(f, w, flow_inv_flag(f, j), -1)) return false;
+    flow_load_tile(f.Ldiag + (size_t)j * NB * NB, NB, Li, p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Mt[p.tr0 + 4 * e][p.tc] = acc[e];
+    lds_barrier();
+    // L_ij = tile * inv(L_jj)^T (inv(L) is lower triangular: zeros above the diagonal)
+    double x[4] = {0, 0, 0, 0};
+    flow_mma<false>(x, Mt, Li, p);
+    double *Lij = f.Lmat + (size_t)(i * NB) * ld + j * NB;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) store_sc1(Lij + (size_t)(p.tr0 + 4 * e) * ld + p.tc, x[e]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(f.flags + flow_tile_flag(f, i, j), f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
 
-    // ---- D_row ---------------------------------------------------------------------------
-    const int row = b >> 3;
+// Forward part of block row `row` by a D workgroup: updates, its own band of L, the factor of the diagonal tile
+// and inv(L_rr) published (which is left in Li for the backward phase).  Returns false when the launch was aborted.
+__device__ __forceinline__ bool
+flow_d_forward(const CholFlow &f, FlowWaiter &w, const FlowPos &p, int row, FlowLds Xr, FlowLds Xc, FlowLds Li, FlowLds Mt)
+{
+    const int nblk = f.nblk, ld = f.ld, tid = threadIdx.x;
     const bool has_diag = row < nblk;
     const int lo = max(0, row - kFlowW), hi = min(row, nblk - 1);     // own columns
     const int my_tag = f.epoch | ((flow_xcc() + 1) << 24);
-    auto stamp = [&](int slot) { if (f.trace && tid == 0) f.trace[row * 16 + slot] = (long long)wall_clock64(); };
+    auto stamp = [&](int slot) { if (f.trace && tid == 0) f.trace[row * kFlowTraceStride + slot] = (long long)wall_clock64(); };
     stamp(0);
-    // (A warm-up pass of the factor on an identity block -- one copy of the code, run twice -- was
-    //  measured and dropped: the instruction fetches are not what the factor waits for, 12k of its
-    //  14k cycles are the pivot loop itself warm or cold, and the loop form cost registers: 256
-    //  VGPRs + scratch, two workgroups per CU instead of three.)
     double acc[kFlowW + 1][4];
 #pragma unroll
     for (int t = 0; t <= kFlowW; ++t) {
@@ -544,15 +695,49 @@ chol_flow_kernel(CholFlow f)
             for (int e = 0; e < 4; ++e) acc[t][e] = At[(size_t)(p.tr0 + 4 * e) * ld + p.tc];
         }
     }
-    for (int k = 0; k < row; ++k) {
-        // ---- L(row, k) into Xr ----
-        if (k < lo) {
-            if (!flow_wait(f, w, flow_tile_flag(f, row, k), -1)) return;
-            flow_load_tile(f.Lmat + (size_t)(row * NB) * ld + k * NB, ld, Xr, p);
-        } else {
+    // ---- columns left of the band: L(row, k) is a P tile, L(c, k) of the own columns c != row a P tile or a
+    //      neighbour's band tile; all of a step's flags are polled side by side and its tiles fetched together ----
+    for (int k = 0; k < lo; ++k) {
+        int slow = -1, box = -1;
+        if (tid == 0) slow = flow_tile_flag(f, row, k);
+        else if (tid <= kFlowW) {
+            const int c = lo + (int)tid - 1;
+            if (c <= hi && c != row) {
+                slow = flow_tile_flag(f, c, k);
+                if (c - k <= kFlowW) box = flow_box_flag(f, c, c - k);
+            }
+        }
+        if (!flow_wait_lanes(f, w, slow, box)) return false;
+        const FlowTile tr = flow_fetch_tile(f.Lmat + (size_t)(row * NB) * ld + k * NB, ld, p);
+        FlowTile tc[kFlowW];
+#pragma unroll
+        for (int t = 0; t < kFlowW; ++t) {
+            const int c = lo + t;
+            if (c <= hi && c != row) {
+                if (flow_how(w, t + 1) == 2) tc[t] = flow_fetch_tile(flow_box(f, c, c - k), NB, p);
+                else tc[t] = flow_fetch_tile(f.Lmat + (size_t)(c * NB) * ld + k * NB, ld, p);
+            }
+        }
+        flow_put_tile(tr, Xr, p);
+#pragma unroll
+        for (int t = 0; t < kFlowW; ++t) {
+            const int c = lo + t;
+            if (c <= hi && c != row) flow_put_tile(tc[t], t == 0 ? Xc : t == 1 ? Li : Mt, p);
+        }
+        lds_barrier();
+#pragma unroll
+        for (int t = 0; t <= kFlowW; ++t) {
+            const int c = lo + t;
+            if (c <= hi) flow_mma<true>(acc[t], Xr, c == row ? Xr : t == 0 ? Xc : t == 1 ? Li : Mt, p);
+        }
+        lds_barrier();
+    }
+    // ---- the band: columns lo .. row - 1, the critical path ----
+    for (int k = lo; k < row; ++k) {
+        {
             const int how = flow_wait(f, w, flow_inv_flag(f, k), flow_box_flag(f, k, 0));
-            if (!how) return;
-            if (k == row - 1 && f.trace && tid == 0) f.trace[row * 16 + 7] = how;
+            if (!how) return false;
+            if (k == row - 1 && f.trace && tid == 0) f.trace[row * kFlowTraceStride + 7] = how;
             flow_load_tile(how == 2 ? flow_box(f, k, 0) : f.Ldiag + (size_t)k * NB * NB, NB, Li, p);
             // own tile of column k (register index is compile-time under the unrolled select)
             double t4[4] = {0, 0, 0, 0};
@@ -588,7 +773,7 @@ chol_flow_kernel(CholFlow f)
                 // L(c, k): a D's if c - k <= kFlowW, else a P tile
                 const bool from_d = c - k <= kFlowW;
                 const int how = flow_wait(f, w, flow_tile_flag(f, c, k), from_d ? flow_box_flag(f, c, c - k) : -1);
-                if (!how) return;
+                if (!how) return false;
                 if (how == 2) flow_load_tile(flow_box(f, c, c - k), NB, Xc, p);
                 else flow_load_tile(f.Lmat + (size_t)(c * NB) * ld + k * NB, ld, Xc, p);
                 lds_barrier();
@@ -611,15 +796,17 @@ chol_flow_kernel(CholFlow f)
         lds_barrier();
         stamp(4);
         const long long c_start = (long long)clock64();
-        if (tid < 64) {
-            // the critical path: the factor, then its inverse to the mailbox (D_(row+1) is polling)
-            factor_diag_block<false>(&Mt[0][0], NB + 1, nullptr, row, flow_box(f, row, 0), f.info, &Li[0][0], NB + 1, NB, true,
-                f.trace ? f.trace + row * 16 + 1 : nullptr);
-            if (f.trace && tid == 0) f.trace[row * 16 + 2] = (long long)clock64() - c_start;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (tid == 0) store_flag_plain(f.flags + flow_box_flag(f, row, 0), my_tag);
-            stamp(5);
-            if (f.trace && tid == 0) f.trace[row * 16 + 6] = (long long)clock64() - c_start;
+        if (tid < 128) {
+            // the critical path: the factor (two waves; Xr / Xc are its scratch), then its inverse to the mailbox
+            // (D_(row+1) is polling) -- stored by the second wave, which therefore drains and flags
+            factor_diag_block<false>(&Mt[0][0], NB + 1, row, flow_box(f, row, 0), f.info, &Xr[0][0], &Xc[0][0], w.prog, &Li[0][0], NB + 1, NB, true,
+                f.trace ? f.trace + row * kFlowTraceStride + 1 : nullptr);
+            if ((tid >> 6) == 1) {
+                if (f.trace && tid == 64) f.trace[row * kFlowTraceStride + 2] = (long long)clock64() - c_start;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (tid == 64) store_flag_plain(f.flags + flow_box_flag(f, row, 0), my_tag);
+                if (f.trace && tid == 64) { f.trace[row * kFlowTraceStride + 5] = (long long)wall_clock64(); f.trace[row * kFlowTraceStride + 6] = (long long)clock64() - c_start; }
+            }
         }
         lds_barrier();
         // the sc1 copy of the inverse for everybody else (Li holds it)
@@ -635,15 +822,25 @@ chol_flow_kernel(CholFlow f)
         if (has_diag) __hip_atomic_store(f.flags + flow_inv_flag(f, row), f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     w.pending_flag = -1;
-    if (!has_diag || f.x == nullptr) return;
+    return true;
+}
 
-    // ---- backward substitution, same launch: x_k = inv(L_kk)^T (y_k - sum_{i > k} L_ik^T x_i) ----------------
-    // D_k owns block k of the solution.  It still holds inv(L_kk) in LDS; y_k is row 0 of the right-hand side
-    // tile (nblk, k); the tiles L(i, k) of ITS column come in from i = nblk - 1 downwards, each fetched while
-    // the workgroup waits for x_i (two LDS buffers), so that a step costs the hand-off of 32 doubles and two
-    // 32 x 32 matrix-vector products -- the single-workgroup kernel it replaces walked the same chain at
-    // 3.7 us per step with a trip to L2 for every block row.
-    auto tile_into = [&](int i, double (*dst)[NB + 1]) -> bool {
+// Backward substitution for block `row` of the solution by the D workgroup that owns the row:
+// x_k = inv(L_kk)^T (y_k - sum_{i > k} L_ik^T x_i).  inv(L_kk) is in Li (li_resident) or fetched from the
+// workgroup's own sc1 copy; y_k is row 0 of the right-hand side tile (nblk, k); the tiles L(i, k) of ITS column
+// come in from i = nblk - 1 downwards, each fetched while the workgroup waits for x_i (two LDS buffers), so that
+// a step costs the hand-off of 32 doubles and two 32 x 32 matrix-vector products.
+__device__ __forceinline__ bool
+flow_d_backward(const CholFlow &f, FlowWaiter &w, const FlowPos &p, int row, bool li_resident, FlowLds Xr, FlowLds Xc, FlowLds Li,
+    double *sv, double *xv)
+{
+    const int nblk = f.nblk, ld = f.ld, tid = threadIdx.x;
+    const int my_tag = f.epoch | ((flow_xcc() + 1) << 24);
+    if (!li_resident) {
+        lds_barrier();
+        flow_load_tile(f.Ldiag + (size_t)row * NB * NB, NB, Li, p);
+    }
+    auto tile_into = [&](int i, FlowLds dst) -> bool {
         const bool from_d = i - row <= kFlowW;
         const int how = flow_wait(f, w, flow_tile_flag(f, i, row), from_d ? flow_box_flag(f, i, i - row) : -1);
         if (!how) return false;
@@ -654,16 +851,16 @@ chol_flow_kernel(CholFlow f)
     {
         const bool from_d = nblk - row <= kFlowW;
         const int how = flow_wait(f, w, flow_tile_flag(f, nblk, row), from_d ? flow_box_flag(f, nblk, nblk - row) : -1);
-        if (!how) return;
+        if (!how) return false;
         if (tid < NB) sv[tid] = load_sc1(how == 2 ? flow_box(f, nblk, nblk - row) + tid : f.Lmat + (size_t)(nblk * NB) * ld + row * NB + tid);
     }
     int cur = 0;
-    if (nblk - 1 > row && !tile_into(nblk - 1, Xr)) return;
+    if (nblk - 1 > row && !tile_into(nblk - 1, Xr)) return false;
     for (int i = nblk - 1; i > row; --i) {
-        double (*T)[NB + 1] = cur ? Xc : Xr;
-        if (i - 1 > row && !tile_into(i - 1, cur ? Xr : Xc)) return;
+        FlowLds T = cur ? Xc : Xr;
+        if (i - 1 > row && !tile_into(i - 1, cur ? Xr : Xc)) return false;
         const int how = flow_wait(f, w, flow_x_flag(f, i), flow_xbox_flag(f, i));
-        if (!how) return;
+        if (!how) return false;
         if (tid < NB) xv[tid] = load_sc1(how == 2 ? flow_xbox(f, i) + tid : f.x + (size_t)i * NB + tid);
         lds_barrier();
         if (tid < NB) {
@@ -688,40 +885,91 @@ chol_flow_kernel(CholFlow f)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) __hip_atomic_store(f.flags + flow_x_flag(f, row), f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    return true;
+}
+
+// Two workgroups per CU (256 registers per lane): at three (168) the kernel spilled -- into scratch memory inside the
+// diagonal factor, of all places -- and since a workgroup works through a list of tiles the grid no longer needs the room.
+__global__ __launch_bounds__(256, 2) void
+chol_flow_kernel(CholFlow f)
+{
+    if (f.lm && (f.lm->stop || f.lm->lin_failed || f.lm->flow_aborted)) return;
+    __shared__ __attribute__((aligned(16))) double Xr[NB][NB + 1];
+    __shared__ __attribute__((aligned(16))) double Xc[NB][NB + 1];
+    __shared__ __attribute__((aligned(16))) double Li[NB][NB + 1];
+    __shared__ __attribute__((aligned(16))) double Mt[NB][NB + 1];
+    __shared__ int lds_how[16];
+    __shared__ int lds_word;
+    __shared__ int lds_prog[2];
+    __shared__ double sv[NB], xv[NB];
+    const int nblk = f.nblk;
+    const FlowPos p = flow_pos();
+    FlowWaiter w;
+    w.how = lds_how; w.word = &lds_word; w.prog = lds_prog; w.phase = 0; w.pending_flag = -1;
+    if (threadIdx.x == 0) { lds_prog[0] = 0; lds_prog[1] = 0; }     // (a barrier stands between this and every use)
+
+    // workgroup -> role: blocks 0, 8, 16, ... are the D's (one XCD under round-robin placement), the others the P's
+    const int b = blockIdx.x;
+    const bool is_d = (b & 7) == 0 && (b >> 3) < f.num_d;
+    if (!is_d) {
+        const int pidx = b - min((b + 7) >> 3, f.num_d);          // blocks below b that are not D's
+        // column j of the list holds rows j + kFlowW + 1 .. nblk: nblk - kFlowW - j tiles
+        int j = 0, base = 0;
+        for (int t = pidx; t < f.num_tiles; t += f.num_p) {
+            while (t - base >= nblk - kFlowW - j) { base += nblk - kFlowW - j; ++j; }
+            if (!flow_p_tile(f, w, p, j + kFlowW + 1 + (t - base), j, Xr, Xc, Li, Mt)) return;
+            lds_barrier();
+        }
+        return;
+    }
+    const int d = b >> 3;
+    int last = -1;
+    for (int row = d; row <= nblk; row += f.num_d) {
+        if (!flow_d_forward(f, w, p, row, Xr, Xc, Li, Mt)) return;
+        last = row;
+        lds_barrier();
+    }
+    if (f.x == nullptr) return;
+    for (int row = last; row >= 0; row -= f.num_d) {
+        if (row >= nblk) continue;                                  // the right-hand side's row has no unknowns
+        if (!flow_d_backward(f, w, p, row, row == last, Xr, Xc, Li, sv, xv)) return;
+    }
 }
 
 // diagnostics: where the D workgroups of the most recent factorisation spent their time
 static long long *g_flow_trace = nullptr;
+constexpr size_t kFlowTraceBytes = (size_t)(kFlowMaxBlocks + 1) * kFlowTraceStride * 8;
 long long *chol_flow_trace_buffer(int enable)
 {
-    if (enable && !g_flow_trace) { if (hipMalloc(reinterpret_cast<void **>(&g_flow_trace), 65 * 16 * 8) != hipSuccess) g_flow_trace = nullptr; else (void)hipMemset(g_flow_trace, 0, 65 * 16 * 8); }
+    if (enable && !g_flow_trace) { if (hipMalloc(reinterpret_cast<void **>(&g_flow_trace), kFlowTraceBytes) != hipSuccess) g_flow_trace = nullptr; else (void)hipMemset(g_flow_trace, 0, kFlowTraceBytes); }
     if (!enable && g_flow_trace) { (void)hipFree(g_flow_trace); g_flow_trace = nullptr; }
     return g_flow_trace;
 }
+
+// test hook (osfm_ba_debug_flow_spin_limit): polls a wait makes before it gives the launch up; <= 0: the default
+static std::atomic<int> g_flow_spin_limit{kFlowSpinLimitDefault};
+void chol_flow_set_spin_limit(int limit) { g_flow_spin_limit.store(limit > 0 ? limit : kFlowSpinLimitDefault); }
 
 // residency check of the flow kernel, per device: workgroups that can be resident at once
 int chol_flow_capacity()
 {
     static int cap[64];
-    static bool known[64];
+    static std::once_flag once[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    if (!known[dev]) {
+    std::call_once(once[dev], [dev]() {
         int per_cu = 0;
         hipDeviceProp_t prop;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chol_flow_kernel, 256, 0) != hipSuccess ||
-            hipGetDeviceProperties(&prop, dev) != hipSuccess) { cap[dev] = 0; }
-        else {
-            // The query can promise one block per CU more than the hardware admits when the SGPR
-            // count is what limits (MI355X_MICROARCH.md, residency: 7-8 blocks per CU); this kernel
-            // is bound by its 164 VGPRs (3 per CU), far from that.  A workgroup that is not resident
-            // would be a hang, so: two fewer per CU where the answer is in the doubtful range, and a
-            // tenth of the chip left free on top.
-            if (per_cu >= 6) per_cu -= 2;
-            cap[dev] = (int)(0.9 * per_cu * prop.multiProcessorCount);
-        }
-        known[dev] = true;
-    }
+            hipGetDeviceProperties(&prop, dev) != hipSuccess) { cap[dev] = 0; return; }
+        // The query can promise one block per CU more than the hardware admits when the SGPR
+        // count is what limits (MI355X_MICROARCH.md, residency: 7-8 blocks per CU); this kernel
+        // is bound by its VGPRs and LDS (3-4 per CU), far from that.  A workgroup that is not resident
+        // would be a hang, so: two fewer per CU where the answer is in the doubtful range, and a
+        // tenth of the chip left free on top.
+        if (per_cu >= 6) per_cu -= 2;
+        cap[dev] = (int)(0.9 * per_cu * prop.multiProcessorCount);
+    });
     return cap[dev];
 }
 
@@ -742,7 +990,7 @@ size_t chol_flow_mailbox_bytes(int n)
 __global__ __launch_bounds__(64) void
 chol_rhs_tail_kernel(const double *A, double *Lout, int ld, int nblk, const double *Ldiag, const LmDev *lm)
 {
-    if (lm && (lm->stop || lm->lin_failed)) return;
+    if (lm && (lm->stop || lm->lin_failed || lm->flow_aborted)) return;
     const int k = nblk - 1, c = threadIdx.x;
     if (c >= NB) return;
     const double *y = A + (size_t)(nblk * NB) * ld + k * NB;
@@ -767,7 +1015,7 @@ chol_rhs_tail_kernel(const double *A, double *Lout, int ld, int nblk, const doub
 __global__ __launch_bounds__(1024) void
 chol_backsolve_kernel(const double *A, int ld, int nblk, int n, const double *Ldiag, double *x, const LmDev *lm)
 {
-    if (lm && (lm->stop || lm->lin_failed)) return;
+    if (lm && (lm->stop || lm->lin_failed || lm->flow_aborted)) return;
     extern __shared__ double ys[];           // y [N], then x [N]
     __shared__ double xk[NB];
     __shared__ double Li[NB][NB];            // inv(L_kk), row-major
@@ -818,36 +1066,47 @@ int cholesky_padded_dim(int n) { return (n + NB - 1) / NB * NB; }
 void launch_small_solve(const double *A, int n, double *Ldiag, double *x, int *info, const BaDev &d,
     double *partials_cam, hipStream_t s)
 {
-    hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(64), 0, s, A, NB, n, Ldiag, x, info, d, partials_cam);
+    hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(128), 0, s, A, NB, n, Ldiag, x, info, d, partials_cam);
 }
 
 // A: (N + 32) x N row-major, rows/cols >= n padded with identity, rhs in row N.
 // Ldiag: N * 32 doubles of scratch for the inverses of the factored diagonal blocks.
-void launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double *x, int *info, const LmDev *lm, hipStream_t s,
+// Returns the form that was launched: 1 the one-launch flow form, 0 launch per block column.
+int launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double *x, int *info, const LmDev *lm, hipStream_t s,
     int *flow_flags, int flow_epoch, double *flow_mailbox)
 {
     const int N = cholesky_padded_dim(n);
     const int nblk = N / NB;
-    // the D's sit at the blocks 0, 8, 16, ...; the P tiles (rows more than kFlowW below the diagonal, the
-    // right-hand side row included) fill the blocks between and behind them
-    int num_p = 0;
-    for (int j = 0; j < nblk; ++j) num_p += std::max(nblk - j - kFlowW, 0);
-    int flow_groups = 8 * nblk + 1;                                   // through D_nblk at block 8 * nblk
-    {
-        const int between = 7 * nblk;                                   // non-D blocks below 8 * nblk
-        if (num_p > between) flow_groups += num_p - between;
-    }
-    if (flow_flags && flow_mailbox && nblk >= 2 && nblk <= 64 && flow_groups <= chol_flow_capacity()) {
+    // The D's sit at the blocks 0, 8, 16, ...; the P workgroups fill the blocks between and behind them.  One P
+    // workgroup per tile (rows more than kFlowW below the diagonal, the right-hand side row included) while that
+    // fits the device, else the tiles are dealt round robin to as many as do fit.
+    int num_tiles = 0;
+    for (int j = 0; j < nblk; ++j) num_tiles += std::max(nblk - kFlowW - j, 0);
+    static const int exp_max_d = getenv("OSFM_FLOW_MAX_D") ? atoi(getenv("OSFM_FLOW_MAX_D")) : kFlowMaxD;
+    static const int exp_max_groups = getenv("OSFM_FLOW_MAX_GROUPS") ? atoi(getenv("OSFM_FLOW_MAX_GROUPS")) : 1 << 30;
+    const int num_d = std::min(nblk + 1, exp_max_d);
+    const int d_span = 8 * (num_d - 1) + 1;                              // through the last D
+    auto d_below = [&](int g) { return std::min((g + 7) >> 3, num_d); };  // D blocks among the first g
+    int groups = d_span;
+    while (groups - d_below(groups) < num_tiles) ++groups;
+    const int cap = flow_flags && flow_mailbox ? chol_flow_capacity() : 0;
+    groups = std::min(std::min(groups, cap), std::max(exp_max_groups, d_span + 1));
+    const int num_p = groups - d_below(groups);
+    if (flow_flags && flow_mailbox && nblk >= 2 && nblk <= kFlowMaxBlocks && groups >= d_span && (num_tiles == 0 || num_p >= 1)) {
         CholFlow f;
         f.mailbox = flow_mailbox;
         f.A = A; f.Lmat = Lmat; f.Ldiag = Ldiag; f.flags = flow_flags; f.info = info; f.lm = lm;
         f.ld = N; f.nblk = nblk; f.epoch = flow_epoch; f.trace = g_flow_trace;
+        f.num_d = num_d; f.num_p = std::max(num_p, 1); f.num_tiles = num_tiles;
+        f.spin_limit = g_flow_spin_limit.load();
         // the backward substitution runs inside the same launch; x has room for the padded system (N entries)
         f.x = getenv("OSFM_BA_FLOW_FACTOR_ONLY") ? nullptr : x;
         {
             // Two of these launches must never share the device: each needs ALL its workgroups resident, and two
             // half-resident grids would wait for each other until the spin limit fails both.  Solves on different
             // streams (host threads) are therefore chained on the device: a launch waits for the previous one's event.
+            // (Launches of OTHER processes, or a foreign kernel that holds CUs for long, are not covered: the spin
+            //  limit turns that into an aborted launch, which the caller repeats in the launch-per-column form.)
             static std::mutex flow_mu[64];
             static hipEvent_t flow_ev[64];
             int dev = 0;
@@ -856,15 +1115,15 @@ void launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double
             std::lock_guard<std::mutex> lock(flow_mu[dev]);
             if (flow_ev[dev]) (void)hipStreamWaitEvent(s, flow_ev[dev], 0);
             else (void)hipEventCreateWithFlags(&flow_ev[dev], hipEventDisableTiming);
-            hipLaunchKernelGGL(chol_flow_kernel, dim3(flow_groups), dim3(256), 0, s, f);
+            hipLaunchKernelGGL(chol_flow_kernel, dim3(groups), dim3(256), 0, s, f);
             if (flow_ev[dev]) (void)hipEventRecord(flow_ev[dev], s);
         }
         if (!f.x)
             hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(1024), (size_t)2 * N * sizeof(double), s, Lmat, N,
                 nblk, n, Ldiag, x, lm);
-        return;
+        return 1;
     }
-    hipLaunchKernelGGL(chol_first_kernel, dim3(1), dim3(64), 0, s, A, N, Ldiag, info, lm);
+    hipLaunchKernelGGL(chol_first_kernel, dim3(1), dim3(128), 0, s, A, N, Ldiag, info, lm);
     for (int k = 0; k < nblk; ++k) {
         // tiles (i, j), k < j <= i <= nblk, j < nblk: for k = nblk - 1 only the right-hand-side
         // row is left, and it has no tile with j < nblk: its forward substitution is the
@@ -876,6 +1135,7 @@ void launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double
     hipLaunchKernelGGL(chol_rhs_tail_kernel, dim3(1), dim3(64), 0, s, A, Lmat, N, nblk, Ldiag, lm);
     hipLaunchKernelGGL(chol_backsolve_kernel, dim3(1), dim3(1024), (size_t)2 * N * sizeof(double), s, Lmat, N,
         nblk, n, Ldiag, x, lm);
+    return 0;
 }
 
 }  // namespace osfm

@@ -33,6 +33,8 @@ struct LmDev {
     int32_t iteration, term, stop;
     int32_t num_success, num_unsuccess, invalid_steps, last_successful;
     int32_t update_diag, want_gradient, lin_failed, nonfinite;
+    int32_t flow_aborted;        // the one-launch Cholesky gave its launch up: nothing is decided until the host has repeated it
+    int32_t pad0;
 };
 
 struct BaDev {
@@ -74,7 +76,7 @@ __device__ __forceinline__ double load_sc1(const double *p)
 __device__ __forceinline__ bool lm_resolve(BaDev &d)
 {
     if (!d.lm) return true;
-    if (d.lm->stop) return false;
+    if (d.lm->stop || d.lm->flow_aborted) return false;
     // selects, not d.cams2[cur]: a kernel argument indexed with a run-time value is copied to scratch
     // memory as a whole (184 bytes per lane), and every field read after that comes from there
     const int cur = d.lm->cur;

@@ -100,6 +100,7 @@ struct LmScratch {
 // host_out (may be null): page-locked host slot that receives the state the kernel leaves
 void launch_lm_decide(LmDev *lm, const LmParams &prm, const LmScratch &sc, LmDev *host_out, hipStream_t s);
 void launch_lm_post(LmDev *lm, const LmParams &prm, const LmScratch &sc, int initial, LmDev *host_out, hipStream_t s);
+void launch_lm_clear_abort(LmDev *lm, hipStream_t s);
 
 void launch_point_pass(const BaDev &d, const PointPassArgs &a, int blocks, hipStream_t s);
 void launch_pair_pass(const BaDev &d, const PairPassArgs &a, hipStream_t s);
@@ -140,8 +141,12 @@ int cholesky_padded_dim(int n);
 // reduced system's trailing updates)
 // flow_flags (may be null: launch-per-column form): chol_flow_flag_count(n) ints, zeroed ONCE; flow_epoch: a
 // value > 0 that differs from every earlier call on the same flags (the hand-off flags of the one-launch form)
-void launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double *x, int *info, const LmDev *lm, hipStream_t s,
+// Returns 1 when the one-launch form ran, 0 for the launch-per-column form.  The one-launch form reports a launch it
+// had to give up (a wait that outlasted its spin limit: not all workgroups were resident) as info >= kFlowAborted.
+constexpr int kFlowAborted = 1 << 20;
+int launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double *x, int *info, const LmDev *lm, hipStream_t s,
     int *flow_flags = nullptr, int flow_epoch = 0, double *flow_mailbox = nullptr);
+void chol_flow_set_spin_limit(int limit);   // test hook: polls before a wait gives the launch up (<= 0: default)
 int chol_flow_flag_count(int n);
 long long *chol_flow_trace_buffer(int enable);     // diagnostics, see osfm_ba_debug_chol_trace
 size_t chol_flow_mailbox_bytes(int n);     // flow_mailbox: scratch of that size (no initialisation needed)

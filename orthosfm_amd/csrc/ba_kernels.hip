@@ -647,7 +647,7 @@ ba_cost_pass_kernel(BaDev dg, const double *cams, const double *points, double *
     __shared__ double sh[4];
     if (dg.lm) {
         // LM solve: the cost of the CANDIDATE (the iterate buffer that is not current)
-        if (dg.lm->stop || dg.lm->lin_failed) return;
+        if (dg.lm->stop || dg.lm->lin_failed || dg.lm->flow_aborted) return;
         cams = dg.lm->cur ? dg.cams2[0] : dg.cams2[1]; points = dg.lm->cur ? dg.points2[0] : dg.points2[1];
     }
     const BaDev d = stage_cameras(dg, cam_lds, staged != 0, cams, nullptr);
@@ -811,7 +811,13 @@ __global__ __launch_bounds__(256) void
 ba_lm_decide_kernel(LmDev *lm, LmParams prm, LmScratch sc, LmDev *host_out)
 {
     __shared__ double sh[256];
-    if (lm->stop) { if (threadIdx.x == 0) publish_state(lm, host_out); return; }
+    if (lm->stop || lm->flow_aborted) { if (threadIdx.x == 0) publish_state(lm, host_out); return; }
+    if (*sc.chol_info >= kFlowAborted) {
+        // not a numerical failure: the factorisation's launch was given up (ba_cholesky.hip).  Nothing is decided;
+        // the host repeats the iteration in the launch-per-column form (osfm_ba_solve)
+        if (threadIdx.x == 0) { *sc.chol_info = 0; lm->flow_aborted = 1; publish_state(lm, host_out); }
+        return;
+    }
     const bool solved = !lm->lin_failed;
     double mcc = 0.0, sn = 0.0, xn = 0.0, cand = 0.0;
     if (solved) {
@@ -859,7 +865,7 @@ __global__ __launch_bounds__(256) void
 ba_lm_post_kernel(LmDev *lm, LmParams prm, LmScratch sc, int initial, LmDev *host_out)
 {
     __shared__ double sh[256];
-    if (lm->stop) { if (threadIdx.x == 0) publish_state(lm, host_out); return; }
+    if (lm->stop || lm->flow_aborted) { if (threadIdx.x == 0) publish_state(lm, host_out); return; }
     const double cost = strided_reduce(sc.partA, sc.blocksM, 1, false, sh);
     const double gp = strided_reduce(sc.partA + sc.blocksM, sc.blocksM, 1, true, sh);
     const double bad = strided_reduce(sc.partA + 2 * (size_t)sc.blocksM, sc.blocksM, 1, true, sh);
@@ -873,6 +879,9 @@ void launch_lm_decide(LmDev *lm, const LmParams &prm, const LmScratch &sc, LmDev
 {
     hipLaunchKernelGGL(ba_lm_decide_kernel, dim3(1), dim3(256), 0, s, lm, prm, sc, host_out);
 }
+
+__global__ void ba_lm_clear_abort_kernel(LmDev *lm) { lm->flow_aborted = 0; }
+void launch_lm_clear_abort(LmDev *lm, hipStream_t s) { hipLaunchKernelGGL(ba_lm_clear_abort_kernel, dim3(1), dim3(1), 0, s, lm); }
 
 void launch_lm_post(LmDev *lm, const LmParams &prm, const LmScratch &sc, int initial, LmDev *host_out, hipStream_t s)
 {

@@ -336,3 +336,64 @@ def test_concurrent_solves_share_the_device(ba):
         assert out[k] is not None
         assert out[k][0] == s0.num_iterations and out[k][1] == s0.final_cost and out[k][3] == s0.termination
         assert np.array_equal(out[k][2], ref.cam_params)
+
+
+def _solve_with_env(ba, sc, env=None):
+    import os
+    fp = ba.FlatProblem.from_scene(sc)
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        s = ba.solve(fp)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return s, fp
+
+
+@pytest.mark.parametrize("model,cams,pts", [(0, 61, 6000), (0, 200, 30000), (1, 500, 60000)])
+def test_one_launch_cholesky_equals_launch_per_column(ba, model, cams, pts):
+    """The same 300-, 995- and 2495-unknown reduced systems (60 / 199 free quaternion cameras, 499 Euler
+    cameras with every angle free: BASELINE configs[3] and configs[4]) solved with the one-launch Cholesky
+    (workgroups handing tiles to each other; 78 block columns share the workgroups of the device) and with
+    one launch per block column: same LM trajectory -- iteration / accept counts, termination -- and the
+    final cost to 1e-12 (the two forms round differently: matrix-core tile products against FMA chains)."""
+    sc = synth.make_ba_scene(model, cams, pts, config_id=41)
+    s1, fp1 = _solve_with_env(ba, sc)
+    s2, fp2 = _solve_with_env(ba, sc, {"OSFM_BA_CHOLESKY_STEPS": "1"})
+    assert s1.flow_fallbacks == 0 and s2.flow_fallbacks == 0
+    assert (s1.num_iterations, s1.num_successful_steps, s1.num_unsuccessful_steps, s1.termination) == \
+        (s2.num_iterations, s2.num_successful_steps, s2.num_unsuccessful_steps, s2.termination)
+    assert s1.num_iterations >= 3
+    assert abs(s1.final_cost - s2.final_cost) <= 1e-12 * s2.final_cost
+    assert np.abs(fp1.cam_params - fp2.cam_params).max() <= 1e-10
+    assert np.abs(fp1.points - fp2.points).max() <= 1e-9
+
+
+@pytest.mark.parametrize("cams,pts", [(12, 1500), (61, 6000)])
+def test_a_cholesky_launch_given_up_is_repeated_launch_by_launch(ba, cams, pts):
+    """A wait of the one-launch Cholesky that outlasts its spin limit (its workgroups were not all resident:
+    another process or a long foreign kernel on the device) gives the launch up.  That is a scheduling
+    condition, not a matrix that is not positive definite: the solve repeats the factorisation in the
+    launch-per-column form, keeps that form, counts it -- and lands on the bits of a launch-per-column solve.
+    The test hook makes every wait that is not satisfied at once give up (12 cameras: the host runs an
+    iteration ahead of the device's decisions; 61: it reads every decision)."""
+    from orthosfm_amd import capi
+    sc = synth.make_ba_scene(0, cams, pts, config_id=42)
+    s_ref, fp_ref = _solve_with_env(ba, sc, {"OSFM_BA_CHOLESKY_STEPS": "1"})
+    capi.check(capi.lib.osfm_ba_debug_flow_spin_limit(1))
+    try:
+        s, fp = _solve_with_env(ba, sc)
+    finally:
+        capi.check(capi.lib.osfm_ba_debug_flow_spin_limit(0))
+    assert s.flow_fallbacks == 1
+    assert (s.num_iterations, s.num_successful_steps, s.num_unsuccessful_steps, s.termination) == \
+        (s_ref.num_iterations, s_ref.num_successful_steps, s_ref.num_unsuccessful_steps, s_ref.termination)
+    assert s.final_cost == s_ref.final_cost
+    assert np.array_equal(fp.cam_params, fp_ref.cam_params) and np.array_equal(fp.points, fp_ref.points)
+    # and the next solve is back on the one-launch form
+    s2, _ = _solve_with_env(ba, sc)
+    assert s2.flow_fallbacks == 0 and s2.num_iterations == s_ref.num_iterations
