@@ -382,16 +382,31 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
         return OSFM_OK;
     };
     int n_lin = 0;
+    // The LM control rides in the tails of the passes (the last workgroup of the back pass decides, the last one of
+    // the pair pass finalises the iteration): two launches of one workgroup less per iteration; and while the camera
+    // tables with the candidates fit LDS the back pass also makes the candidate cameras and evaluates the
+    // candidate's cost -- two more launches and a pass over the observations less.
+    DevArray tickets;
+    OSFM_RETURN_IF(tickets.alloc(2 * lm_ticket_bytes()));
+    OSFM_HIP_CHECK(hipMemsetAsync(tickets.ptr, 0, 2 * lm_ticket_bytes(), s));
+    const bool post_fused = num_pairs > 0 && getenv("OSFM_BA_SEPARATE_POST") == nullptr;
+    enum { kPostNone = 0, kPostInitial = 1, kPostLoop = 2 };
 
-    auto linearize = [&](bool reset) -> int {
+    auto linearize = [&](bool reset, int post, LmDev *host_out) -> int {
         pa.mode = kPassNormal; qa.mode = kPassNormal;
         OSFM_RETURN_IF(tic(0));
         launch_point_pass(d, pa, blocksM, s);
         OSFM_RETURN_IF(toc());
         if (reset) launch_reset_system(S.as<double>(), s_elems, N, nc, N, s);
+        memset(&qa.post, 0, sizeof(qa.post));
+        if (post != kPostNone && post_fused) {
+            qa.post.lm = lm; qa.post.prm = prm; qa.post.sc = sc; qa.post.host_out = host_out;
+            qa.post.ticket = tickets.as<int32_t>() + lm_ticket_bytes() / 4; qa.post.initial = post == kPostInitial; qa.post.enabled = 1;
+        }
         OSFM_RETURN_IF(tic(1));
         launch_pair_pass(d, qa, s);
         OSFM_RETURN_IF(toc());
+        if (post != kPostNone && !post_fused) launch_lm_post(lm, prm, sc, post == kPostInitial, host_out, s);
         n_lin++;
         return OSFM_OK;
     };
@@ -405,9 +420,9 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
         OSFM_HIP_CHECK(hipGetLastError());
     }
     d.lm = lm;
+    const bool fused = back_pass_can_fuse(d) && getenv("OSFM_BA_SEPARATE_BACK") == nullptr;
     lap("alloc + lists up");
-    OSFM_RETURN_IF(linearize(true));
-    launch_lm_post(lm, prm, sc, 1, nullptr, s);
+    OSFM_RETURN_IF(linearize(true, kPostInitial, nullptr));
     OSFM_HIP_CHECK(hipGetLastError());
     lap("first linearize");
     const auto t_loop = std::chrono::steady_clock::now();
@@ -417,7 +432,7 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     // what it knows and pays one row of do-nothing kernels at the end.  Large ones are bound
     // by the device: there the host waits for the decision of iteration i (it has the
     // linearisation of i still queued behind it, so the device does not idle) and never
-    // enqueues the 30+ Cholesky launches of an iteration that will not happen.
+    // enqueues the Cholesky of an iteration that will not happen.
     const bool eager = N / 32 <= 4;
     LmDev fin;
     memset(&fin, 0, sizeof(fin));
@@ -426,23 +441,34 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     for (int it = 0; it < max_slots - 2; ++it) {
         const int slot = it + 1;          // h_state[slot]: the state this iteration leaves
         OSFM_RETURN_IF(tic(2));
+        // the launch-per-column form works in place: the system has to be cleared before it is accumulated again
+        // (the one-launch form only reads it, and the pair pass overwrites every block it owns)
+        bool consumed = false;
         if (small) launch_small_solve(S.as<double>(), nc, Ldiag.as<double>(), y_c.as<double>(), info.as<int>(), d, part_cam.as<double>(), s);
-        else if (nc > 0) launch_cholesky_solve(S.as<double>(), Lmat.as<double>(), nc, Ldiag.as<double>(), y_c.as<double>(), info.as<int>(), lm, s,
-            flow_now ? flow_flags.as<int>() : nullptr, ++flow_epoch, flow_now ? flow_mailbox.as<double>() : nullptr);
+        else if (nc > 0) consumed = launch_cholesky_solve(S.as<double>(), Lmat.as<double>(), nc, Ldiag.as<double>(), y_c.as<double>(), info.as<int>(), lm, s,
+            flow_now ? flow_flags.as<int>() : nullptr, ++flow_epoch, flow_now ? flow_mailbox.as<double>() : nullptr) == 0;
         OSFM_RETURN_IF(toc());
         OSFM_RETURN_IF(tic(3));
-        if (!small) launch_cam_update(d, y_c.as<double>(), nullptr, part_cam.as<double>(), s);
         BackPassArgs ba;
+        memset(&ba, 0, sizeof(ba));
         ba.y_c = y_c.as<double>(); ba.vinv = vinv.as<double>(); ba.ge = ge.as<double>(); ba.obsrec = obsrec.as<double>();
         ba.points_out = nullptr; ba.partials = partB.as<double>();
-        launch_back_pass(d, ba, blocksM, s);
-        OSFM_RETURN_IF(toc());
-        launch_cost_pass(d, nullptr, nullptr, partC.as<double>(), blocksM, s);
-        // the kernels write the state they leave straight into the host's slot
-        launch_lm_decide(lm, prm, sc, eager ? nullptr : &h_state[slot], s);
+        if (fused) {
+            ba.fused = 1; ba.partials_cam = part_cam.as<double>(); ba.cost_partials = partC.as<double>();
+            ba.decide.lm = lm; ba.decide.prm = prm; ba.decide.sc = sc; ba.decide.host_out = eager ? nullptr : &h_state[slot];
+            ba.decide.ticket = tickets.as<int32_t>(); ba.decide.enabled = 1;
+            launch_back_pass(d, ba, blocksM, s);
+            OSFM_RETURN_IF(toc());
+        } else {
+            if (!small) launch_cam_update(d, y_c.as<double>(), nullptr, part_cam.as<double>(), s);
+            launch_back_pass(d, ba, blocksM, s);
+            OSFM_RETURN_IF(toc());
+            launch_cost_pass(d, nullptr, nullptr, partC.as<double>(), blocksM, s);
+            // the kernels write the state they leave straight into the host's slot
+            launch_lm_decide(lm, prm, sc, eager ? nullptr : &h_state[slot], s);
+        }
         if (!eager) OSFM_HIP_CHECK(hipEventRecord(evs[slot], s));
-        OSFM_RETURN_IF(linearize(!small));
-        launch_lm_post(lm, prm, sc, 0, eager ? &h_state[slot] : nullptr, s);
+        OSFM_RETURN_IF(linearize(consumed, kPostLoop, eager ? &h_state[slot] : nullptr));
         OSFM_HIP_CHECK(hipGetLastError());
         int seen = -1;                    // the slot whose state the host has read in this round
         if (eager) {
@@ -458,16 +484,16 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
         }
         if (seen >= 0 && h_state[seen].flow_aborted) {
             // The one-launch factorisation of iteration seen - 1 gave up (a wait outlasted its spin limit: its
-            // workgroups were not all resident).  Nothing was decided from it -- ba_lm_decide left the state as
-            // it was and every kernel behind it returned at once (the reset of the system excepted) -- so the
-            // system is linearised again at the same iterate, with the same diagonal, and the iteration is
-            // repeated in the launch-per-column form, like the rest of the solve.
+            // workgroups were not all resident).  Nothing was decided from it -- the decision left the state as
+            // it was and every kernel behind it returned at once -- so the system is linearised again at the same
+            // iterate, with the same diagonal (no second finalisation: that is the iteration's, still to come),
+            // and the iteration is repeated in the launch-per-column form, like the rest of the solve.
             if (!flow_now || ++restarts > 1) { set_error("ba_solve: the Cholesky launch was given up twice (device busy?)"); return OSFM_E_DEVICE; }
             flow_now = false;
             sum->flow_fallbacks++;
             OSFM_HIP_CHECK(hipStreamSynchronize(s));
             launch_lm_clear_abort(lm, s);
-            OSFM_RETURN_IF(linearize(!small));
+            OSFM_RETURN_IF(linearize(!small, kPostNone, nullptr));
             it = seen - 2;                // the loop's increment makes it seen - 1: that iteration again
             continue;
         }

@@ -343,6 +343,22 @@ struct ObsLin {
     int off;      // offset of the camera in the tangent vector
 };
 
+// the robustified residual of observation k at camera parameters cams[obs_cam[k]] and the point P itself (a
+// candidate still in registers): what linearize_obs(..., want_j = false) leaves in o.rho0
+__device__ __forceinline__ double
+obs_cost_at(const BaDev &d, int k, const double *cams, const double (&P)[4])
+{
+    const int c = d.obs_cam[k];
+    ObsFull e;
+    if (d.model == kModelQuat)
+        eval_quat(cams + 7 * c, P, (double)d.img_w[c], (double)d.img_h[c], d.obs_xy[2 * k], d.obs_xy[2 * k + 1], false, e);
+    else
+        eval_euler(cams + 7 * c, P, (double)d.img_w[c], (double)d.img_h[c], d.obs_xy[2 * k], d.obs_xy[2 * k + 1], false, e);
+    const double s = e.r[0] * e.r[0] + e.r[1] * e.r[1];
+    const double a = d.huber, b = a * a;
+    return s > b ? 2.0 * a * sqrt(s) - b : s;
+}
+
 __device__ __forceinline__ void
 linearize_obs(const BaDev &d, int k, const double *cams, const double *points, bool want_j, ObsLin &o)
 {
@@ -430,7 +446,7 @@ __device__ __forceinline__ bool inv3_spd(const double A[3][3], double inv[3][3])
 // Candidate of one camera: x+ = Plus(x, scale * step), step = -y, and the camera's share of
 // the step / parameter norms (ambient coordinates of the non-constant blocks).
 __device__ __forceinline__ void
-cam_update_one(const BaDev &d, const double *y_c, double *cams_out, double *partials_cam, int c)
+cam_update_one(const BaDev &d, const double *y_c, double *cams_out, double *partials_cam, int c, double *cams_out2 = nullptr)
 {
     const double *cam = d.cams + 7 * c;
     double out[7];
@@ -460,10 +476,14 @@ cam_update_one(const BaDev &d, const double *y_c, double *cams_out, double *part
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
         cams_out[7 * c + i] = out[i];
+        if (cams_out2) cams_out2[7 * c + i] = out[i];
         if (act[i]) { sn += (cam[i] - out[i]) * (cam[i] - out[i]); xn += cam[i] * cam[i]; }
     }
-    partials_cam[2 * c] = sn;
-    partials_cam[2 * c + 1] = xn;
+    if (partials_cam) {
+        // (write-through: the workgroup that decides reads them in the same launch, maybe from another XCD)
+        store_sc1(&partials_cam[2 * c], sn);
+        store_sc1(&partials_cam[2 * c + 1], xn);
+    }
 }
 
 }  // namespace osfm

@@ -34,6 +34,41 @@ struct PointPassArgs {
     double *obsrec;           // [O][kObsRec]: per-observation blocks of this linearisation
 };
 
+// Tolerances and limits of the LM loop (ceres::Solver::Options as set in
+// bundle_adjustment.cpp:126-133 plus the defaults it leaves alone).
+struct LmParams {
+    double function_tolerance, gradient_tolerance, parameter_tolerance;
+    double min_relative_decrease, max_radius, min_radius;
+    int32_t max_iterations, max_invalid_steps;
+};
+
+// scratch the decision kernels reduce: per-block partials of the passes
+struct LmScratch {
+    const double *partA;     // [3][blocksM]  point pass: cost, gradient max, not-PD flag
+    const double *partB;     // [3][blocksM]  back pass: model cost change, |dx|^2, |x|^2
+    const double *partC;     // [blocksM]     cost pass: candidate cost
+    const double *part_cam;  // [C][2]        camera update: |dx|^2, |x|^2
+    const double *gmax_cam;  // [C]           camera gradient norms
+    int32_t *chol_info;      // [1]           first non-positive pivot + 1 (reset after reading)
+    int32_t blocksM, C;
+    double *reset_S;         // one-block systems: the decide kernel clears S ((reset_N + 32) x reset_N,
+    int32_t reset_n, reset_N;    // identity on the padding diagonal from reset_n on); null otherwise
+};
+
+// What the last workgroup of a launch needs to run the LM control in its tail (ba_lm_decide behind the back pass,
+// ba_lm_post behind the pair pass) instead of a launch of one workgroup each: 6-14 us of kernel plus a launch gap,
+// twice per iteration.  Every workgroup leaves its partials write-through and takes a ticket; the one that takes
+// the last runs the fixed-order reductions over all of them, so the result does not depend on which one that is.
+struct LmTail {
+    LmDev *lm;
+    LmParams prm;
+    LmScratch sc;
+    LmDev *host_out;          // page-locked host slot that receives the state (may be null)
+    int32_t *ticket;          // lm_ticket_bytes() of them, zero between launches (sharded counter)
+    int32_t initial;          // post: the linearisation in front of the first iteration
+    int32_t enabled;
+};
+
 constexpr int kPairChunk = 512;   // entries of a camera pair's list per pair-pass wave; kPairChunkSmall below
 constexpr int kPairChunkSmall = 256;       // kPairChunkSmallLimit entries (few cameras: more, shorter waves)
 constexpr int kPairChunkSmallLimit = 1 << 20;
@@ -66,6 +101,7 @@ struct PairPassArgs {
     double *S;                // [.][ldS] row-major, lower triangle blocks written
     int ldS;
     double *rhs;              // [nc]
+    LmTail post;              // enabled: the last workgroup runs ba_lm_post
 };
 
 struct BackPassArgs {
@@ -74,27 +110,13 @@ struct BackPassArgs {
     const double *obsrec;     // [O][kObsRec]
     double *points_out;       // [M][4] candidate points
     double *partials;         // [3][blocks]: model cost change, |dx|^2, |x|^2
-};
-
-// Tolerances and limits of the LM loop (ceres::Solver::Options as set in
-// bundle_adjustment.cpp:126-133 plus the defaults it leaves alone).
-struct LmParams {
-    double function_tolerance, gradient_tolerance, parameter_tolerance;
-    double min_relative_decrease, max_radius, min_radius;
-    int32_t max_iterations, max_invalid_steps;
-};
-
-// scratch the decision kernels reduce: per-block partials of the passes
-struct LmScratch {
-    const double *partA;     // [3][blocksM]  point pass: cost, gradient max, not-PD flag
-    const double *partB;     // [3][blocksM]  back pass: model cost change, |dx|^2, |x|^2
-    const double *partC;     // [blocksM]     cost pass: candidate cost
-    const double *part_cam;  // [C][2]        camera update: |dx|^2, |x|^2
-    const double *gmax_cam;  // [C]           camera gradient norms
-    int32_t *chol_info;      // [1]           first non-positive pivot + 1 (reset after reading)
-    int32_t blocksM, C;
-    double *reset_S;         // one-block systems: the decide kernel clears S ((reset_N + 32) x reset_N,
-    int32_t reset_n, reset_N;    // identity on the padding diagonal from reset_n on); null otherwise
+    // fused form (LM solve whose camera tables, candidates included, fit LDS): the launch also makes the candidate
+    // cameras (every workgroup for itself, in LDS; workgroup 0 writes them out), evaluates the candidate's cost
+    // (the cost pass: a launch and a pass over the observations less) and, in its last workgroup, decides
+    int fused;
+    double *partials_cam;     // [C][2]
+    double *cost_partials;    // [blocks]
+    LmTail decide;
 };
 
 // host_out (may be null): page-locked host slot that receives the state the kernel leaves
@@ -107,6 +129,8 @@ void launch_pair_pass(const BaDev &d, const PairPassArgs &a, hipStream_t s);
 // cams_out == nullptr (LM solve): the candidate goes to the iterate buffer that is not current
 void launch_cam_update(const BaDev &d, const double *y_c, double *cams_out, double *partials_cam, hipStream_t s);
 void launch_back_pass(const BaDev &d, const BackPassArgs &a, int blocks, hipStream_t s);
+size_t lm_ticket_bytes();
+bool back_pass_can_fuse(const BaDev &d);      // the camera tables and the candidate cameras fit LDS
 void launch_cost_pass(const BaDev &d, const double *cams, const double *points, double *partials,
     int blocks, hipStream_t s);
 void launch_reduce(const double *partials, int n, int num_slots, unsigned max_mask, double *out,

@@ -93,7 +93,7 @@ __device__ __forceinline__ double quad_sum(double v)
 }
 
 // per-block partial -> partials[slot * gridDim.x + blockIdx.x]
-template <bool IS_MAX>
+template <bool IS_MAX, bool SC1 = false>
 __device__ __forceinline__ void block_partial(double v, double *partials, int slot, double *sh)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -104,9 +104,42 @@ __device__ __forceinline__ void block_partial(double v, double *partials, int sl
     if (threadIdx.x == 0) {
         double t = sh[0];
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = IS_MAX ? fmax(t, sh[w]) : t + sh[w];
-        partials[(size_t)slot * gridDim.x + blockIdx.x] = t;
+        if (SC1) store_sc1(&partials[(size_t)slot * gridDim.x + blockIdx.x], t);
+        else partials[(size_t)slot * gridDim.x + blockIdx.x] = t;
     }
 }
+
+// The workgroup that takes the last ticket of a launch (every workgroup calls this once, behind its last
+// write-through store): MI355X_MICROARCH.md, "Valid forms" -- every storing wave drains its stores, one lane adds
+// to the counter behind the workgroup's barrier, the workgroup whose add came last loads (sc1) behind a barrier
+// that lane joins.  The counter is sharded: one word of all workgroups was 1.5k - 6k device-scope adds to ONE
+// address from eight XCDs, 25 - 30 us of a launch; here a workgroup adds to the shard blockIdx % kTicketShards (a
+// cache line each), the last of a shard to the top word, the last of those is the last of the launch.  All words
+// are left at zero for the next launch.
+constexpr int kTicketShards = 64, kTicketStride = 32;        // ints: a shard per 128-byte line, the top word behind them
+__device__ __forceinline__ bool last_workgroup(int32_t *ticket, int *lds_flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int shard = (int)(blockIdx.x % kTicketShards);
+        const int members = ((int)gridDim.x - shard + kTicketShards - 1) / kTicketShards;
+        const int live = min((int)gridDim.x, kTicketShards);
+        int32_t *word = ticket + shard * kTicketStride, *top = ticket + kTicketShards * kTicketStride;
+        int last = 0;
+        if (__hip_atomic_fetch_add(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+            __hip_atomic_store(word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(top, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == live - 1) {
+                __hip_atomic_store(top, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+            }
+        }
+        *lds_flag = last;
+    }
+    __syncthreads();
+    return *lds_flag != 0;
+}
+size_t lm_ticket_bytes() { return (size_t)(kTicketShards + 1) * kTicketStride * 4; }
 
 // ---------------------------------------------------------------------------
 // Camera tables in LDS.  The per-point kernels walk a track's observations one
@@ -119,12 +152,14 @@ __device__ __forceinline__ void block_partial(double v, double *partials, int sl
 // ---------------------------------------------------------------------------
 constexpr size_t kCamStageLimit = 64 * 1024;
 
-static size_t cam_stage_bytes(const BaDev &d, bool with_y)
+// with_candidates: room for a second set of camera parameters behind the tables (the fused back pass)
+static size_t cam_stage_bytes(const BaDev &d, bool with_y, bool with_candidates = false)
 {
     auto r8 = [](size_t bytes) { return (bytes + 7) / 8 * 8; };      // stage_array rounds every table up
-    const size_t b = 8 * ((size_t)7 * d.C + (size_t)d.nc * (with_y ? 2 : 1)) + 4 * r8((size_t)4 * d.C) + r8((size_t)6 * d.C);
+    const size_t b = 8 * ((size_t)7 * d.C * (with_candidates ? 2 : 1) + (size_t)d.nc * (with_y ? 2 : 1)) + 4 * r8((size_t)4 * d.C) + r8((size_t)6 * d.C);
     return b <= kCamStageLimit ? b : 0;
 }
+bool back_pass_can_fuse(const BaDev &d) { return d.C > 0 && cam_stage_bytes(d, true, true) != 0; }
 
 template <typename T>
 __device__ __forceinline__ const T *stage_array(const T *src, int n, char *&lds)
@@ -145,9 +180,10 @@ __device__ __forceinline__ const T *stage_array(const T *src, int n, char *&lds)
 
 // d with its per-camera arrays (and cams / y_c, if given) replaced by LDS copies
 __device__ __forceinline__ BaDev stage_cameras(const BaDev &d, char *lds, bool staged, const double *&cams,
-    const double **y_c)
+    const double **y_c, char **lds_end = nullptr)
 {
     BaDev o = d;
+    if (lds_end) *lds_end = lds;
     if (!staged || d.C <= 0) return o;
     cams = stage_array(cams, 7 * d.C, lds);
     o.cams = cams;
@@ -158,8 +194,189 @@ __device__ __forceinline__ BaDev stage_cameras(const BaDev &d, char *lds, bool s
     o.cam_ldim = stage_array(d.cam_ldim, d.C, lds);
     o.cam_off = stage_array(d.cam_off, d.C, lds);
     o.cam_colmap = stage_array(d.cam_colmap, 6 * d.C, lds);
+    if (lds_end) *lds_end = lds;
     __syncthreads();
     return o;
+}
+
+// ---------------------------------------------------------------------------
+// LM control on the device.  Fixed-order reductions of the per-block partials, then the
+// decisions of TrustRegionMinimizer / LevenbergMarquardtStrategy by thread 0.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double block_reduce_256(double v, bool is_max, double *sh)
+{
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st)
+            sh[threadIdx.x] = is_max ? fmax(sh[threadIdx.x], sh[threadIdx.x + st]) : sh[threadIdx.x] + sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// SC1: the values were stored write-through by other workgroups of THIS launch (sc1 loads, see last_workgroup)
+template <bool SC1 = false>
+__device__ __forceinline__ double strided_reduce(const double *p, int n, int stride, bool is_max, double *sh)
+{
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double x = SC1 ? load_sc1(p + (size_t)i * stride) : p[(size_t)i * stride];
+        v = is_max ? fmax(v, x) : v + x;
+    }
+    return block_reduce_256(v, is_max, sh);
+}
+
+// After the candidate of an iteration has been evaluated: step validity, the parameter /
+// function tolerance tests, accept or reject, the new radius, and what the linearisation
+// that follows has to do.
+// state -> the host's slot for this iteration (page-locked memory the device writes directly:
+// a copy engine transfer per iteration cost 4 us plus a 6 us bubble before the next kernel)
+__device__ __forceinline__ void publish_state(const LmDev *lm, LmDev *host_out)
+{
+    if (host_out) *host_out = *lm;
+}
+
+__device__ __forceinline__ void
+lm_decide_logic(LmDev *lm, const LmParams &prm, const LmScratch &sc, bool solved, double mcc, double sn, double xn,
+    double cand)
+{
+    const int info = *sc.chol_info;
+    *sc.chol_info = 0;
+    const double step_norm = sqrt(sn), x_norm = sqrt(xn);
+    lm->model_cost_change = mcc; lm->step_norm = step_norm; lm->x_norm = x_norm; lm->cand_cost = cand;
+    const bool solve_ok = solved && info == 0 && isfinite(mcc) && isfinite(step_norm);
+    const bool step_valid = solve_ok && mcc > 0.0;
+    if (!step_valid) {
+        // HandleInvalidStep -> LevenbergMarquardtStrategy::StepIsInvalid
+        if (++lm->invalid_steps >= prm.max_invalid_steps) { lm->term = OSFM_BA_FAILURE; lm->stop = 1; return; }
+        lm->radius = lm->radius / lm->decrease_factor; lm->decrease_factor *= 2.0;
+        lm->num_unsuccess++;
+        lm->update_diag = 0; lm->want_gradient = 0;
+        return;
+    }
+    lm->invalid_steps = 0;
+    if (!isfinite(cand)) cand = 1.7976931348623157e308;
+    // ParameterToleranceReached / FunctionToleranceReached
+    if (step_norm <= prm.parameter_tolerance * (x_norm + prm.parameter_tolerance)) { lm->term = OSFM_BA_CONVERGENCE_PARAMETER; lm->stop = 1; return; }
+    const double cost_change = lm->x_cost - cand;
+    if (fabs(cost_change) <= prm.function_tolerance * lm->x_cost) { lm->term = OSFM_BA_CONVERGENCE_FUNCTION; lm->stop = 1; return; }
+    const double relative_decrease = cost_change / mcc;
+    if (relative_decrease > prm.min_relative_decrease) {
+        // HandleSuccessfulStep + LevenbergMarquardtStrategy::StepAccepted
+        lm->cur ^= 1;
+        const double t = 2.0 * relative_decrease - 1.0;
+        lm->radius = fmin(prm.max_radius, lm->radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+        lm->decrease_factor = 2.0;
+        lm->num_success++;
+        lm->last_successful = 1;
+        lm->update_diag = 1; lm->want_gradient = 1;
+    } else {
+        // LevenbergMarquardtStrategy::StepRejected
+        lm->radius = lm->radius / lm->decrease_factor; lm->decrease_factor *= 2.0;
+        lm->num_unsuccess++;
+        lm->update_diag = 0; lm->want_gradient = 0;
+    }
+}
+
+// One workgroup of 256 threads (a kernel of its own, or the last workgroup of the back pass: SC1)
+template <bool SC1>
+__device__ __forceinline__ void
+lm_decide_block(LmDev *lm, const LmParams &prm, const LmScratch &sc, LmDev *host_out, double *sh)
+{
+    if (lm->stop || lm->flow_aborted) { if (threadIdx.x == 0) publish_state(lm, host_out); return; }
+    if (*sc.chol_info >= kFlowAborted) {
+        // not a numerical failure: the factorisation's launch was given up (ba_cholesky.hip).  Nothing is decided;
+        // the host repeats the iteration in the launch-per-column form (osfm_ba_solve)
+        if (threadIdx.x == 0) { *sc.chol_info = 0; lm->flow_aborted = 1; publish_state(lm, host_out); }
+        return;
+    }
+    const bool solved = !lm->lin_failed;
+    double mcc = 0.0, sn = 0.0, xn = 0.0, cand = 0.0;
+    if (solved) {
+        mcc = strided_reduce<SC1>(sc.partB, sc.blocksM, 1, false, sh);
+        sn = strided_reduce<SC1>(sc.partB + sc.blocksM, sc.blocksM, 1, false, sh) + strided_reduce<SC1>(sc.part_cam, sc.C, 2, false, sh);
+        xn = strided_reduce<SC1>(sc.partB + 2 * (size_t)sc.blocksM, sc.blocksM, 1, false, sh) + strided_reduce<SC1>(sc.part_cam + 1, sc.C, 2, false, sh);
+        cand = strided_reduce<SC1>(sc.partC, sc.blocksM, 1, false, sh);
+    }
+    // a one-block system was consumed by the solve at the head of this iteration: clear it
+    // for the linearisation that follows (saves that launch its own reset kernel)
+    if (sc.reset_S) {
+        const int N = sc.reset_N, n = sc.reset_n;
+        for (int i = threadIdx.x; i < (N + 32) * N; i += blockDim.x) {
+            const int row = i / N, col = i - row * N;
+            sc.reset_S[i] = (row == col && row >= n && row < N) ? 1.0 : 0.0;
+        }
+    }
+    if (threadIdx.x != 0) return;
+    lm_decide_logic(lm, prm, sc, solved, mcc, sn, xn, cand);
+    publish_state(lm, host_out);
+}
+
+__global__ __launch_bounds__(256) void
+ba_lm_decide_kernel(LmDev *lm, LmParams prm, LmScratch sc, LmDev *host_out)
+{
+    __shared__ double sh[256];
+    lm_decide_block<false>(lm, prm, sc, host_out, sh);
+}
+
+// After a linearisation: cost / gradient norm of a new iterate, the not-positive-definite
+// flag, then FinalizeIterationAndCheckIfMinimizerCanContinue for the iteration that follows.
+__device__ __forceinline__ void
+lm_post_logic(LmDev *lm, const LmParams &prm, int initial, double cost, double gp, double bad, double gc)
+{
+    if (lm->want_gradient) { lm->x_cost = cost; lm->grad_max = fmax(gp, gc); }
+    lm->lin_failed = bad != 0.0 ? 1 : 0;
+    if (initial) {
+        lm->initial_cost = cost;
+        if (!isfinite(cost)) { lm->nonfinite = 1; lm->term = OSFM_BA_FAILURE; lm->stop = 1; return; }
+        if (lm->grad_max <= prm.gradient_tolerance) { lm->term = OSFM_BA_CONVERGENCE_GRADIENT; lm->stop = 1; return; }
+    }
+    // the LM diagonal is refreshed by the linearisation that follows an accepted step only
+    lm->update_diag = 0; lm->want_gradient = 0;
+    if (lm->iteration >= prm.max_iterations) { lm->term = OSFM_BA_NO_CONVERGENCE; lm->stop = 1; return; }
+    if (lm->last_successful && lm->grad_max <= prm.gradient_tolerance) { lm->term = OSFM_BA_CONVERGENCE_GRADIENT; lm->stop = 1; return; }
+    if (lm->radius <= prm.min_radius) { lm->term = OSFM_BA_CONVERGENCE_TRUST_REGION; lm->stop = 1; return; }
+    lm->iteration++;
+    lm->last_successful = 0;
+}
+
+// One workgroup of 256 threads (a kernel of its own, or the last workgroup of the pair pass: GMAX_SC1 -- the
+// camera gradient norms come from that launch, the point pass's partials from the one before it)
+template <bool GMAX_SC1>
+__device__ __forceinline__ void
+lm_post_block(LmDev *lm, const LmParams &prm, const LmScratch &sc, int initial, LmDev *host_out, double *sh)
+{
+    if (lm->stop || lm->flow_aborted) { if (threadIdx.x == 0) publish_state(lm, host_out); return; }
+    const double cost = strided_reduce(sc.partA, sc.blocksM, 1, false, sh);
+    const double gp = strided_reduce(sc.partA + sc.blocksM, sc.blocksM, 1, true, sh);
+    const double bad = strided_reduce(sc.partA + 2 * (size_t)sc.blocksM, sc.blocksM, 1, true, sh);
+    const double gc = strided_reduce<GMAX_SC1>(sc.gmax_cam, sc.C, 1, true, sh);
+    if (threadIdx.x != 0) return;
+    lm_post_logic(lm, prm, initial, cost, gp, bad, gc);
+    publish_state(lm, host_out);
+}
+
+__global__ __launch_bounds__(256) void
+ba_lm_post_kernel(LmDev *lm, LmParams prm, LmScratch sc, int initial, LmDev *host_out)
+{
+    __shared__ double sh[256];
+    lm_post_block<false>(lm, prm, sc, initial, host_out, sh);
+}
+
+void launch_lm_decide(LmDev *lm, const LmParams &prm, const LmScratch &sc, LmDev *host_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_lm_decide_kernel, dim3(1), dim3(256), 0, s, lm, prm, sc, host_out);
+}
+
+__global__ void ba_lm_clear_abort_kernel(LmDev *lm) { lm->flow_aborted = 0; }
+void launch_lm_clear_abort(LmDev *lm, hipStream_t s) { hipLaunchKernelGGL(ba_lm_clear_abort_kernel, dim3(1), dim3(1), 0, s, lm); }
+
+void launch_lm_post(LmDev *lm, const LmParams &prm, const LmScratch &sc, int initial, LmDev *host_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_lm_post_kernel, dim3(1), dim3(256), 0, s, lm, prm, sc, initial, host_out);
 }
 
 // ---------------------------------------------------------------------------
@@ -353,17 +570,14 @@ pair_finish(const BaDev &d, const PairPassArgs &a, int c1, int c2, int n1, int n
         }
         double gm = 0.0;
         for (int i = 0; i < 7; ++i) gm = fmax(gm, fabs(cam[i] - out[i]));
-        a.gmax_out[c1] = gm;
+        store_sc1(&a.gmax_out[c1], gm);        // read by the last workgroup of this launch (ba_lm_post in its tail)
     }
 }
 
-__global__ __launch_bounds__(256, 2) void
-ba_pair_pass_kernel(BaDev d, PairPassArgs a)
+// one wave's chunk (ent_lds / rec_lds: the kernel's LDS blocks, one per wave)
+__device__ __forceinline__ void
+pair_pass_wave(const BaDev &d, const PairPassArgs &a, int2 (*ent_lds)[64], double (*rec_lds)[2][64 * 18])
 {
-    if (!lm_resolve(d)) return;
-    if (d.lm && a.mode == kPassNormal) {
-        a.radius = d.lm->radius; a.update_diag = d.lm->update_diag; a.want_gradient = d.lm->want_gradient;
-    }
     const int lane = threadIdx.x & 63;
     // consecutive chunks (camera pairs sorted by c1, then c2) on the same XCD: the records of
     // camera c1 serve ~200 pairs in a row and stay in that XCD's L2 (round robin over the XCDs
@@ -400,8 +614,6 @@ ba_pair_pass_kernel(BaDev d, PairPassArgs a)
     // fourteen lines per instruction -- by DMA (global_load_lds: no registers in between) into a block of
     // the wave's own, record after record (144 B apart: the lanes' 16-byte reads of their own records then
     // fall on different banks).  No barrier: one wave's LDS operations execute in order.
-    __shared__ int2 ent_lds[4][64];
-    __shared__ __attribute__((aligned(16))) double rec_lds[4][2][64 * 18];
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
     const int wv = (int)(threadIdx.x >> 6);
@@ -530,6 +742,29 @@ ba_pair_pass_kernel(BaDev d, PairPassArgs a)
     if (lane == 0) pair_finish(d, a, c1, c2, n1, n2, o1, o2, acc, U, rhs, g);
 }
 
+__global__ __launch_bounds__(256, 2) void
+ba_pair_pass_kernel(BaDev d, PairPassArgs a)
+{
+    __shared__ int lds_last;
+    __shared__ double sh[256];
+    __shared__ int2 ent_lds[4][64];
+    __shared__ __attribute__((aligned(16))) double rec_lds[4][2][64 * 18];
+    if (!lm_resolve(d)) {
+        // a stopped solve: the state still goes to the host's slot (ba_lm_post did that)
+        if (a.post.enabled && blockIdx.x == 0 && threadIdx.x == 0) publish_state(a.post.lm, a.post.host_out);
+        return;
+    }
+    if (d.lm && a.mode == kPassNormal) {
+        a.radius = d.lm->radius; a.update_diag = d.lm->update_diag; a.want_gradient = d.lm->want_gradient;
+    }
+    pair_pass_wave(d, a, ent_lds, rec_lds);
+    if (!a.post.enabled) return;
+    // ---- ba_lm_post in the tail of the workgroup that finishes last (the camera gradient norms of the diagonal
+    //      pairs were stored write-through) ----
+    if (!last_workgroup(a.post.ticket, &lds_last)) return;
+    lm_post_block<true>(a.post.lm, a.post.prm, a.post.sc, a.post.initial, a.post.host_out, sh);
+}
+
 void launch_pair_pass(const BaDev &d, const PairPassArgs &a, hipStream_t s)
 {
     if (a.num_pairs <= 0) return;
@@ -562,14 +797,34 @@ __global__ __launch_bounds__(256) void
 ba_back_pass_kernel(BaDev dg, BackPassArgs a, int staged)
 {
     extern __shared__ __attribute__((aligned(16))) char cam_lds[];
-    __shared__ double sh[4];
-    if (!lm_resolve(dg)) return;
-    if (dg.lm) { if (dg.lm->lin_failed) return; a.points_out = dg.lm->cur ? dg.points2[0] : dg.points2[1]; }
+    __shared__ double sh[256];
+    __shared__ int lds_last;
+    const bool fused = a.fused != 0;
+    if (!lm_resolve(dg)) {
+        if (fused && blockIdx.x == 0) lm_decide_block<true>(a.decide.lm, a.decide.prm, a.decide.sc, a.decide.host_out, sh);   // publishes the stopped state
+        return;
+    }
+    if (dg.lm && dg.lm->lin_failed) {
+        // the linearisation failed: there is no step; the decision (an invalid step) is one workgroup's work
+        if (fused && blockIdx.x == 0) lm_decide_block<true>(a.decide.lm, a.decide.prm, a.decide.sc, a.decide.host_out, sh);
+        return;
+    }
+    double *cams_global_out = nullptr;
+    if (dg.lm) { a.points_out = dg.lm->cur ? dg.points2[0] : dg.points2[1]; cams_global_out = dg.lm->cur ? dg.cams2[0] : dg.cams2[1]; }
     const double *cams = dg.cams;
-    const BaDev d = stage_cameras(dg, cam_lds, staged != 0, cams, &a.y_c);
+    char *lds_end = nullptr;
+    const BaDev d = stage_cameras(dg, cam_lds, staged != 0, cams, &a.y_c, &lds_end);
+    // fused: the candidate cameras Plus(x, -step), every workgroup for itself behind its camera tables; workgroup 0
+    // also writes them (and the cameras' share of the step norms) where the cost pass / ba_cam_update did
+    double *cand = reinterpret_cast<double *>(lds_end);
+    if (fused) {
+        for (int c = threadIdx.x; c < d.C; c += 256)
+            cam_update_one(d, a.y_c, cand, blockIdx.x == 0 ? a.partials_cam : nullptr, c, blockIdx.x == 0 ? cams_global_out : nullptr);
+        __syncthreads();
+    }
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = gt / kPointLanes, sub = gt % kPointLanes;
-    double mcc = 0.0, sn = 0.0, xn = 0.0;
+    double mcc = 0.0, sn = 0.0, xn = 0.0, ccost = 0.0;
     if (j < d.M) {
         const int k0 = d.pt_start[j], k1 = d.pt_start[j + 1];
         double step_p[3] = { 0, 0, 0 };
@@ -625,15 +880,30 @@ ba_back_pass_kernel(BaDev dg, BackPassArgs a, int staged)
         }
         if (sub == 0)
             for (int x = 0; x < 4; ++x) a.points_out[4 * j + x] = out[x];
+        if (fused) {
+            // the cost of the candidate (ba_cost_pass_kernel's sum, lane by lane): the candidate point is in the
+            // registers of all four lanes of the track, the candidate cameras are in LDS
+            for (int k = k0 + sub; k < k1; k += kPointLanes) ccost += 0.5 * obs_cost_at(d, k, cand, out);
+        }
     }
-    block_partial<false>(mcc, a.partials, 0, sh);
-    block_partial<false>(sn, a.partials, 1, sh);
-    block_partial<false>(xn, a.partials, 2, sh);
+    if (!fused) {
+        block_partial<false>(mcc, a.partials, 0, sh);
+        block_partial<false>(sn, a.partials, 1, sh);
+        block_partial<false>(xn, a.partials, 2, sh);
+        return;
+    }
+    block_partial<false, true>(mcc, a.partials, 0, sh);
+    block_partial<false, true>(sn, a.partials, 1, sh);
+    block_partial<false, true>(xn, a.partials, 2, sh);
+    block_partial<false, true>(ccost, a.cost_partials, 0, sh);
+    // ---- ba_lm_decide in the tail of the workgroup that finishes last ----
+    if (!last_workgroup(a.decide.ticket, &lds_last)) return;
+    lm_decide_block<true>(a.decide.lm, a.decide.prm, a.decide.sc, a.decide.host_out, sh);
 }
 
 void launch_back_pass(const BaDev &d, const BackPassArgs &a, int blocks, hipStream_t s)
 {
-    const size_t lds = cam_stage_bytes(d, true);
+    const size_t lds = cam_stage_bytes(d, true, a.fused != 0);
     hipLaunchKernelGGL(ba_back_pass_kernel, dim3(blocks), dim3(256), lds, s, d, a, lds ? 1 : 0);
 }
 
@@ -725,167 +995,6 @@ ba_max_reduce_kernel(const double *v, int n, double *out)
         __syncthreads();
     }
     if (threadIdx.x == 0) *out = sh[0];
-}
-
-// ---------------------------------------------------------------------------
-// LM control on the device.  Fixed-order reductions of the per-block partials, then the
-// decisions of TrustRegionMinimizer / LevenbergMarquardtStrategy by thread 0.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ double block_reduce_256(double v, bool is_max, double *sh)
-{
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int st = 128; st >= 1; st >>= 1) {
-        if ((int)threadIdx.x < st)
-            sh[threadIdx.x] = is_max ? fmax(sh[threadIdx.x], sh[threadIdx.x + st]) : sh[threadIdx.x] + sh[threadIdx.x + st];
-        __syncthreads();
-    }
-    const double r = sh[0];
-    __syncthreads();
-    return r;
-}
-
-__device__ __forceinline__ double strided_reduce(const double *p, int n, int stride, bool is_max, double *sh)
-{
-    double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const double x = p[(size_t)i * stride];
-        v = is_max ? fmax(v, x) : v + x;
-    }
-    return block_reduce_256(v, is_max, sh);
-}
-
-// After the candidate of an iteration has been evaluated: step validity, the parameter /
-// function tolerance tests, accept or reject, the new radius, and what the linearisation
-// that follows has to do.
-// state -> the host's slot for this iteration (page-locked memory the device writes directly:
-// a copy engine transfer per iteration cost 4 us plus a 6 us bubble before the next kernel)
-__device__ __forceinline__ void publish_state(const LmDev *lm, LmDev *host_out)
-{
-    if (host_out) *host_out = *lm;
-}
-
-__device__ __forceinline__ void
-lm_decide_logic(LmDev *lm, const LmParams &prm, const LmScratch &sc, bool solved, double mcc, double sn, double xn,
-    double cand)
-{
-    const int info = *sc.chol_info;
-    *sc.chol_info = 0;
-    const double step_norm = sqrt(sn), x_norm = sqrt(xn);
-    lm->model_cost_change = mcc; lm->step_norm = step_norm; lm->x_norm = x_norm; lm->cand_cost = cand;
-    const bool solve_ok = solved && info == 0 && isfinite(mcc) && isfinite(step_norm);
-    const bool step_valid = solve_ok && mcc > 0.0;
-    if (!step_valid) {
-        // HandleInvalidStep -> LevenbergMarquardtStrategy::StepIsInvalid
-        if (++lm->invalid_steps >= prm.max_invalid_steps) { lm->term = OSFM_BA_FAILURE; lm->stop = 1; return; }
-        lm->radius = lm->radius / lm->decrease_factor; lm->decrease_factor *= 2.0;
-        lm->num_unsuccess++;
-        lm->update_diag = 0; lm->want_gradient = 0;
-        return;
-    }
-    lm->invalid_steps = 0;
-    if (!isfinite(cand)) cand = 1.7976931348623157e308;
-    // ParameterToleranceReached / FunctionToleranceReached
-    if (step_norm <= prm.parameter_tolerance * (x_norm + prm.parameter_tolerance)) { lm->term = OSFM_BA_CONVERGENCE_PARAMETER; lm->stop = 1; return; }
-    const double cost_change = lm->x_cost - cand;
-    if (fabs(cost_change) <= prm.function_tolerance * lm->x_cost) { lm->term = OSFM_BA_CONVERGENCE_FUNCTION; lm->stop = 1; return; }
-    const double relative_decrease = cost_change / mcc;
-    if (relative_decrease > prm.min_relative_decrease) {
-        // HandleSuccessfulStep + LevenbergMarquardtStrategy::StepAccepted
-        lm->cur ^= 1;
-        const double t = 2.0 * relative_decrease - 1.0;
-        lm->radius = fmin(prm.max_radius, lm->radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
-        lm->decrease_factor = 2.0;
-        lm->num_success++;
-        lm->last_successful = 1;
-        lm->update_diag = 1; lm->want_gradient = 1;
-    } else {
-        // LevenbergMarquardtStrategy::StepRejected
-        lm->radius = lm->radius / lm->decrease_factor; lm->decrease_factor *= 2.0;
-        lm->num_unsuccess++;
-        lm->update_diag = 0; lm->want_gradient = 0;
-    }
-}
-
-__global__ __launch_bounds__(256) void
-ba_lm_decide_kernel(LmDev *lm, LmParams prm, LmScratch sc, LmDev *host_out)
-{
-    __shared__ double sh[256];
-    if (lm->stop || lm->flow_aborted) { if (threadIdx.x == 0) publish_state(lm, host_out); return; }
-    if (*sc.chol_info >= kFlowAborted) {
-        // not a numerical failure: the factorisation's launch was given up (ba_cholesky.hip).  Nothing is decided;
-        // the host repeats the iteration in the launch-per-column form (osfm_ba_solve)
-        if (threadIdx.x == 0) { *sc.chol_info = 0; lm->flow_aborted = 1; publish_state(lm, host_out); }
-        return;
-    }
-    const bool solved = !lm->lin_failed;
-    double mcc = 0.0, sn = 0.0, xn = 0.0, cand = 0.0;
-    if (solved) {
-        mcc = strided_reduce(sc.partB, sc.blocksM, 1, false, sh);
-        sn = strided_reduce(sc.partB + sc.blocksM, sc.blocksM, 1, false, sh) + strided_reduce(sc.part_cam, sc.C, 2, false, sh);
-        xn = strided_reduce(sc.partB + 2 * (size_t)sc.blocksM, sc.blocksM, 1, false, sh) + strided_reduce(sc.part_cam + 1, sc.C, 2, false, sh);
-        cand = strided_reduce(sc.partC, sc.blocksM, 1, false, sh);
-    }
-    // a one-block system was consumed by the solve at the head of this iteration: clear it
-    // for the linearisation that follows (saves that launch its own reset kernel)
-    if (sc.reset_S) {
-        const int N = sc.reset_N, n = sc.reset_n;
-        for (int i = threadIdx.x; i < (N + 32) * N; i += blockDim.x) {
-            const int row = i / N, col = i - row * N;
-            sc.reset_S[i] = (row == col && row >= n && row < N) ? 1.0 : 0.0;
-        }
-    }
-    if (threadIdx.x != 0) return;
-    lm_decide_logic(lm, prm, sc, solved, mcc, sn, xn, cand);
-    publish_state(lm, host_out);
-}
-
-// After a linearisation: cost / gradient norm of a new iterate, the not-positive-definite
-// flag, then FinalizeIterationAndCheckIfMinimizerCanContinue for the iteration that follows.
-__device__ __forceinline__ void
-lm_post_logic(LmDev *lm, const LmParams &prm, int initial, double cost, double gp, double bad, double gc)
-{
-    if (lm->want_gradient) { lm->x_cost = cost; lm->grad_max = fmax(gp, gc); }
-    lm->lin_failed = bad != 0.0 ? 1 : 0;
-    if (initial) {
-        lm->initial_cost = cost;
-        if (!isfinite(cost)) { lm->nonfinite = 1; lm->term = OSFM_BA_FAILURE; lm->stop = 1; return; }
-        if (lm->grad_max <= prm.gradient_tolerance) { lm->term = OSFM_BA_CONVERGENCE_GRADIENT; lm->stop = 1; return; }
-    }
-    // the LM diagonal is refreshed by the linearisation that follows an accepted step only
-    lm->update_diag = 0; lm->want_gradient = 0;
-    if (lm->iteration >= prm.max_iterations) { lm->term = OSFM_BA_NO_CONVERGENCE; lm->stop = 1; return; }
-    if (lm->last_successful && lm->grad_max <= prm.gradient_tolerance) { lm->term = OSFM_BA_CONVERGENCE_GRADIENT; lm->stop = 1; return; }
-    if (lm->radius <= prm.min_radius) { lm->term = OSFM_BA_CONVERGENCE_TRUST_REGION; lm->stop = 1; return; }
-    lm->iteration++;
-    lm->last_successful = 0;
-}
-
-__global__ __launch_bounds__(256) void
-ba_lm_post_kernel(LmDev *lm, LmParams prm, LmScratch sc, int initial, LmDev *host_out)
-{
-    __shared__ double sh[256];
-    if (lm->stop || lm->flow_aborted) { if (threadIdx.x == 0) publish_state(lm, host_out); return; }
-    const double cost = strided_reduce(sc.partA, sc.blocksM, 1, false, sh);
-    const double gp = strided_reduce(sc.partA + sc.blocksM, sc.blocksM, 1, true, sh);
-    const double bad = strided_reduce(sc.partA + 2 * (size_t)sc.blocksM, sc.blocksM, 1, true, sh);
-    const double gc = strided_reduce(sc.gmax_cam, sc.C, 1, true, sh);
-    if (threadIdx.x != 0) return;
-    lm_post_logic(lm, prm, initial, cost, gp, bad, gc);
-    publish_state(lm, host_out);
-}
-
-void launch_lm_decide(LmDev *lm, const LmParams &prm, const LmScratch &sc, LmDev *host_out, hipStream_t s)
-{
-    hipLaunchKernelGGL(ba_lm_decide_kernel, dim3(1), dim3(256), 0, s, lm, prm, sc, host_out);
-}
-
-__global__ void ba_lm_clear_abort_kernel(LmDev *lm) { lm->flow_aborted = 0; }
-void launch_lm_clear_abort(LmDev *lm, hipStream_t s) { hipLaunchKernelGGL(ba_lm_clear_abort_kernel, dim3(1), dim3(1), 0, s, lm); }
-
-void launch_lm_post(LmDev *lm, const LmParams &prm, const LmScratch &sc, int initial, LmDev *host_out, hipStream_t s)
-{
-    hipLaunchKernelGGL(ba_lm_post_kernel, dim3(1), dim3(256), 0, s, lm, prm, sc, initial, host_out);
 }
 
 // zero, with the identity on the padding diagonal

@@ -687,9 +687,29 @@ int upload_view(osfm_matcher *m, int view, const uint16_t *sift, int n_sift, con
 // facilities the reference uses (std::mt19937(0) + std::normal_distribution<>,
 // cascade_hashing.h:225-254): the distribution's algorithm is the library's,
 // so the values equal the reference's when both are built against libstdc++.
+static int build_cashash(osfm_matcher *m);
+
+// The average descriptor -- and with it every hash -- is taken over ALL views (CascadeHashing::init receives the whole
+// viewport list, cascade_hashing.cc:33-70), so a cascade batch needs the complete bank: a slot that was never set
+// is an error, not an empty view, and no upload may run beside the build (uploads mutate the views under up_mu; the
+// flag is cleared BEFORE the build so that an upload that follows raises it again and is not lost).
 int ensure_cashash(osfm_matcher *m)
 {
-    if (!m->cas_dirty) return OSFM_OK;
+    std::lock_guard<std::mutex> lock(m->up_mu);
+    for (size_t v = 0; v < m->views.size(); ++v)
+        if (!m->views[v].set) {
+            set_error("cascade hashing: view %d of %d has not been set (the hashes depend on the average descriptor of ALL views)",
+                (int)v, (int)m->views.size());
+            return OSFM_E_STATE;
+        }
+    if (!m->cas_dirty.exchange(false)) return OSFM_OK;
+    const int rc = build_cashash(m);
+    if (rc != OSFM_OK) m->cas_dirty = true;
+    return rc;
+}
+
+static int build_cashash(osfm_matcher *m)
+{
     OSFM_HIP_CHECK(hipStreamSynchronize(m->up_stream));       // the hashes are built from every view
     hipStream_t s = m->stream;
     for (int type = 0; type < 2; ++type) {
@@ -744,7 +764,6 @@ int ensure_cashash(osfm_matcher *m)
     }
     OSFM_HIP_CHECK(hipGetLastError());
     OSFM_HIP_CHECK(hipStreamSynchronize(s));
-    m->cas_dirty = false;
     return OSFM_OK;
 }
 

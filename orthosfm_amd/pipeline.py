@@ -471,7 +471,10 @@ def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, ti
     for k in range(n_batches):
         sub = pf[bounds[k]:bounds[k + 1]]
         t1 = time.perf_counter()
-        wait_for_views(int(sub.max()) + 1 if sub.size else 0)
+        # Cascade hashing hashes every descriptor against the average over ALL views (CascadeHashing::init,
+        # cascade_hashing.cc:33-70): its first batch needs the complete bank, not just the views it names --
+        # the library refuses a cascade batch while a view is missing.  Exhaustive matching takes what it names.
+        wait_for_views(V if matcher != "exhaustive" else (int(sub.max()) + 1 if sub.size else 0))
         upload_wait += time.perf_counter() - t1
         t1 = time.perf_counter()
         buf = free.get()

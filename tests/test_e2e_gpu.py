@@ -235,3 +235,45 @@ def test_config4_500_views_euler_all_dof_at_stated_size():
     assert worst < 1e-3, worst
     tt = res.tracks
     assert int((tt.alive_t & tt.has_point).sum()) > 1000
+
+
+def test_cascade_mode_of_the_pipeline_equals_sequential_uploads():
+    """matcher='cascade' is what the application hard-codes (matching_mve.cpp:406-408).  The pipeline overlaps
+    view uploads with matching, but CascadeHashing hashes every descriptor against the average over ALL views
+    (cascade_hashing.cc:33-70): its first batch must wait for the whole bank.  Same pair lists (status and
+    correspondences per pair) and the same tracks as all views uploaded first, then one compute() -- on a set
+    large enough for several batches -- and the library refuses a cascade batch while a view is missing."""
+    from orthosfm_amd import capi, pipeline as P
+    from orthosfm_amd.matching import HipCascadeHashing
+    from orthosfm_amd.tracks import Tracks, Viewport
+    iset = synth.make_image_set(48, 1200, config_id=72)
+    V, W, H = iset.num_views, iset.width, iset.height
+    tt, info = P.match_and_build_tracks(iset, "cascade", 0, True)
+    P.join_background()
+    o = capi.default_match_options()
+    o.geometric_verification = 1
+    m = HipCascadeHashing(V, options=o)
+    for v in range(V):
+        m.set_view(v, iset.sift[v])
+        m.set_positions(v, ((iset.pos[v] + 0.5 - np.array([W / 2, H / 2])) / max(W, H)).astype(np.float32))
+    out = m.compute()
+    m.close()
+    status = np.array([tv.status for tv in out], np.int32)
+    assert np.array_equal(status, info["pair_status"])
+    matching = [tv for tv in out if tv.status == capi.PAIR_MATCHED]
+    assert len(matching) == info["matched_pairs"] >= 20
+    assert sum(tv.matches.shape[0] for tv in matching) == info["correspondences"]
+    tracks = Tracks().compute(matching, [Viewport(iset.sift[v].shape[0]) for v in range(V)])
+    assert len(tracks) == info["num_mve_tracks"]
+    feats = np.array([(v, f) for t in tracks for v, f in t.features], np.int32).reshape(-1, 2)
+    assert np.array_equal(np.stack([tt.view, tt.feat], 1), feats)
+    # a cascade batch with a slot that was never set: refused, the hashes would be those of another bank
+    m2 = HipCascadeHashing(3)
+    m2.set_view(0, iset.sift[0])
+    m2.set_view(1, iset.sift[1])
+    with pytest.raises(capi.OsfmError) as e:
+        m2.pairwise_match(0, 1)
+    assert e.value.status == capi.E_STATE
+    m2.set_view(2, iset.sift[2])
+    assert (m2.pairwise_match(0, 1).matches_1_2 >= 0).sum() > 0
+    m2.close()
