@@ -431,7 +431,7 @@ def realistic_operands_bench(iset, V, pairs, capacity, device_index, headline_ms
     from orthosfm_amd.matching import HipExhaustiveMatching
     out = {"what": "k SIFT descriptors per view with a byte > 127 (synth.add_peaky_rows); everything else as the headline",
            "headline_ms_per_step": headline_ms, "cases": []}
-    for k in (1, 20, 200):
+    for k in (1, 20, 200, 1000):
         sub = copy.copy(iset)
         sub.sift = [a.copy() for a in iset.sift]
         synth.add_peaky_rows(sub, k)
@@ -475,6 +475,60 @@ def realistic_operands_bench(iset, V, pairs, capacity, device_index, headline_ms
                 case["parity_bad_pairs"] = bad
         out["cases"].append(case)
         m.close()
+    return out
+
+
+def feature_all_bench(V, F, n_surf, pairs, device_index, steps, sift_pop_s, with_cpu):
+    """The application's FEATURE_ALL (matching_mve.cpp:333, exhaustive_matching.cc:114-180): every view carries SIFT
+    AND SURF descriptors -- F + n_surf per view through osfm_match_all (low-res gate on the SIFT block, two-way
+    matching of both types, cross-check, combined lists).  pairs/s of the whole pass, and the D = 64 tile kernel's
+    rate from its own launches (osfm_match_stats.surf_*), beside the D = 128 kernel's of the same pass."""
+    from orthosfm_amd import capi, synth
+    from orthosfm_amd.matching import HipExhaustiveMatching
+    iset = synth.make_image_set(V, F, n_surf=n_surf, config_id=2)
+    m = HipExhaustiveMatching(V, device=device_index, copy_results=False)
+    for v in range(V):
+        m.set_view(v, iset.sift[v], iset.surf[v])
+    cap = (F + n_surf) * len(pairs)
+    m.use_result_buffer(capi.pinned_rows(cap))
+    parr = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
+    for _ in range(2):
+        m.compute_arrays(parr, capacity=cap)
+    t0 = time.perf_counter()
+    tile_ms = surf_ms = 0.0
+    macs = surf_macs = 0
+    for _ in range(steps):
+        ra, corr = m.compute_arrays(parr, capacity=cap)
+        st = m.stats()
+        tile_ms += st.tile_kernel_ms; surf_ms += st.surf_tile_kernel_ms
+        macs += st.mac_count; surf_macs += st.surf_mac_count
+    dt = (time.perf_counter() - t0) / steps
+    n_corr = int(np.where(ra["status"] == capi.PAIR_MATCHED, ra["num_matches"], 0).sum())
+    out = {"workload": f"{V} views x ({F} SIFT + {n_surf} SURF), {len(pairs)} pairs, exhaustive, both types combined per pair",
+           "pairs_per_s": len(pairs) / dt, "ms_per_step": dt * 1e3, "correspondences": n_corr,
+           "surf_tile_kernel": {"kernel": "match_tile_kernel<4, false, true, ...> (D = 64)", "ms_per_step": surf_ms / steps,
+                                "achieved_TOPs": 2.0 * surf_macs / max(surf_ms, 1e-9) / 1e9,
+                                "frac_of_int8_peak": 2.0 * surf_macs / max(surf_ms, 1e-9) / 1e9 / I8_MFMA_PEAK_TOPS},
+           "sift_tile_kernel": {"ms_per_step": (tile_ms - surf_ms) / steps,
+                                "achieved_TOPs": 2.0 * (macs - surf_macs) / max(tile_ms - surf_ms, 1e-9) / 1e9,
+                                "headline_achieved_TOPs": sift_pop_s}}
+    if with_cpu:
+        import oracle_lib
+        objs = m.as_objects(ra, corr)
+        bad, checked = [], 0
+        for idx in np.linspace(0, len(pairs) - 1, 2).astype(int):
+            tv = objs[idx]
+            a, b = pairs[idx]
+            e12, _ = oracle_lib.oracle_pairwise_match(iset.sift[a], iset.surf[a], iset.sift[b], iset.surf[b])
+            ids = np.nonzero(e12 >= 0)[0]
+            exp = np.stack([ids, e12[ids]], axis=1).astype(np.int32)
+            if tv.status == capi.PAIR_MATCHED:
+                checked += 1
+                if not np.array_equal(np.asarray(tv.matches), exp):
+                    bad.append([int(a), int(b)])
+        out["parity_checked_pairs"] = checked
+        out["parity_ok"] = not bad
+    m.close()
     return out
 
 
@@ -918,6 +972,14 @@ def main():
         except Exception as e:
             realistic = {"error": repr(e)}
 
+    feature_all = None
+    if extras and not args.no_realistic:
+        try:
+            ach = 2.0 * macs / max(kern_ms, 1e-9) / 1e9
+            feature_all = feature_all_bench(V, F, 5000, my_pairs, device_index, max(args.steps // 2, 3), ach, not args.no_cpu_baseline)
+        except Exception as e:
+            feature_all = {"error": repr(e)}
+
     gated = None
     if extras and not args.no_verify and not args.no_ba:
         try:
@@ -1046,10 +1108,23 @@ def main():
             line["realistic_operands"] = realistic
             if any(not c.get("parity_ok", True) for c in realistic.get("cases", [])):
                 parity_bad = parity_bad + ["realistic_operands"]
+        if feature_all is not None:
+            line["feature_all"] = feature_all
+            if not feature_all.get("parity_ok", True):
+                parity_bad = parity_bad + ["feature_all"]
         if gated is not None:
             line["gates_at_work"] = gated
         if ba is not None:
             line["ba"] = ba
+            if "error" not in ba:
+                # the second half of the metric where the driver's record keeps it: BASELINE configs[3] (200 cameras,
+                # 100k tracks) -- LM iterations/s per call (SURVEY 8d's unit: upload, pair lists and write-back included)
+                # and inside the LM loop, the HBM fraction of the iteration's algorithmic bytes, one factorisation + solve
+                line["roofline"]["ba"] = {"iterations_per_s": ba["iterations_per_s"],
+                                          "lm_loop_iterations_per_s": ba["lm_loop_iterations_per_s"],
+                                          "frac": ba["roofline"]["frac"],
+                                          "cholesky_ms": ba["kernel_ms"]["cholesky"] / max(ba["iterations"], 1),
+                                          "workload": ba["workload"]}
         if e2e is not None:
             line["config3_single_gpu"] = e2e
         print(json.dumps(line))

@@ -42,6 +42,23 @@ OSFM_API int osfm_device_count(void);
  * batches and check that handles give their memory back. */
 OSFM_API int osfm_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 
+/* What the library itself holds in this process, by kind -- the counterpart of osfm_device_memory that does not
+ * depend on what the HIP runtime keeps in pools of its own: after osfm_match_destroy of the last matcher
+ * device_buffer_bytes, live_matchers are zero and pinned_host_bytes / live_streams / live_events are back at what
+ * the per-process stream sets of the BA entries hold (they are kept for reuse); pool_cached_bytes is what
+ * osfm_trim_device_memory would hand back. */
+typedef struct osfm_memory_report {
+    int64_t device_buffer_bytes;   /* grow-only device buffers owned by live handles (banks, scratch, hashes) */
+    int64_t pool_live_bytes;       /* work arrays of calls in flight (BA, triangulation, filters) */
+    int64_t pool_cached_bytes;     /* work arrays kept for the next call */
+    int64_t pinned_host_bytes;     /* page-locked staging of live handles and of the kept stream sets */
+    int32_t live_matchers;
+    int32_t live_streams;
+    int32_t live_events;
+    int32_t reserved;
+} osfm_memory_report;
+OSFM_API int osfm_library_memory(osfm_memory_report *out);
+
 /* The work arrays of the bundle-adjustment / triangulation / filter calls come from a
  * per-device cache of device memory (hipMalloc and hipFree cost 50-100 us apiece, dozens per
  * call, hundreds of calls per reconstruction); at most 8 GiB per device are kept.  This
@@ -278,6 +295,12 @@ typedef struct osfm_match_stats {
      * counter they took; cycles / ticks * 100 MHz = the clock the chip held under that kernel */
     double tile_shader_cycles;
     double tile_refclk_ticks;
+    /* the SURF (D = 64) share of tile_kernel_ms / tile_kernel_launches / mac_count: a view that carries both
+     * descriptor types (the application's FEATURE_ALL, matching_mve.cpp:333) runs one launch per type */
+    double surf_tile_kernel_ms;
+    int32_t surf_tile_kernel_launches;
+    int32_t reserved2;
+    int64_t surf_mac_count;
 } osfm_match_stats;
 OSFM_API int osfm_match_get_stats(const osfm_matcher *m, osfm_match_stats *out);
 

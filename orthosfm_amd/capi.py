@@ -67,7 +67,15 @@ class MatchStats(C.Structure):
                 ("lowres_kernel_launches", C.c_int32), ("reserved", C.c_int32),
                 ("lowres_mac_count", C.c_int64), ("cashash_kernel_ms", C.c_double),
                 ("cashash_kernel_launches", C.c_int32), ("special_kernel_launches", C.c_int32),
-                ("special_kernel_ms", C.c_double), ("tile_shader_cycles", C.c_double), ("tile_refclk_ticks", C.c_double)]
+                ("special_kernel_ms", C.c_double), ("tile_shader_cycles", C.c_double), ("tile_refclk_ticks", C.c_double),
+                ("surf_tile_kernel_ms", C.c_double), ("surf_tile_kernel_launches", C.c_int32), ("reserved2", C.c_int32),
+                ("surf_mac_count", C.c_int64)]
+
+
+class MemoryReport(C.Structure):
+    _fields_ = [("device_buffer_bytes", C.c_int64), ("pool_live_bytes", C.c_int64), ("pool_cached_bytes", C.c_int64),
+                ("pinned_host_bytes", C.c_int64), ("live_matchers", C.c_int32), ("live_streams", C.c_int32),
+                ("live_events", C.c_int32), ("reserved", C.c_int32)]
 
 
 class BaProblem(C.Structure):
@@ -115,7 +123,7 @@ class BaSummary(C.Structure):
 
 # every symbol include/osfm_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = [
-    "osfm_last_error", "osfm_version", "osfm_device_count", "osfm_device_memory", "osfm_trim_device_memory", "osfm_ransac_selfcheck", "osfm_ba_debug_chol_trace", "osfm_ba_debug_flow_spin_limit",
+    "osfm_last_error", "osfm_version", "osfm_device_count", "osfm_device_memory", "osfm_library_memory", "osfm_trim_device_memory", "osfm_ransac_selfcheck", "osfm_ba_debug_chol_trace", "osfm_ba_debug_flow_spin_limit",
     "osfm_match_options_default", "osfm_match_create", "osfm_match_create_multi", "osfm_match_get_devices", "osfm_match_destroy",
     "osfm_quantize_sift", "osfm_quantize_surf",
     "osfm_match_set_view", "osfm_match_set_view_float", "osfm_match_view_size", "osfm_match_set_positions",
@@ -199,6 +207,13 @@ def device_memory(device: int = 0):
     f, t = C.c_uint64(), C.c_uint64()
     check(lib.osfm_device_memory(device, C.byref(f), C.byref(t)))
     return f.value, t.value
+
+
+def library_memory() -> MemoryReport:
+    """What the library itself holds in this process (osfm_library_memory)."""
+    r = MemoryReport()
+    check(lib.osfm_library_memory(C.byref(r)))
+    return r
 
 
 def default_match_options() -> MatchOptions:

@@ -55,7 +55,7 @@ struct ViewData {
     // stream waits for it before a batch that names the view (uploads do not wait for matching and
     // matching does not wait for uploads of views it does not use)
     hipEvent_t ready = nullptr;
-    ~ViewData() { if (ready) (void)hipEventDestroy(ready); }
+    ~ViewData() { event_destroy(ready); }
     ViewData() = default;
     ViewData(const ViewData &) = delete;
     ViewData &operator=(const ViewData &) = delete;
@@ -245,7 +245,7 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
     bool needs_mask[2] = {false, false};   // some problem is limited below its view size
     bool any_special[2] = {false, false};  // some problem has gathered special rows
     bool any_c0[2] = {false, false}, any_corrected[2] = {false, false};
-    int64_t macs = 0, alg_bytes = 0;
+    int64_t macs = 0, alg_bytes = 0, macs_surf = 0;
     int64_t cas_queries[2] = {0, 0};
 
     for (int p = 0; p < num_pairs; ++p) {
@@ -375,6 +375,7 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
             if (!empty) {
                 const int dim = type == 0 ? 128 : 64;
                 macs += (int64_t)pr.n1 * pr.n2 * dim;
+                if (type == 1) macs_surf += (int64_t)pr.n1 * pr.n2 * dim;
                 alg_bytes += (int64_t)(pr.n1 + pr.n2) * (dim + 4);
             }
         }
@@ -540,6 +541,7 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
         } else {
             m->stats.tile_kernel_ms += ms;
             m->stats.tile_kernel_launches += 1;
+            if (type == 1) { m->stats.surf_tile_kernel_ms += ms; m->stats.surf_tile_kernel_launches += 1; }
         }
     }
     if (!(spjobs.empty() && spjobs_wide.empty())) {
@@ -555,6 +557,7 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
         m->stats.lowres_mac_count += macs;
     } else {
         m->stats.mac_count += macs;
+        m->stats.surf_mac_count += macs_surf;
         m->stats.algorithmic_bytes += alg_bytes;
     }
     return OSFM_OK;
@@ -594,9 +597,9 @@ int upload_view(osfm_matcher *m, int view, const uint16_t *sift, int n_sift, con
     const int ps = m->pin_next++ & 1;
     if (m->pin_used[ps]) OSFM_HIP_CHECK(hipEventSynchronize(m->pin_ev[ps]));
     if (m->pin_bytes[ps] < need) {
-        if (m->pin_ptr[ps]) (void)hipHostFree(m->pin_ptr[ps]);
+        pinned_free(m->pin_ptr[ps], m->pin_bytes[ps]);
         m->pin_ptr[ps] = nullptr; m->pin_bytes[ps] = 0;
-        OSFM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&m->pin_ptr[ps]), need + need / 4, hipHostMallocDefault));
+        OSFM_HIP_CHECK(pinned_alloc(reinterpret_cast<void **>(&m->pin_ptr[ps]), need + need / 4, hipHostMallocDefault));
         m->pin_bytes[ps] = need + need / 4;
     }
     char *pin = m->pin_ptr[ps];
@@ -674,7 +677,7 @@ int upload_view(osfm_matcher *m, int view, const uint16_t *sift, int n_sift, con
     OSFM_HIP_CHECK(hipGetLastError());
     OSFM_HIP_CHECK(hipEventRecord(m->pin_ev[ps], s));
     m->pin_used[ps] = true;
-    if (!v.ready) OSFM_HIP_CHECK(hipEventCreateWithFlags(&v.ready, hipEventDisableTiming));
+    if (!v.ready) OSFM_HIP_CHECK(event_create(&v.ready, false));
     OSFM_HIP_CHECK(hipEventRecord(v.ready, s));
     v.surf_norm2_max = (int)std::min<long long>(norm2_max, 0x7fffffff);
     v.set = true;
@@ -870,9 +873,9 @@ int multi_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm
         osfm_matcher::Staging &sg = m->shard_stage[k];
         const size_t need = (size_t)std::max<int64_t>(sub_cap[k], 1) * 2;
         if (sg.ints < need) {
-            if (sg.ptr) (void)hipHostFree(sg.ptr);
+            pinned_free(sg.ptr, sg.ints * 4);
             sg.ptr = nullptr; sg.ints = 0;
-            OSFM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&sg.ptr), (need + need / 8) * 4, hipHostMallocPortable));
+            OSFM_HIP_CHECK(pinned_alloc(reinterpret_cast<void **>(&sg.ptr), (need + need / 8) * 4, hipHostMallocPortable));
             sg.ints = need + need / 8;
         }
         const int r = osfm_match_all(m->shards[k], sub_pairs[k].data(), (int)sub_pairs[k].size(), sub_res[k].data(),
@@ -983,6 +986,20 @@ int osfm_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes)
     return OSFM_OK;
 }
 
+int osfm_library_memory(osfm_memory_report *out)
+{
+    if (!out) { set_error("library_memory: null"); return OSFM_E_ARG; }
+    out->device_buffer_bytes = g_ledger.device_buffer_bytes.load();
+    out->pool_live_bytes = g_ledger.pool_live_bytes.load();
+    out->pool_cached_bytes = g_ledger.pool_cached_bytes.load();
+    out->pinned_host_bytes = g_ledger.pinned_host_bytes.load();
+    out->live_matchers = g_ledger.live_matchers.load();
+    out->live_streams = g_ledger.live_streams.load();
+    out->live_events = g_ledger.live_events.load();
+    out->reserved = 0;
+    return OSFM_OK;
+}
+
 int osfm_match_options_default(osfm_match_options *o)
 {
     if (!o) { set_error("options_default: null"); return OSFM_E_ARG; }
@@ -1021,22 +1038,22 @@ int osfm_match_create(int device, int num_views, const osfm_match_options *opts,
     }
     OSFM_HIP_CHECK(hipSetDevice(device));
     // owned until the last step succeeded: an error return frees everything made so far
-    struct Owner { osfm_matcher *p; ~Owner() { if (p) osfm_match_destroy(p); } } owner{new osfm_matcher()};
+    struct Owner { osfm_matcher *p; ~Owner() { if (p) osfm_match_destroy(p); } } owner{(g_ledger.live_matchers++, new osfm_matcher())};
     osfm_matcher *m = owner.p;
     m->device = device;
     if (opts) m->opts = *opts; else osfm_match_options_default(&m->opts);
     m->views = std::vector<ViewData>(num_views);
     reset_stats(m);
-    OSFM_HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    OSFM_HIP_CHECK(stream_create(&m->stream));
     for (int i = 0; i < 2; ++i)
-        for (int j = 0; j < 2; ++j) OSFM_HIP_CHECK(hipEventCreate(&m->ev[i][j]));
-    for (int j = 0; j < 2; ++j) OSFM_HIP_CHECK(hipEventCreate(&m->ev_sp[j]));
-    for (int j = 0; j < 2; ++j) OSFM_HIP_CHECK(hipEventCreateWithFlags(&m->pin_ev[j], hipEventDisableTiming));
-    OSFM_HIP_CHECK(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
-    OSFM_HIP_CHECK(hipStreamCreateWithFlags(&m->up_stream, hipStreamNonBlocking));
+        for (int j = 0; j < 2; ++j) OSFM_HIP_CHECK(event_create(&m->ev[i][j], true));
+    for (int j = 0; j < 2; ++j) OSFM_HIP_CHECK(event_create(&m->ev_sp[j], true));
+    for (int j = 0; j < 2; ++j) OSFM_HIP_CHECK(event_create(&m->pin_ev[j], false));
+    OSFM_HIP_CHECK(stream_create(&m->copy_stream));
+    OSFM_HIP_CHECK(stream_create(&m->up_stream));
     for (int j = 0; j < 2; ++j) {
-        OSFM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_compact[j], hipEventDisableTiming));
-        OSFM_HIP_CHECK(hipEventCreateWithFlags(&m->ev_copied[j], hipEventDisableTiming));
+        OSFM_HIP_CHECK(event_create(&m->ev_compact[j], false));
+        OSFM_HIP_CHECK(event_create(&m->ev_copied[j], false));
     }
     // at most 512: the finish kernel's scan of the special rows keys them with nine bits
     if (m->opts.special_kernel_max != 0) m->special_max = std::min(std::max(m->opts.special_kernel_max, 0), 512);
@@ -1063,7 +1080,7 @@ int osfm_match_create_multi(const int *device_ids, int num_devices, int num_view
 {
     if (!out || !device_ids || num_devices < 1 || num_views < 0) { set_error("match_create_multi: bad arguments"); return OSFM_E_ARG; }
     *out = nullptr;
-    struct Owner { osfm_matcher *p; ~Owner() { if (p) osfm_match_destroy(p); } } owner{new osfm_matcher()};
+    struct Owner { osfm_matcher *p; ~Owner() { if (p) osfm_match_destroy(p); } } owner{(g_ledger.live_matchers++, new osfm_matcher())};
     osfm_matcher *m = owner.p;
     m->device = device_ids[0];
     if (opts) m->opts = *opts; else osfm_match_options_default(&m->opts);
@@ -1093,29 +1110,29 @@ int osfm_match_destroy(osfm_matcher *m)
     if (!m) return OSFM_OK;
     if (!m->shards.empty() || !m->shard_stage.empty()) {
         for (auto *sh : m->shards) osfm_match_destroy(sh);
-        for (auto &sg : m->shard_stage) if (sg.ptr) (void)hipHostFree(sg.ptr);
+        for (auto &sg : m->shard_stage) pinned_free(sg.ptr, sg.ints * 4);
+        g_ledger.live_matchers--;
         delete m;
         return OSFM_OK;
     }
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     for (int i = 0; i < 2; ++i)
-        for (int j = 0; j < 2; ++j)
-            if (m->ev[i][j]) (void)hipEventDestroy(m->ev[i][j]);
-    for (int j = 0; j < 2; ++j)
-        if (m->ev_sp[j]) (void)hipEventDestroy(m->ev_sp[j]);
+        for (int j = 0; j < 2; ++j) event_destroy(m->ev[i][j]);
+    for (int j = 0; j < 2; ++j) event_destroy(m->ev_sp[j]);
     for (int j = 0; j < 2; ++j) {
-        if (m->pin_ev[j]) (void)hipEventDestroy(m->pin_ev[j]);
-        if (m->pin_ptr[j]) (void)hipHostFree(m->pin_ptr[j]);
+        event_destroy(m->pin_ev[j]);
+        pinned_free(m->pin_ptr[j], m->pin_bytes[j]);
     }
-    if (m->copy_stream) { (void)hipStreamSynchronize(m->copy_stream); (void)hipStreamDestroy(m->copy_stream); }
-    if (m->up_stream) { (void)hipStreamSynchronize(m->up_stream); (void)hipStreamDestroy(m->up_stream); }
+    stream_destroy(m->copy_stream);
+    stream_destroy(m->up_stream);
     for (int j = 0; j < 2; ++j) {
-        if (m->ev_compact[j]) (void)hipEventDestroy(m->ev_compact[j]);
-        if (m->ev_copied[j]) (void)hipEventDestroy(m->ev_copied[j]);
+        event_destroy(m->ev_compact[j]);
+        event_destroy(m->ev_copied[j]);
     }
-    if (m->stream) (void)hipStreamDestroy(m->stream);
-    for (auto *sg : m->comb_staging) { if (sg->ptr) (void)hipHostFree(sg->ptr); delete sg; }
+    stream_destroy(m->stream);
+    for (auto *sg : m->comb_staging) { pinned_free(sg->ptr, sg->ints * 4); delete sg; }
+    g_ledger.live_matchers--;
     delete m;       // every DeviceBuffer (views, scratch, cascade-hashing data) frees itself
     return OSFM_OK;
 }
@@ -1292,9 +1309,9 @@ void serve_requests(osfm_matcher *m, const std::vector<osfm_matcher::PairRequest
     const size_t need = (size_t)std::max<int64_t>(res.out_ints, 4);
     hipError_t e = hipSuccess;
     if (stage->ints < need) {
-        if (stage->ptr) (void)hipHostFree(stage->ptr);
+        pinned_free(stage->ptr, stage->ints * 4);
         stage->ptr = nullptr; stage->ints = 0;
-        e = hipHostMalloc(reinterpret_cast<void **>(&stage->ptr), (need + need / 4) * 4, hipHostMallocDefault);
+        e = pinned_alloc(reinterpret_cast<void **>(&stage->ptr), (need + need / 4) * 4, hipHostMallocDefault);
         if (e == hipSuccess) stage->ints = need + need / 4;
     }
     if (e == hipSuccess) e = hipMemcpyAsync(stage->ptr, m->out.ptr, need * 4, hipMemcpyDeviceToHost, m->stream);
@@ -1697,6 +1714,8 @@ int osfm_match_get_stats(const osfm_matcher *m, osfm_match_stats *out)
             out->cashash_kernel_ms += t.cashash_kernel_ms; out->cashash_kernel_launches += t.cashash_kernel_launches;
             out->special_kernel_launches += t.special_kernel_launches; out->special_kernel_ms += t.special_kernel_ms;
             out->tile_shader_cycles += t.tile_shader_cycles; out->tile_refclk_ticks += t.tile_refclk_ticks;
+            out->surf_tile_kernel_ms += t.surf_tile_kernel_ms; out->surf_tile_kernel_launches += t.surf_tile_kernel_launches;
+            out->surf_mac_count += t.surf_mac_count;
         }
         return OSFM_OK;
     }

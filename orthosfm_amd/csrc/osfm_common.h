@@ -1,6 +1,8 @@
 // Shared host helpers: error reporting and a grow-only device buffer.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <map>
@@ -31,6 +33,59 @@ void set_error(const char *fmt, ...);
         if (_s != OSFM_OK) return _s; \
     } while (0)
 
+// What the library itself holds (osfm_library_memory): every allocation path below books here, so that a handle
+// that does not give its memory back shows as a number that stays up after its destroy -- whatever the runtime
+// keeps in pools of its own (which the free-memory reading of hipMemGetInfo cannot tell apart from a leak).
+struct MemoryLedger {
+    std::atomic<long long> device_buffer_bytes{0};   // DeviceBuffer: grow-only device memory owned by live handles
+    std::atomic<long long> pool_live_bytes{0};       // DevicePool blocks handed out (calls in flight)
+    std::atomic<long long> pool_cached_bytes{0};     // DevicePool blocks kept for reuse
+    std::atomic<long long> pinned_host_bytes{0};     // page-locked host staging
+    std::atomic<int> live_matchers{0}, live_streams{0}, live_events{0};
+};
+inline MemoryLedger g_ledger;
+
+inline hipError_t pinned_alloc(void **p, size_t bytes, unsigned flags)
+{
+    const hipError_t e = hipHostMalloc(p, bytes, flags);
+    if (e == hipSuccess) g_ledger.pinned_host_bytes += (long long)bytes;
+    return e;
+}
+inline void pinned_free(void *p, size_t bytes)
+{
+    if (!p) return;
+    (void)hipHostFree(p);
+    g_ledger.pinned_host_bytes -= (long long)bytes;
+}
+inline hipError_t stream_create(hipStream_t *s)
+{
+    const hipError_t e = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    if (e == hipSuccess) g_ledger.live_streams++;
+    return e;
+}
+inline void stream_destroy(hipStream_t s)
+{
+    if (!s) return;
+    (void)hipStreamSynchronize(s);
+    (void)hipStreamDestroy(s);
+    g_ledger.live_streams--;
+}
+inline hipError_t event_create(hipEvent_t *e, bool timing)
+{
+    const hipError_t r = timing ? hipEventCreate(e) : hipEventCreateWithFlags(e, hipEventDisableTiming);
+    if (r == hipSuccess) g_ledger.live_events++;
+    return r;
+}
+inline void event_destroy(hipEvent_t e)
+{
+    if (!e) return;
+    (void)hipEventDestroy(e);
+    g_ledger.live_events--;
+}
+
+struct DevicePool;
+size_t device_pool_trim(int device);       // (defined behind DevicePool: DeviceBuffer retries through it)
+
 // Device allocation that only ever grows; contents are NOT preserved on growth.
 // Owns its memory: freed by the destructor (or release()); movable, not copyable.
 struct DeviceBuffer {
@@ -49,15 +104,23 @@ struct DeviceBuffer {
     int reserve(size_t need)
     {
         if (need <= bytes) return OSFM_OK;
-        if (ptr) { (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
+        release();
         size_t want = need + need / 8 + 256;
-        OSFM_HIP_CHECK(hipMalloc(&ptr, want));
+        hipError_t e = hipMalloc(&ptr, want);
+        if (e != hipSuccess) {
+            // out of memory while the work-array cache of this device holds blocks nobody uses: hand them back, once
+            (void)hipGetLastError();
+            int device = 0;
+            if (hipGetDevice(&device) == hipSuccess && device_pool_trim(device) > 0) e = hipMalloc(&ptr, want);
+        }
+        OSFM_HIP_CHECK(e);
         bytes = want;
+        g_ledger.device_buffer_bytes += (long long)bytes;
         return OSFM_OK;
     }
     void release()
     {
-        if (ptr) (void)hipFree(ptr);
+        if (ptr) { (void)hipFree(ptr); g_ledger.device_buffer_bytes -= (long long)bytes; }
         ptr = nullptr; bytes = 0;
     }
     template <typename T> T *as() const { return static_cast<T *>(ptr); }
@@ -69,9 +132,22 @@ struct DeviceBuffer {
 // thirds of a global-adjustment call inside the incremental reconstruction.  Blocks handed
 // back are kept, by size class (steps of 1/8 of a power of two, at most 12.5 % slack), and
 // given out again; osfm_trim_device_memory() returns them to the driver.  What is kept is
-// bounded (kPoolKeepBytes per device); beyond it a block is freed at once.
+// bounded per device -- a sixth of the card, at most 48 GB (the work arrays of a 500-view global adjustment are
+// ~6 GB; on a 288 GB card the bound is the 48) --; beyond it a block is freed at once.
 struct DevicePool {
-    static constexpr size_t kPoolKeepBytes = (size_t)48 << 30;   // of 288 GB: the work arrays of a 500-view global adjustment are ~6 GB
+    static constexpr size_t kPoolKeepMax = (size_t)48 << 30;
+    std::unordered_map<int, size_t> keep_limit;                             // per device, from hipMemGetInfo on first use
+    size_t keep_bytes(int device)          // caller holds the mutex
+    {
+        auto it = keep_limit.find(device);
+        if (it != keep_limit.end()) return it->second;
+        size_t free_b = 0, total_b = 0, lim = kPoolKeepMax;
+        int cur = 0;
+        if (hipGetDevice(&cur) == hipSuccess && cur == device && hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b)
+            lim = std::min(kPoolKeepMax, total_b / 6);
+        keep_limit[device] = lim;
+        return lim;
+    }
     struct Block { void *ptr; size_t bytes; };
     std::mutex mutex;
     std::unordered_map<int, std::multimap<size_t, void *>> free_blocks;    // device -> size class -> blocks
@@ -99,6 +175,7 @@ struct DevicePool {
                 fb.erase(it);
                 kept[device] -= cls;
                 live[*out] = {device, cls};
+                g_ledger.pool_cached_bytes -= (long long)cls; g_ledger.pool_live_bytes += (long long)cls;
                 return OSFM_OK;
             }
         }
@@ -112,6 +189,7 @@ struct DevicePool {
         OSFM_HIP_CHECK(e);
         std::lock_guard<std::mutex> lock(mutex);
         live[*out] = {device, cls};
+        g_ledger.pool_live_bytes += (long long)cls;
         return OSFM_OK;
     }
     void free(void *ptr)
@@ -125,9 +203,11 @@ struct DevicePool {
             if (it != live.end()) {
                 device = it->second.first; cls = it->second.second;
                 live.erase(it);
-                if (kept[device] + cls <= kPoolKeepBytes) {
+                g_ledger.pool_live_bytes -= (long long)cls;
+                if (kept[device] + cls <= keep_bytes(device)) {
                     free_blocks[device].emplace(cls, ptr);
                     kept[device] += cls;
+                    g_ledger.pool_cached_bytes += (long long)cls;
                     return;
                 }
             }
@@ -149,10 +229,12 @@ struct DevicePool {
             }
         }
         for (void *p : victims) (void)hipFree(p);
+        g_ledger.pool_cached_bytes -= (long long)bytes;
         return bytes;
     }
 };
 inline DevicePool g_device_pool;
+inline size_t device_pool_trim(int device) { return g_device_pool.trim(device); }
 
 // Blocks released while a stream lease is active on this thread may still be in use by
 // work queued on that stream (an error path returns with kernels in flight); they go back
@@ -203,8 +285,8 @@ struct StreamSet {
     int ensure_pinned(size_t bytes)
     {
         if (bytes <= pinned_bytes) return OSFM_OK;
-        if (pinned) { (void)hipHostFree(pinned); pinned = nullptr; pinned_bytes = 0; }
-        OSFM_HIP_CHECK(hipHostMalloc(&pinned, bytes, hipHostMallocDefault));
+        if (pinned) { pinned_free(pinned, pinned_bytes); pinned = nullptr; pinned_bytes = 0; }
+        OSFM_HIP_CHECK(pinned_alloc(&pinned, bytes, hipHostMallocDefault));
         pinned_bytes = bytes;
         return OSFM_OK;
     }
@@ -212,7 +294,7 @@ struct StreamSet {
     {
         while (events.size() < n) {
             hipEvent_t e = nullptr;
-            OSFM_HIP_CHECK(hipEventCreate(&e));
+            OSFM_HIP_CHECK(event_create(&e, true));
             events.push_back(e);
         }
         return OSFM_OK;
@@ -245,14 +327,14 @@ struct StreamLease {
         if (!set) {
             StreamSet *n = new StreamSet;
             n->device = device;
-            hipError_t e = hipStreamCreateWithFlags(&n->s, hipStreamNonBlocking);
+            hipError_t e = stream_create(&n->s);
             for (auto &p : n->ev) {
-                if (e == hipSuccess) e = hipEventCreate(&p.a);
-                if (e == hipSuccess) e = hipEventCreate(&p.b);
+                if (e == hipSuccess) e = event_create(&p.a, true);
+                if (e == hipSuccess) e = event_create(&p.b, true);
             }
             if (e != hipSuccess) {
-                for (auto &p : n->ev) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
-                if (n->s) (void)hipStreamDestroy(n->s);
+                for (auto &p : n->ev) { event_destroy(p.a); event_destroy(p.b); }
+                stream_destroy(n->s);
                 delete n;
                 OSFM_HIP_CHECK(e);
             }
