@@ -303,6 +303,9 @@ typedef struct osfm_match_stats {
     int64_t surf_mac_count;
 } osfm_match_stats;
 OSFM_API int osfm_match_get_stats(const osfm_matcher *m, osfm_match_stats *out);
+/* The same record of ONE shard of a multi-device matcher (osfm_match_create_multi; shard 0 of a single-device
+ * one): what that device did in the most recent call -- the balance of the deal can be read off mac_count. */
+OSFM_API int osfm_match_get_shard_stats(const osfm_matcher *m, int shard, osfm_match_stats *out);
 
 /* CascadeHashing::LocalData of one view (cascade_hashing.h:146-168), computed on
  * demand: hashes [n][2] (SIFT, type 0) or [n][1] (SURF, type 1) 64-bit words,

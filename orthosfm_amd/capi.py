@@ -129,7 +129,7 @@ EXPORTS = [
     "osfm_match_set_view", "osfm_match_set_view_float", "osfm_match_view_size", "osfm_match_set_positions",
     "osfm_ransac_options_default", "osfm_ransac_fundamental",
     "osfm_match_pair", "osfm_match_pair_lowres", "osfm_match_twoway", "osfm_match_all",
-    "osfm_pair_from_index", "osfm_match_get_stats", "osfm_match_get_cascade_hashes",
+    "osfm_pair_from_index", "osfm_match_get_stats", "osfm_match_get_shard_stats", "osfm_match_get_cascade_hashes",
     "osfm_ba_options_default", "osfm_ba_solve", "osfm_ba_reprojection_errors",
     "osfm_ba_triangulate",
     "osfm_nn_distances", "osfm_filter_outlier_tracks", "osfm_filter_reprojection",

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <queue>
 #include <thread>
@@ -787,6 +788,10 @@ void reset_stats(osfm_matcher *m) { memset(&m->stats, 0, sizeof(m->stats)); }
 // ---------------------------------------------------------------------------
 namespace {
 
+enum { kPhaseBoth = 0, kPhaseGate = 1, kPhaseFull = 2 };
+int match_all_single(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_pair_result *results,
+    int32_t *corr, int64_t capacity, int64_t *total, int phase);
+
 template <class F>
 int for_each_shard(osfm_matcher *m, F &&fn)
 {
@@ -810,39 +815,47 @@ int for_each_shard(osfm_matcher *m, F &&fn)
     return OSFM_OK;
 }
 
-// Longest processing time first on N1 * N2 (known up front); ties go to the lower shard.
-// Equal work everywhere degenerates to round robin, as in distributed.py.
-void deal_pairs_lpt(const osfm_matcher *m, const osfm_pair *pairs, int num_pairs, std::vector<std::vector<int>> *owner)
+// Longest processing time first on N1 * N2 over the pairs `cand` (ascending pair indices); ties go to the lower
+// shard.  Equal work everywhere degenerates to round robin, as in distributed.py.
+void deal_pairs_lpt(const osfm_matcher *m, const osfm_pair *pairs, const std::vector<int> &cand, std::vector<std::vector<int>> *owner)
 {
     const int n = (int)m->shards.size();
     owner->assign(n, {});
     const auto &views = m->shards[0]->views;
-    std::vector<int64_t> w(num_pairs);
+    const int nc = (int)cand.size();
+    std::vector<int64_t> w(nc);
     bool uniform = true;
-    for (int p = 0; p < num_pairs; ++p) {
-        const ViewData &a = views[pairs[p].view_1], &b = views[pairs[p].view_2];
-        w[p] = (int64_t)(a.ns + a.nu) * (int64_t)(b.ns + b.nu);
-        uniform &= w[p] == w[0];
+    for (int i = 0; i < nc; ++i) {
+        const ViewData &a = views[pairs[cand[i]].view_1], &b = views[pairs[cand[i]].view_2];
+        w[i] = (int64_t)(a.ns + a.nu) * (int64_t)(b.ns + b.nu);
+        uniform &= w[i] == w[0];
     }
     if (uniform) {
-        for (int p = 0; p < num_pairs; ++p) (*owner)[p % n].push_back(p);
+        for (int i = 0; i < nc; ++i) (*owner)[i % n].push_back(cand[i]);
         return;
     }
-    std::vector<int> order(num_pairs);
-    for (int p = 0; p < num_pairs; ++p) order[p] = p;
+    std::vector<int> order(nc);
+    for (int i = 0; i < nc; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return w[x] > w[y]; });
     typedef std::pair<int64_t, int> Load;
     std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
     for (int k = 0; k < n; ++k) heap.push({0, k});
-    std::vector<int> own(num_pairs);
-    for (int p : order) {
+    std::vector<int> own(nc);
+    for (int i : order) {
         Load l = heap.top(); heap.pop();
-        own[p] = l.second;
-        heap.push({l.first + w[p], l.second});
+        own[i] = l.second;
+        heap.push({l.first + w[i], l.second});
     }
-    for (int p = 0; p < num_pairs; ++p) (*owner)[own[p]].push_back(p);      // ascending inside a shard
+    for (int i = 0; i < nc; ++i) (*owner)[own[i]].push_back(cand[i]);      // ascending inside a shard
 }
 
+// Two rounds, each dealt by what it costs.  The low-res gate (bundler_matching.cc:146-158: 500 x 500 features per
+// pair, 1 / 1600 of a full match) goes round robin over ALL pairs; what it lets through -- on real image sets the
+// survivors follow the scene, not the pair index: views of another scene reject whole rows of the pair matrix --
+// is then dealt longest-first on N1 * N2 for the full matching.  (One deal before the gate balanced the weights
+// of pairs of which a structured third was never matched.)  The shard threads live through both rounds and the
+// copy of the lists: a barrier between the rounds (the survivors of all shards are dealt together) and one behind
+// the counts (a list's place in the caller's buffer follows from the counts of every pair before it).
 int multi_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_pair_result *results,
     int32_t *corr, int64_t capacity, int64_t *total)
 {
@@ -852,60 +865,112 @@ int multi_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm
         OSFM_RETURN_IF(check_view(m->shards[0], pairs[p].view_1, "match_all"));
         OSFM_RETURN_IF(check_view(m->shards[0], pairs[p].view_2, "match_all"));
     }
-    std::vector<std::vector<int>> owner;
-    deal_pairs_lpt(m, pairs, num_pairs, &owner);
+    const auto &views = m->shards[0]->views;
+    const bool verify = m->opts.geometric_verification != 0;
+    std::vector<std::vector<int>> owner(n);                   // round 2: pairs of each shard, ascending
     std::vector<std::vector<osfm_pair>> sub_pairs(n);
     std::vector<std::vector<osfm_pair_result>> sub_res(n);
     std::vector<int64_t> sub_total(n, 0), sub_cap(n, 0);
     std::vector<int> sub_status(n, OSFM_OK);
-    const auto &views = m->shards[0]->views;
-    for (int k = 0; k < n; ++k) {
-        int64_t bound = 0;      // a pair has at most min(features of either view) mutual matches
-        for (int p : owner[k]) {
-            sub_pairs[k].push_back(pairs[p]);
-            const ViewData &a = views[pairs[p].view_1], &b = views[pairs[p].view_2];
-            bound += std::min(a.ns + a.nu, b.ns + b.nu);
+    std::vector<int64_t> goff(num_pairs, 0);                  // a pair's list inside its shard's block
+    int64_t run = 0;
+    bool overflow = false;
+
+    // a barrier for the n shard threads; the last one to arrive runs `serial` before anyone leaves
+    std::mutex bmu;
+    std::condition_variable bcv;
+    int waiting = 0, generation = 0;
+    bool failed = false;                                      // a shard has failed: the others stop at the next barrier
+    auto barrier = [&](bool ok, const std::function<void()> &serial) -> bool {
+        std::unique_lock<std::mutex> lk(bmu);
+        if (!ok) failed = true;
+        if (++waiting == n) {
+            if (!failed) serial();
+            waiting = 0; ++generation;
+            bcv.notify_all();
+        } else {
+            const int gen = generation;
+            bcv.wait(lk, [&] { return generation != gen; });
         }
-        sub_res[k].resize(owner[k].size());
-        sub_cap[k] = std::min(bound, capacity);
-    }
-    int st = for_each_shard(m, [&](size_t k) -> int {
+        return !failed;
+    };
+
+    const int st = for_each_shard(m, [&](size_t k) -> int {
+        // ---- round 1: the gate of every n-th pair ----
+        std::vector<osfm_pair> gp;
+        std::vector<int> gidx;
+        for (int p = (int)k; p < num_pairs; p += n) { gp.push_back(pairs[p]); gidx.push_back(p); }
+        std::vector<osfm_pair_result> gres(gp.size());
+        int r = match_all_single(m->shards[k], gp.data(), (int)gp.size(), gres.data(), nullptr, 0, nullptr, kPhaseGate);
+        if (r == OSFM_OK) for (size_t i = 0; i < gidx.size(); ++i) results[gidx[i]] = gres[i];
+        if (!barrier(r == OSFM_OK, [&] {
+                // the survivors of all shards, dealt by the work they are
+                std::vector<int> cand;
+                for (int p = 0; p < num_pairs; ++p) if (results[p].status == OSFM_PAIR_MATCHED) cand.push_back(p);
+                deal_pairs_lpt(m, pairs, cand, &owner);
+                for (int q = 0; q < n; ++q) {
+                    int64_t bound = 0;      // a pair has at most min(features of either view) mutual matches
+                    for (int p : owner[q]) {
+                        sub_pairs[q].push_back(pairs[p]);
+                        sub_res[q].push_back(results[p]);
+                        const ViewData &a = views[pairs[p].view_1], &b = views[pairs[p].view_2];
+                        bound += std::min(a.ns + a.nu, b.ns + b.nu);
+                    }
+                    sub_cap[q] = std::min(bound, capacity);
+                }
+            }))
+            return r;
+        // ---- round 2: full matching (and RANSAC-F) of this shard's survivors into its own page-locked block ----
         osfm_matcher::Staging &sg = m->shard_stage[k];
         const size_t need = (size_t)std::max<int64_t>(sub_cap[k], 1) * 2;
+        r = OSFM_OK;
         if (sg.ints < need) {
             pinned_free(sg.ptr, sg.ints * 4);
             sg.ptr = nullptr; sg.ints = 0;
-            OSFM_HIP_CHECK(pinned_alloc(reinterpret_cast<void **>(&sg.ptr), (need + need / 8) * 4, hipHostMallocPortable));
-            sg.ints = need + need / 8;
+            if (pinned_alloc(reinterpret_cast<void **>(&sg.ptr), (need + need / 8) * 4, hipHostMallocPortable) != hipSuccess) {
+                set_error("match_all: no page-locked memory for the lists of device %d", m->shards[k]->device);
+                r = OSFM_E_DEVICE;
+            } else sg.ints = need + need / 8;
         }
-        const int r = osfm_match_all(m->shards[k], sub_pairs[k].data(), (int)sub_pairs[k].size(), sub_res[k].data(),
-            sg.ptr, sub_cap[k], &sub_total[k]);
-        // a shard that runs out of room has still classified and counted every pair
-        sub_status[k] = r;
-        return r == OSFM_E_CAPACITY ? OSFM_OK : r;
+        if (r == OSFM_OK) {
+            r = match_all_single(m->shards[k], sub_pairs[k].data(), (int)sub_pairs[k].size(), sub_res[k].data(),
+                sg.ptr, sub_cap[k], &sub_total[k], kPhaseFull);
+            // a shard that runs out of room has still classified and counted every pair
+            sub_status[k] = r;
+            if (r == OSFM_E_CAPACITY) r = OSFM_OK;
+        }
+        if (!barrier(r == OSFM_OK, [&] {
+                // every count is known: the lists' places in the caller's buffer, in pair order
+                std::vector<size_t> pos(n, 0);
+                std::vector<int> own(num_pairs, -1);
+                for (int q = 0; q < n; ++q) for (int p : owner[q]) own[p] = q;
+                for (int p = 0; p < num_pairs; ++p) {
+                    const int q = own[p];
+                    if (q < 0) continue;                       // stopped at the gate (or empty): as round 1 left it
+                    results[p] = sub_res[q][pos[q]++];
+                    const int64_t local = results[p].offset;
+                    results[p].offset = 0;
+                    if (results[p].status == OSFM_PAIR_MATCHED) {
+                        results[p].offset = run;
+                        goff[p] = local;
+                        run += verify ? results[p].num_inliers : results[p].num_matches;
+                    }
+                }
+                overflow = run > capacity;
+                for (int q = 0; q < n; ++q) overflow |= sub_status[q] == OSFM_E_CAPACITY;
+            }))
+            return r;
+        if (overflow) return OSFM_OK;
+        // ---- this shard's lists to their places ----
+        const int32_t *src = sg.ptr;
+        for (int p : owner[k]) {
+            if (results[p].status != OSFM_PAIR_MATCHED) continue;
+            const int64_t cnt = verify ? results[p].num_inliers : results[p].num_matches;
+            if (cnt > 0) memcpy(corr + 2 * results[p].offset, src + 2 * goff[p], (size_t)cnt * 8);
+        }
+        return OSFM_OK;
     });
     if (st != OSFM_OK) return st;
-    const bool verify = m->opts.geometric_verification != 0;
-    int64_t run = 0;
-    std::vector<int64_t> goff(num_pairs, 0);
-    {
-        std::vector<size_t> pos(n, 0);
-        std::vector<int> own(num_pairs, 0);
-        for (int k = 0; k < n; ++k) for (int p : owner[k]) own[p] = k;
-        for (int p = 0; p < num_pairs; ++p) {
-            const int k = own[p];
-            results[p] = sub_res[k][pos[k]++];
-            const int64_t local = results[p].offset;
-            results[p].offset = 0;
-            if (results[p].status == OSFM_PAIR_MATCHED) {
-                results[p].offset = run;
-                goff[p] = local;
-                run += verify ? results[p].num_inliers : results[p].num_matches;
-            }
-        }
-    }
-    bool overflow = run > capacity;
-    for (int k = 0; k < n; ++k) overflow |= sub_status[k] == OSFM_E_CAPACITY;
     if (total) {
         // on overflow every shard reports what it needs: the required total
         int64_t need = 0;
@@ -917,16 +982,7 @@ int multi_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm
             (long long)(total ? *total : run), (long long)capacity);
         return OSFM_E_CAPACITY;
     }
-    // every shard copies its own lists to their places (pair order) in the caller's buffer
-    return for_each_shard(m, [&](size_t k) -> int {
-        const int32_t *src = m->shard_stage[k].ptr;
-        for (int p : owner[k]) {
-            if (results[p].status != OSFM_PAIR_MATCHED) continue;
-            const int64_t cnt = verify ? results[p].num_inliers : results[p].num_matches;
-            if (cnt > 0) memcpy(corr + 2 * results[p].offset, src + 2 * goff[p], (size_t)cnt * 8);
-        }
-        return OSFM_OK;
-    });
+    return OSFM_OK;
 }
 
 }  // namespace
@@ -1460,9 +1516,23 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
         return OSFM_E_ARG;
     }
     if (!m->shards.empty()) return multi_match_all(m, pairs, num_pairs, results, corr, capacity, total);
+    return match_all_single(m, pairs, num_pairs, results, corr, capacity, total, kPhaseBoth);
+}
+
+}  // extern "C"
+
+namespace {
+
+// bundler::Matching::compute on one device.  phase: kPhaseBoth -- the whole of it; kPhaseGate -- classification and
+// the low-res gate only (a pair that goes on to full matching is left at OSFM_PAIR_MATCHED with its lowres_matches);
+// kPhaseFull -- full matching (and RANSAC-F) of the pairs whose result arrives as OSFM_PAIR_MATCHED, everything else
+// is left as it is.  The multi-device front runs the two halves as two rounds with a deal of their own each.
+int match_all_single(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_pair_result *results,
+    int32_t *corr, int64_t capacity, int64_t *total, int phase)
+{
     std::lock_guard<std::mutex> lock(m->mu);
     OSFM_HIP_CHECK(hipSetDevice(m->device));
-    reset_stats(m);
+    if (phase != kPhaseFull) reset_stats(m);
     const osfm_match_options &o = m->opts;
     // whatever way this call ends, no copy into the caller's buffer is still in flight afterwards
     struct CopyDrain { hipStream_t s; ~CopyDrain() { if (s) (void)hipStreamSynchronize(s); } } copy_drain{m->copy_stream};
@@ -1474,6 +1544,10 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
         OSFM_RETURN_IF(check_view(m, pairs[p].view_2, "match_all"));
         const ViewData &a = m->views[pairs[p].view_1], &b = m->views[pairs[p].view_2];
         osfm_pair_result &r = results[p];
+        if (phase == kPhaseFull) {
+            if (r.status == OSFM_PAIR_MATCHED) full_idx.push_back(p);
+            continue;
+        }
         r.status = OSFM_PAIR_MATCHED; r.lowres_matches = -1; r.num_matches = 0; r.num_inliers = -1; r.offset = 0;
         const size_t np1 = (size_t)a.ns + a.nu, np2 = (size_t)b.ns + b.nu;
         if (np1 == 0 || np2 == 0) { r.status = OSFM_PAIR_SKIPPED_EMPTY; continue; }
@@ -1528,6 +1602,7 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
         }
         std::sort(full_idx.begin(), full_idx.end());
     }
+    if (phase == kPhaseGate) { if (total) *total = 0; return OSFM_OK; }
 
     // ---- full matching + ordered correspondence lists -----------------------
     const int min_matches = std::max(8, o.min_feature_matches);
@@ -1680,6 +1755,10 @@ int osfm_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm_
     return OSFM_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
 int osfm_match_get_cascade_hashes(osfm_matcher *m, int view, int type, uint64_t *hashes,
     uint8_t *bucket_ids)
 {
@@ -1696,6 +1775,15 @@ int osfm_match_get_cascade_hashes(osfm_matcher *m, int view, int type, uint64_t 
         OSFM_HIP_CHECK(hipMemcpy(hashes, v.cas_hash[type].ptr, (size_t)n * words * 8, hipMemcpyDeviceToHost));
     if (n > 0 && bucket_ids)
         OSFM_HIP_CHECK(hipMemcpy(bucket_ids, v.cas_bucket[type].ptr, (size_t)n * kCasGroups, hipMemcpyDeviceToHost));
+    return OSFM_OK;
+}
+
+int osfm_match_get_shard_stats(const osfm_matcher *m, int shard, osfm_match_stats *out)
+{
+    if (!m || !out) { set_error("get_shard_stats: null argument"); return OSFM_E_ARG; }
+    const int n = m->shards.empty() ? 1 : (int)m->shards.size();
+    if (shard < 0 || shard >= n) { set_error("get_shard_stats: shard %d of %d", shard, n); return OSFM_E_ARG; }
+    *out = m->shards.empty() ? m->stats : m->shards[shard]->stats;
     return OSFM_OK;
 }
 

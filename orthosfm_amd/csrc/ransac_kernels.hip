@@ -10,6 +10,9 @@
 // pair p is splitmix64(seed, p, i, d): results are reproducible and independent
 // of how pairs are batched or sharded.  All arithmetic is double precision in
 // the operation order of the CPU oracle, so both agree bit for bit.
+#include <atomic>
+#include <mutex>
+
 #include "ransac_kernels.h"
 #include "osfm_common.h"
 
@@ -464,8 +467,25 @@ ransac_kernel(const RansacJob *__restrict__ jobs, int num_jobs, int max_iteratio
     if (tid == 0) *job.count_out = s_run;
 }
 
-static int g_ransac_prefilter = 1;
-static unsigned long long *g_ransac_check = nullptr;
+// Scoring mode of the process and, per device, the counters of mode 2 (every pre-classified decision compared with
+// the double path): a launch counts into the block of the device it runs on -- one block for "the current device"
+// let device k add into device 0's memory once a matcher had shards on several devices.
+static std::atomic<int> g_ransac_mode{1};
+constexpr int kRansacMaxDevices = 64;
+static std::mutex g_ransac_check_mu;
+static unsigned long long *g_ransac_check[kRansacMaxDevices];
+
+static unsigned long long *ransac_check_block(bool create)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kRansacMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(g_ransac_check_mu);
+    if (!g_ransac_check[dev] && create) {
+        if (hipMalloc(&g_ransac_check[dev], 3 * sizeof(unsigned long long)) != hipSuccess) { g_ransac_check[dev] = nullptr; return nullptr; }
+        (void)hipMemset(g_ransac_check[dev], 0, 3 * sizeof(unsigned long long));
+    }
+    return g_ransac_check[dev];
+}
 
 void launch_ransac(const RansacJob *d_jobs, int num_jobs, int max_iterations, double threshold,
     uint64_t seed, void *scratch, hipStream_t s)
@@ -474,25 +494,38 @@ void launch_ransac(const RansacJob *d_jobs, int num_jobs, int max_iterations, do
     RansacSlot *slots = static_cast<RansacSlot *>(scratch);
     int32_t *done = reinterpret_cast<int32_t *>(static_cast<char *>(scratch) + (size_t)num_jobs * kRansacSplit * sizeof(RansacSlot));
     (void)hipMemsetAsync(done, 0, (size_t)num_jobs * sizeof(int32_t), s);
+    const int mode = g_ransac_mode.load();
     hipLaunchKernelGGL(ransac_kernel, dim3(num_jobs * kRansacSplit), dim3(256), 0, s, d_jobs, num_jobs, max_iterations,
-        threshold * threshold, seed, slots, done, g_ransac_prefilter, g_ransac_check);
+        threshold * threshold, seed, slots, done, mode != 0 ? 1 : 0, mode == 2 ? ransac_check_block(true) : nullptr);
 }
 
 // diagnostics (osfm_ransac_selfcheck): mode 0 = double path only, 1 = pre-classification (default),
 // 2 = pre-classification with every decision compared against the double path; counters[3] =
-// wrong decisions, undecided tests, tests
+// wrong decisions, undecided tests, tests -- summed over the devices that ran checked launches
 int ransac_set_mode(int mode, unsigned long long *counters_out)
 {
-    if (counters_out && g_ransac_check) {
+    int cur = 0;
+    OSFM_HIP_CHECK(hipGetDevice(&cur));
+    unsigned long long sum[3] = {0, 0, 0};
+    for (int dev = 0; dev < kRansacMaxDevices; ++dev) {
+        unsigned long long *blk;
+        { std::lock_guard<std::mutex> lock(g_ransac_check_mu); blk = g_ransac_check[dev]; }
+        if (!blk) continue;
+        OSFM_HIP_CHECK(hipSetDevice(dev));
         OSFM_HIP_CHECK(hipDeviceSynchronize());
-        OSFM_HIP_CHECK(hipMemcpy(counters_out, g_ransac_check, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long c[3] = {0, 0, 0};
+        OSFM_HIP_CHECK(hipMemcpy(c, blk, sizeof(c), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 3; ++i) sum[i] += c[i];
+        if (mode == 2) OSFM_HIP_CHECK(hipMemset(blk, 0, sizeof(c)));
+        else {
+            (void)hipFree(blk);
+            std::lock_guard<std::mutex> lock(g_ransac_check_mu);
+            g_ransac_check[dev] = nullptr;
+        }
     }
-    if (mode == 2 && !g_ransac_check) {
-        OSFM_HIP_CHECK(hipMalloc(&g_ransac_check, 3 * sizeof(unsigned long long)));
-    }
-    if (g_ransac_check) OSFM_HIP_CHECK(hipMemset(g_ransac_check, 0, 3 * sizeof(unsigned long long)));
-    if (mode != 2 && g_ransac_check) { (void)hipFree(g_ransac_check); g_ransac_check = nullptr; }
-    g_ransac_prefilter = mode != 0;
+    OSFM_HIP_CHECK(hipSetDevice(cur));
+    if (counters_out) for (int i = 0; i < 3; ++i) counters_out[i] = sum[i];
+    g_ransac_mode.store(mode);
     return OSFM_OK;
 }
 

@@ -243,6 +243,12 @@ class HipExhaustiveMatching:
         capi.check(capi.lib.osfm_match_get_stats(self._h, C.byref(s)))
         return s
 
+    def shard_stats(self, shard: int) -> capi.MatchStats:
+        """What one shard of a multi-device matcher did in the most recent call."""
+        s = capi.MatchStats()
+        capi.check(capi.lib.osfm_match_get_shard_stats(self._h, C.c_int(shard), C.byref(s)))
+        return s
+
     def close(self):
         if self._h:
             capi.lib.osfm_match_destroy(self._h)

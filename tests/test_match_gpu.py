@@ -676,6 +676,40 @@ def test_matcher_handles_give_their_memory_back():
     print(f"runtime-held after the first cycle: {(free0 - free1) / 2**20:.1f} MB; last three cycles: {(frees[2] - free1) / 2**20:.1f} MB")
 
 
+def test_multi_device_front_balances_what_the_gate_lets_through(hm):
+    """Two scenes in one image set (14 views of one, 10 of another): every pair across the scenes -- 140 of the
+    276, a block of the pair matrix, not a sprinkle -- stops at the low-res gate, which costs 1 / 1600 of a full
+    match.  The front deals the gate round robin and the SURVIVORS by work: bytes identical to one device, and the
+    full-matching work (mac_count) of the logical shards within 5 % of each other (a deal of all pairs by N1 * N2
+    in front of the gate left them 20-30 % apart on this set)."""
+    from orthosfm_amd import capi
+    a = synth.make_image_set(14, 1600, config_id=15)
+    b = synth.make_image_set(10, 1600, config_id=16)
+    sift = list(a.sift) + list(b.sift)
+    V = len(sift)
+    single = hm(V, device=0)
+    for v in range(V):
+        single.set_view(v, sift[v])
+    ra1, corr1 = single.compute_arrays()
+    ra1, corr1 = ra1.copy(), corr1.copy()
+    rejected = int((ra1["status"] == capi.PAIR_REJECTED_LOWRES).sum())
+    assert rejected >= 0.3 * ra1.shape[0], (rejected, ra1.shape[0])
+    assert int((ra1["status"] == capi.PAIR_MATCHED).sum()) >= 100
+    for dev in ([0, 0], [0, 0, 0]):
+        m = hm(V, device=dev)
+        for v in range(V):
+            m.set_view(v, sift[v])
+        ra, corr = m.compute_arrays()
+        assert ra.tobytes() == ra1.tobytes() and corr.tobytes() == corr1.tobytes(), dev
+        macs = [m.shard_stats(k).mac_count for k in range(len(dev))]
+        gate = [m.shard_stats(k).lowres_kernel_launches for k in range(len(dev))]
+        assert min(gate) >= 1                                  # every shard took its share of the gate
+        assert max(macs) <= 1.05 * min(macs), (dev, macs)
+        assert sum(macs) == single.stats().mac_count
+        m.close()
+    single.close()
+
+
 def test_concurrent_pair_calls_are_combined(hm):
     """The per-pair entries called from many threads at once (the reference's OpenMP loop,
     bundler_matching.cc:86-88): whoever finds no leader at work runs everything that is
