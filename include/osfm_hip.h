@@ -481,6 +481,55 @@ OSFM_API int osfm_filter_outlier_tracks(int device, const double *points,
     const uint8_t *has_point, int32_t num_tracks, uint8_t *keep,
     osfm_outlier_stats *stats);
 
+/* ---- the incremental reconstruction's scene, resident on the device (the caller of path B) ----
+ *
+ * runPoseEstimation (src/sfm/reconstruct.cpp:193-281) hands filtered copies of its std::vector<Track> to every step:
+ * per camera group filterTracksWithReprojectionError + a 3-camera runBundleAdjustment on a re-triangulated copy,
+ * triangulateTracks over everything, every third group a global runBundleAdjustment, filterOutlierTracks and the
+ * reprojection filter again.  Through the per-call entries above each of those calls flattens and uploads its
+ * tracks.  A scene holds the track table ONCE -- features in track order, alive flags per feature and track, point
+ * and hasPoint() per track, the aligned cameras -- and every step selects its observations from the flags on the
+ * device.  What a filter of the reference drops from its list is a cleared flag here.  The per-call entries stay
+ * (orthosfm_amd/host/ba_hip_adapter.h uses them); results are identical, step by step.  A scene is used by one
+ * thread at a time (its entries lock it). */
+typedef struct osfm_scene osfm_scene;
+
+/* track_offsets [num_tracks + 1] (features of track t: [offsets[t], offsets[t+1])), feat_view / feat_xy per feature
+ * (Feature::viewID and the float pixel position Feature::x / y, track.h:26-27), image size per view.  Every flag
+ * starts alive, no track has a point, no view has a camera. */
+OSFM_API int osfm_scene_create(int device, int model, int num_views, const int32_t *img_width, const int32_t *img_height,
+    int32_t num_tracks, const int64_t *track_offsets, const int32_t *feat_view, const float *feat_xy, osfm_scene **out);
+OSFM_API int osfm_scene_destroy(osfm_scene *s);
+/* alive flags from the caller's table (either may be NULL: unchanged) */
+OSFM_API int osfm_scene_set_flags(osfm_scene *s, const uint8_t *alive_track, const uint8_t *alive_feature);
+/* mergeIntoGlobal (reconstruct.cpp:236-247): the views get cameras (params [n][7], const masks [n][7] as in
+ * osfm_ba_problem), appended to the aligned cameras in this order.  OSFM_E_STATE when a view has one already. */
+OSFM_API int osfm_scene_align_views(osfm_scene *s, int n, const int32_t *views, const double *params, const uint8_t *cam_const);
+/* the aligned cameras in the order they joined (views / params may be NULL) */
+OSFM_API int osfm_scene_get_cameras(osfm_scene *s, int capacity, int32_t *views, double *params, int32_t *num_cameras);
+/* algorithm->triangulateTracks(alignedCameras, tracks, true) (triangulation.cpp:44-93): every alive track with two or
+ * more rays under the aligned cameras gets its intersection, the others lose their point.  new_views != NULL: only
+ * the tracks those views see are redone -- identical to the full pass as long as the other cameras have not moved
+ * since the last one; check_full != 0 repeats the pass in full and counts the tracks that differ (*mismatches). */
+OSFM_API int osfm_scene_triangulate(osfm_scene *s, int num_new_views, const int32_t *new_views, int check_full, int32_t *mismatches);
+/* filterTracksWithReprojectionError(tracks, alignedCameras) (outlier_filtering.cpp:127-192), permanent */
+OSFM_API int osfm_scene_filter_reprojection(osfm_scene *s, double max_error);
+/* One camera group (reconstruct.cpp:205-219): the reprojection filter under the cameras (views, params, cam_const)
+ * on a copy, then runBundleAdjustment(localCameras, localTracks, algorithm, true, true) on what it leaves -- the
+ * tracks seen by at least two of the cameras, re-triangulated first, their points discarded afterwards.  params is
+ * updated in place; the scene is not changed. */
+OSFM_API int osfm_scene_local_adjustment(osfm_scene *s, int n, const int32_t *views, double *params, const uint8_t *cam_const,
+    double max_error, const osfm_ba_options *opt, osfm_ba_summary *sum, int32_t *num_points, int32_t *num_observations);
+/* runBundleAdjustment(alignedCameras, tracks, algorithm, true, false) (bundle_adjustment.cpp:49-161): every alive
+ * track with a point, every live feature of it whose view has a camera; cameras and points updated in the scene. */
+OSFM_API int osfm_scene_global_adjustment(osfm_scene *s, const osfm_ba_options *opt, osfm_ba_summary *sum, int32_t *num_points,
+    int32_t *num_observations);
+/* filterOutlierTracks over the alive tracks (outlier_filtering.cpp:40-125); what it drops loses its flag */
+OSFM_API int osfm_scene_filter_outliers(osfm_scene *s, osfm_outlier_stats *stats, int32_t *num_killed);
+/* the scene's state back: alive flags per track / feature, hasPoint() and point [num_tracks][4] (any may be NULL) */
+OSFM_API int osfm_scene_download(osfm_scene *s, uint8_t *alive_track, uint8_t *alive_feature, uint8_t *has_point, double *points);
+
+
 /* The device part of orthosfm::filterTracksWithReprojectionError
  * (outlier_filtering.cpp:127-192).  p holds the FULL-SIZE tracks (the
  * caller's filterTracksToAvailableCameras(cameras, tracks, true, true)

@@ -133,6 +133,9 @@ EXPORTS = [
     "osfm_ba_options_default", "osfm_ba_solve", "osfm_ba_reprojection_errors",
     "osfm_ba_triangulate",
     "osfm_nn_distances", "osfm_filter_outlier_tracks", "osfm_filter_reprojection",
+    "osfm_scene_create", "osfm_scene_destroy", "osfm_scene_set_flags", "osfm_scene_align_views", "osfm_scene_get_cameras",
+    "osfm_scene_triangulate", "osfm_scene_filter_reprojection", "osfm_scene_local_adjustment", "osfm_scene_global_adjustment",
+    "osfm_scene_filter_outliers", "osfm_scene_download",
     "osfm_tracks_compute", "osfm_tracks_compute_ranges", "osfm_build_groups",
     "osfm_tracks_builder_create", "osfm_tracks_builder_feed", "osfm_tracks_builder_finish", "osfm_tracks_builder_destroy",
     "osfm_tracks_select_observations",

@@ -14,38 +14,11 @@
 #include <limits>
 #include <vector>
 
-#include "ba_kernels.h"
-#include "osfm_common.h"
+#include "ba_solve.h"
 
 using namespace osfm;
 
 namespace {
-
-// a work array of one call, from the pool of osfm_common.h
-struct DevArray {
-    void *ptr = nullptr;
-    ~DevArray() { if (ptr) pool_release(ptr); }
-    int alloc(size_t bytes)
-    {
-        if (ptr) { pool_release(ptr); ptr = nullptr; }
-        return g_device_pool.alloc(&ptr, std::max<size_t>(bytes, 16));
-    }
-    template <typename T> T *as() const { return static_cast<T *>(ptr); }
-};
-
-template <typename T>
-int upload(DevArray &d, const T *src, size_t n, hipStream_t s)
-{
-    OSFM_RETURN_IF(d.alloc(n * sizeof(T)));
-    if (n) OSFM_HIP_CHECK(hipMemcpyAsync(d.ptr, src, n * sizeof(T), hipMemcpyHostToDevice, s));
-    return OSFM_OK;
-}
-
-struct Layout {
-    std::vector<int32_t> cam_ldim, cam_off, pt_start;
-    std::vector<int8_t> colmap;
-    int nc = 0;
-};
 
 int validate_problem(const osfm_ba_problem *p, const char *what)
 {
@@ -77,37 +50,15 @@ int validate_problem(const osfm_ba_problem *p, const char *what)
     return OSFM_OK;
 }
 
-// Tangent layout of the camera blocks (which columns are free), following
-// SetupParameterBlocks (OrthoQuaternionRecoAlgorithm.cpp:121-148,
-// OrthographicReconstructionAlgorithm.cpp:148-178).
+// pt_start of the caller's observations (validated non-decreasing in obs_point)
 void build_layout(const osfm_ba_problem *p, Layout *L)
 {
-    const int C = p->num_cameras, M = p->num_points, O = p->num_observations;
-    L->cam_ldim.assign(C + 1, 0); L->cam_off.assign(C + 1, 0); L->colmap.assign((size_t)6 * (C + 1), 0);
-    int tot = 0;
-    for (int c = 0; c < C; ++c) {
-        const uint8_t *cc = p->cam_const + 7 * c;
-        int n = 0;
-        int8_t *cm = L->colmap.data() + 6 * c;
-        if (p->model == OSFM_BA_MODEL_QUATERNION) {
-            if (!cc[0]) { cm[n++] = 0; cm[n++] = 1; cm[n++] = 2; }
-            for (int s = 4; s < 7; ++s) if (!cc[s]) cm[n++] = (int8_t)(s - 1);   // full cols 3,4,5
-        } else {
-            for (int s = 0; s < 6; ++s) if (!cc[s]) cm[n++] = (int8_t)s;
-        }
-        L->cam_ldim[c] = n; L->cam_off[c] = tot; tot += n;
-    }
-    L->nc = tot;
+    const int M = p->num_points, O = p->num_observations;
+    build_camera_layout(p->model, p->num_cameras, p->cam_const, L);
     L->pt_start.assign(M + 2, 0);
     for (int k = 0; k < O; ++k) L->pt_start[p->obs_point[k] + 1]++;
     for (int j = 0; j < M; ++j) L->pt_start[j + 1] += L->pt_start[j];
 }
-
-struct DeviceProblem {
-    DevArray cams[2], points[2], obs_xy, obs_cam, obs_pt, pt_start, img_w, img_h;
-    DevArray cam_ldim, cam_off, colmap, scale_c, scale_p;
-    BaDev dev;
-};
 
 // the caller's arrays: queued before the layout is derived on the host, so that the 24 bytes per observation
 // cross PCIe while the host counts them
@@ -128,35 +79,18 @@ int upload_problem(const osfm_ba_problem *p, const Layout &L, double huber, int 
 {
     const int C = p->num_cameras, M = p->num_points, O = p->num_observations;
     if (!caller_arrays_queued) OSFM_RETURN_IF(upload_caller_arrays(p, s, D));
-    OSFM_RETURN_IF(D->cams[1].alloc((size_t)7 * C * 8));
-    OSFM_RETURN_IF(D->points[1].alloc((size_t)4 * M * 8));
     OSFM_RETURN_IF(upload(D->pt_start, L.pt_start.data(), (size_t)M + 1, s));
-    // obs_point is validated non-decreasing, i.e. it is the expansion of pt_start
-    OSFM_RETURN_IF(D->obs_pt.alloc((size_t)O * sizeof(int32_t)));
-    launch_expand_points(D->pt_start.as<int32_t>(), M, D->obs_pt.as<int32_t>(), s);
-    OSFM_RETURN_IF(upload(D->cam_ldim, L.cam_ldim.data(), (size_t)C, s));
-    OSFM_RETURN_IF(upload(D->cam_off, L.cam_off.data(), (size_t)C, s));
-    OSFM_RETURN_IF(upload(D->colmap, L.colmap.data(), (size_t)6 * C, s));
-    OSFM_RETURN_IF(D->scale_c.alloc((size_t)L.nc * 8));
-    OSFM_RETURN_IF(D->scale_p.alloc((size_t)3 * M * 8));
-    launch_fill(D->scale_c.as<double>(), (size_t)L.nc, 1.0, s);
-    launch_fill(D->scale_p.as<double>(), (size_t)3 * M, 1.0, s);
-    BaDev &d = D->dev;
-    memset(&d, 0, sizeof(d));          // lm == nullptr: the plain pointers below are used as they are
-    d.model = p->model; d.C = C; d.M = M; d.O = O; d.nc = L.nc; d.pdim = pdim;
-    d.cams = D->cams[0].as<double>(); d.points = D->points[0].as<double>();
-    d.obs_xy = D->obs_xy.as<double>(); d.obs_cam = D->obs_cam.as<int32_t>(); d.obs_pt = D->obs_pt.as<int32_t>();
-    d.pt_start = D->pt_start.as<int32_t>(); d.img_w = D->img_w.as<int32_t>(); d.img_h = D->img_h.as<int32_t>();
-    d.cam_ldim = D->cam_ldim.as<int32_t>(); d.cam_off = D->cam_off.as<int32_t>();
-    d.cam_colmap = D->colmap.as<int8_t>();
-    d.scale_c = D->scale_c.as<double>(); d.scale_p = D->scale_p.as<double>();
-    d.huber = huber;
+    OSFM_RETURN_IF(upload_camera_layout(L, C, s, D));
     // No synchronisation here: every source array (the caller's and the Layout's) outlives
     // the call, and what follows is ordered behind the copies on the same stream.
-    return OSFM_OK;
+    return finish_device_problem(p->model, C, M, O, L.nc, huber, pdim, s, D);
 }
 
 using StreamGuard = StreamLease;
+
+}  // namespace
+
+namespace osfm {
 
 int select_device(int device)
 {
@@ -170,105 +104,72 @@ int select_device(int device)
     return OSFM_OK;
 }
 
-}  // namespace
 
-extern "C" {
-
-int osfm_ba_debug_chol_trace(int enable, int64_t *stamps)
+void build_camera_layout(int model, int C, const uint8_t *cam_const, Layout *L)
 {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("ba_debug_chol_trace: no HIP device available"); return OSFM_E_DEVICE; }
-    OSFM_HIP_CHECK(hipDeviceSynchronize());
-    long long *buf = chol_flow_trace_buffer(1);
-    if (!buf) { set_error("ba_debug_chol_trace: no memory for the trace"); return OSFM_E_DEVICE; }
-    if (stamps) OSFM_HIP_CHECK(hipMemcpy(stamps, buf, 161 * 32 * 8, hipMemcpyDeviceToHost));
-    if (!enable) chol_flow_trace_buffer(0);
+    L->cam_ldim.assign(C + 1, 0); L->cam_off.assign(C + 1, 0); L->colmap.assign((size_t)6 * (C + 1), 0);
+    int tot = 0;
+    for (int c = 0; c < C; ++c) {
+        const uint8_t *cc = cam_const + 7 * c;
+        int n = 0;
+        int8_t *cm = L->colmap.data() + 6 * c;
+        if (model == OSFM_BA_MODEL_QUATERNION) {
+            if (!cc[0]) { cm[n++] = 0; cm[n++] = 1; cm[n++] = 2; }
+            for (int s = 4; s < 7; ++s) if (!cc[s]) cm[n++] = (int8_t)(s - 1);   // full cols 3,4,5
+        } else {
+            for (int s = 0; s < 6; ++s) if (!cc[s]) cm[n++] = (int8_t)s;
+        }
+        L->cam_ldim[c] = n; L->cam_off[c] = tot; tot += n;
+    }
+    L->nc = tot;
+}
+
+int upload_camera_layout(const Layout &L, int C, hipStream_t s, DeviceProblem *D)
+{
+    OSFM_RETURN_IF(upload(D->cam_ldim, L.cam_ldim.data(), (size_t)C, s));
+    OSFM_RETURN_IF(upload(D->cam_off, L.cam_off.data(), (size_t)C, s));
+    OSFM_RETURN_IF(upload(D->colmap, L.colmap.data(), (size_t)6 * C, s));
+    OSFM_RETURN_IF(D->scale_c.alloc((size_t)L.nc * 8));
+    launch_fill(D->scale_c.as<double>(), (size_t)L.nc, 1.0, s);
     return OSFM_OK;
 }
 
-int osfm_ba_debug_flow_spin_limit(int limit)
+int finish_device_problem(int model, int C, int M, int O, int nc, double huber, int pdim, hipStream_t s, DeviceProblem *D)
 {
-    chol_flow_set_spin_limit(limit);
+    OSFM_RETURN_IF(D->cams[1].alloc((size_t)7 * C * 8));
+    OSFM_RETURN_IF(D->points[1].alloc((size_t)4 * M * 8));
+    // obs_point is non-decreasing, i.e. it is the expansion of pt_start
+    OSFM_RETURN_IF(D->obs_pt.alloc((size_t)O * sizeof(int32_t)));
+    launch_expand_points(D->pt_start.as<int32_t>(), M, D->obs_pt.as<int32_t>(), s);
+    OSFM_RETURN_IF(D->scale_p.alloc((size_t)3 * M * 8));
+    launch_fill(D->scale_p.as<double>(), (size_t)3 * M, 1.0, s);
+    BaDev &d = D->dev;
+    memset(&d, 0, sizeof(d));          // lm == nullptr: the plain pointers below are used as they are
+    d.model = model; d.C = C; d.M = M; d.O = O; d.nc = nc; d.pdim = pdim;
+    d.cams = D->cams[0].as<double>(); d.points = D->points[0].as<double>();
+    d.obs_xy = D->obs_xy.as<double>(); d.obs_cam = D->obs_cam.as<int32_t>(); d.obs_pt = D->obs_pt.as<int32_t>();
+    d.pt_start = D->pt_start.as<int32_t>(); d.img_w = D->img_w.as<int32_t>(); d.img_h = D->img_h.as<int32_t>();
+    d.cam_ldim = D->cam_ldim.as<int32_t>(); d.cam_off = D->cam_off.as<int32_t>();
+    d.cam_colmap = D->colmap.as<int8_t>();
+    d.scale_c = D->scale_c.as<double>(); d.scale_p = D->scale_p.as<double>();
+    d.huber = huber;
     return OSFM_OK;
 }
 
-int osfm_ba_options_default(osfm_ba_options *o)
+int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, int64_t pair_bound, osfm_ba_summary *sum, int *cur_out)
 {
-    if (!o) { set_error("ba_options_default: null"); return OSFM_E_ARG; }
-    o->huber_delta = 1.0;
-    o->function_tolerance = 1e-6;
-    o->gradient_tolerance = 1e-10;
-    o->parameter_tolerance = 1e-10;
-    o->max_num_iterations = 100;
-    o->optimize_points = 1;
-    o->initial_trust_region_radius = 1e4;
-    o->max_trust_region_radius = 1e16;
-    o->min_trust_region_radius = 1e-32;
-    o->min_relative_decrease = 1e-3;
-    o->min_lm_diagonal = 1e-6;
-    o->max_lm_diagonal = 1e32;
-    o->jacobi_scaling = 1;
-    o->max_consecutive_invalid_steps = 5;
-    o->device = 0;
-    o->verbose = 0;
-    o->retriangulate_points = 0;
-    o->reserved = 0;
-    return OSFM_OK;
-}
-
-int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_summary *sum)
-{
-    if (!sum) { set_error("ba_solve: null summary"); return OSFM_E_ARG; }
-    memset(sum, 0, sizeof(*sum));
-    OSFM_RETURN_IF(validate_problem(p, "ba_solve"));
-    osfm_ba_options o;
-    if (opt) o = *opt; else osfm_ba_options_default(&o);
-    OSFM_RETURN_IF(select_device(o.device));
     const auto t_begin = std::chrono::steady_clock::now();
-
-    const int C = p->num_cameras, M = p->num_points;
     auto lap = [&](const char *what) {
         if (o.verbose >= 2)
-            fprintf(stderr, "[osfm ba] %-18s %8.3f ms\n", what,
+            fprintf(stderr, "[osfm ba]   %-16s %8.3f ms\n", what,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     };
-    StreamGuard sg;
-    OSFM_RETURN_IF(sg.acquire());
     hipStream_t s = sg.s;
-
-    // (D is declared before L: the transfers queued from L's vectors are waited for before either goes)
-    DeviceProblem D;
-    OSFM_RETURN_IF(upload_caller_arrays(p, s, &D));
-    lap("caller arrays queued");
-    Layout L;
-    build_layout(p, &L);
-    const int pdim = o.optimize_points ? 3 : 0;
-    const int nc = L.nc;
-    lap("layout");
-    OSFM_RETURN_IF(upload_problem(p, L, o.huber_delta, pdim, s, &D, true));
     BaDev &d = D.dev;
-    // the points the optimisation starts from (tracksBackup, bundle_adjustment.cpp:99)
-    std::vector<double> pts0((size_t)4 * M);
-    if (M) memcpy(pts0.data(), p->points, (size_t)4 * M * 8);
-    if (o.retriangulate_points && M > 0) {
-        // triangulateTracks(cameras, localTracks, true) in front of the solve (bundle_adjustment.cpp:77-83)
-        OSFM_HIP_CHECK(hipMemcpyAsync(D.points[1].ptr, D.points[0].ptr, (size_t)4 * M * 8, hipMemcpyDeviceToDevice, s));
-        launch_triangulate(d, D.points[1].as<double>(), nullptr, s);
-        OSFM_HIP_CHECK(hipMemcpyAsync(D.points[0].ptr, D.points[1].ptr, (size_t)4 * M * 8, hipMemcpyDeviceToDevice, s));
-        OSFM_HIP_CHECK(hipMemcpyAsync(pts0.data(), D.points[1].ptr, (size_t)4 * M * 8, hipMemcpyDeviceToHost, s));
-    }
-    lap("upload problem");
-
+    const int C = d.C, M = d.M, nc = d.nc, pdim = d.pdim;
     // camera-pair lists of the Schur complement, built on the device
     PairListsDev PL;
-    {
-        int64_t bound = 0;
-        for (int j = 0; j < M; ++j) {
-            const int64_t l = L.pt_start[j + 1] - L.pt_start[j];
-            bound += pdim ? l * l : l;
-        }
-        OSFM_RETURN_IF(pair_lists_build(d, pdim != 0, std::max<int64_t>(bound, 1), &PL, s));
-    }
+    OSFM_RETURN_IF(pair_lists_build(d, pdim != 0, std::max<int64_t>(pair_bound, 1), &PL, s));
     const int num_pairs = PL.num_pairs;
     sum->num_pair_entries = PL.num_entries;
     lap("pair lists (device)");
@@ -277,7 +178,7 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     const int N = cholesky_padded_dim(std::max(nc, 1));
     DevArray Lmat;
     DevArray obsrec, diag_c, diag_p, vinv, ge, S, Ldiag, y_c, partA, partB, partC, part_cam, gmax_cam, scalars, info;
-    OSFM_RETURN_IF(obsrec.alloc((size_t)std::max(p->num_observations, 1) * kObsRec * 8));
+    OSFM_RETURN_IF(obsrec.alloc((size_t)std::max(d.O, 1) * kObsRec * 8));
     OSFM_RETURN_IF(diag_c.alloc((size_t)nc * 8));
     OSFM_RETURN_IF(diag_p.alloc((size_t)3 * M * 8));
     OSFM_RETURN_IF(vinv.alloc((size_t)9 * M * 8));
@@ -519,6 +420,111 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
 
     sum->lm_loop_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count();
     lap("LM loop");
+    *cur_out = cur;
+    sum->final_cost = x_cost;
+    sum->num_iterations = iteration;
+    sum->termination = term;
+    sum->point_pass_ms = t_point; sum->pair_pass_ms = t_pair; sum->cholesky_ms = t_chol; sum->back_pass_ms = t_back;
+    sum->linearizations = fin.num_success + fin.num_unsuccess + 1;   // the speculative ones past the end do nothing
+    (void)n_lin;
+    return OSFM_OK;
+}
+
+}  // namespace osfm
+
+extern "C" {
+
+int osfm_ba_debug_chol_trace(int enable, int64_t *stamps)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("ba_debug_chol_trace: no HIP device available"); return OSFM_E_DEVICE; }
+    OSFM_HIP_CHECK(hipDeviceSynchronize());
+    long long *buf = chol_flow_trace_buffer(1);
+    if (!buf) { set_error("ba_debug_chol_trace: no memory for the trace"); return OSFM_E_DEVICE; }
+    if (stamps) OSFM_HIP_CHECK(hipMemcpy(stamps, buf, 161 * 32 * 8, hipMemcpyDeviceToHost));
+    if (!enable) chol_flow_trace_buffer(0);
+    return OSFM_OK;
+}
+
+int osfm_ba_debug_flow_spin_limit(int limit)
+{
+    chol_flow_set_spin_limit(limit);
+    return OSFM_OK;
+}
+
+int osfm_ba_options_default(osfm_ba_options *o)
+{
+    if (!o) { set_error("ba_options_default: null"); return OSFM_E_ARG; }
+    o->huber_delta = 1.0;
+    o->function_tolerance = 1e-6;
+    o->gradient_tolerance = 1e-10;
+    o->parameter_tolerance = 1e-10;
+    o->max_num_iterations = 100;
+    o->optimize_points = 1;
+    o->initial_trust_region_radius = 1e4;
+    o->max_trust_region_radius = 1e16;
+    o->min_trust_region_radius = 1e-32;
+    o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->jacobi_scaling = 1;
+    o->max_consecutive_invalid_steps = 5;
+    o->device = 0;
+    o->verbose = 0;
+    o->retriangulate_points = 0;
+    o->reserved = 0;
+    return OSFM_OK;
+}
+
+int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_summary *sum)
+{
+    if (!sum) { set_error("ba_solve: null summary"); return OSFM_E_ARG; }
+    memset(sum, 0, sizeof(*sum));
+    OSFM_RETURN_IF(validate_problem(p, "ba_solve"));
+    osfm_ba_options o;
+    if (opt) o = *opt; else osfm_ba_options_default(&o);
+    OSFM_RETURN_IF(select_device(o.device));
+    const auto t_begin = std::chrono::steady_clock::now();
+
+    const int C = p->num_cameras, M = p->num_points;
+    auto lap = [&](const char *what) {
+        if (o.verbose >= 2)
+            fprintf(stderr, "[osfm ba] %-18s %8.3f ms\n", what,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
+    StreamGuard sg;
+    OSFM_RETURN_IF(sg.acquire());
+    hipStream_t s = sg.s;
+
+    // (D is declared before L: the transfers queued from L's vectors are waited for before either goes)
+    DeviceProblem D;
+    OSFM_RETURN_IF(upload_caller_arrays(p, s, &D));
+    lap("caller arrays queued");
+    Layout L;
+    build_layout(p, &L);
+    const int pdim = o.optimize_points ? 3 : 0;
+    lap("layout");
+    OSFM_RETURN_IF(upload_problem(p, L, o.huber_delta, pdim, s, &D, true));
+    BaDev &d = D.dev;
+    // the points the optimisation starts from (tracksBackup, bundle_adjustment.cpp:99)
+    std::vector<double> pts0((size_t)4 * M);
+    if (M) memcpy(pts0.data(), p->points, (size_t)4 * M * 8);
+    if (o.retriangulate_points && M > 0) {
+        // triangulateTracks(cameras, localTracks, true) in front of the solve (bundle_adjustment.cpp:77-83)
+        OSFM_HIP_CHECK(hipMemcpyAsync(D.points[1].ptr, D.points[0].ptr, (size_t)4 * M * 8, hipMemcpyDeviceToDevice, s));
+        launch_triangulate(d, D.points[1].as<double>(), nullptr, s);
+        OSFM_HIP_CHECK(hipMemcpyAsync(D.points[0].ptr, D.points[1].ptr, (size_t)4 * M * 8, hipMemcpyDeviceToDevice, s));
+        OSFM_HIP_CHECK(hipMemcpyAsync(pts0.data(), D.points[1].ptr, (size_t)4 * M * 8, hipMemcpyDeviceToHost, s));
+    }
+    lap("upload problem");
+
+    int64_t bound = 0;
+    for (int j = 0; j < M; ++j) {
+        const int64_t l = L.pt_start[j + 1] - L.pt_start[j];
+        bound += pdim ? l * l : l;
+    }
+    int cur = 0;
+    OSFM_RETURN_IF(ba_solve_core(D, o, sg, bound, sum, &cur));
     // ---- write back the current iterate --------------------------------------
     if (C) OSFM_HIP_CHECK(hipMemcpyAsync(p->cam_params, D.cams[cur].ptr, (size_t)7 * C * 8, hipMemcpyDeviceToHost, s));
     if (M) OSFM_HIP_CHECK(hipMemcpyAsync(p->points, D.points[cur].ptr, (size_t)4 * M * 8, hipMemcpyDeviceToHost, s));
@@ -531,12 +537,6 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     }
     sum->mean_point_change = M ? acc / M : 0.0;
     sum->max_point_change = mx;
-    sum->final_cost = x_cost;
-    sum->num_iterations = iteration;
-    sum->termination = term;
-    sum->point_pass_ms = t_point; sum->pair_pass_ms = t_pair; sum->cholesky_ms = t_chol; sum->back_pass_ms = t_back;
-    sum->linearizations = fin.num_success + fin.num_unsuccess + 1;   // the speculative ones past the end do nothing
-    (void)n_lin;
     sum->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return OSFM_OK;
 }

@@ -528,8 +528,11 @@ def join_background():
 
 def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2.0, off_perturb=0.01,
                         seed=7, timings=None, capture=(), max_groups=None, verbose=False, view_ids=None,
-                        euler_dof=4, check_incremental=False):
-    """runPoseEstimation (reconstruct.cpp:174-295) on the track table."""
+                        euler_dof=4, check_incremental=False, use_scene=True):
+    """runPoseEstimation (reconstruct.cpp:174-295) on the track table.  use_scene: the table lives on the device
+    for the whole loop (osfm_scene_*: every step selects its observations there); False: every step flattens its
+    tracks on the host and goes through the per-call entries of the C ABI (what a caller without the scene does;
+    the two forms produce the same cameras, flags and points to the bit: tests/test_e2e_gpu.py)."""
     tm = timings if timings is not None else Timings()
     V = iset.num_views
     W, H = iset.width, iset.height
@@ -556,6 +559,14 @@ def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2
     calls, captured = [], {}
     opt = B.default_options(device=device)
     opt_local = B.default_options(device=device, retriangulate_points=1)
+    scene = None
+    if use_scene and not capture:
+        from .scene import Scene
+        t0 = time.perf_counter()
+        scene = Scene(model, np.full(V, W, np.int32), np.full(V, H, np.int32), tt.offsets, tt.view, tt.xy.astype(np.float32), device)
+        if not (tt.alive_t.all() and tt.alive_f.all()):
+            scene.set_flags(tt.alive_t, tt.alive_f)
+        tm.pose_host_s += time.perf_counter() - t0
 
     def start_pose(v):
         p = gt[v].copy()
@@ -671,6 +682,80 @@ def run_pose_estimation(tt: TrackTable, iset, model, device=0, rot_perturb_deg=2
         tm.local_filter_s += time.perf_counter() - t0
         return idx[sel]
 
+    if scene is not None:
+        # ---- the loop on the device-resident scene ----------------------------------------------------------
+        tri_full = True
+        processed = 0
+        for g in groups:
+            processed += 1
+            ids = list(g.ids)
+            first_group = not aligned
+            lp = np.array([cams[v].copy() if is_aligned[v] else start_pose(v) for v in ids])
+            lc = np.array([default_const_mask(model, euler_dof=euler_dof) for _ in ids])
+            if first_group:
+                lc[0] = default_const_mask(model, fixed=True, euler_dof=euler_dof)
+            t0 = time.perf_counter()
+            s, M, O = scene.local_adjustment(ids, lp, lc, MAX_REPROJECTION_ERROR, opt_local)
+            dt = time.perf_counter() - t0
+            tm.local_ba_s += dt
+            calls.append(BaCall("local", len(ids), M, O, int(s.num_iterations), dt * 1e3, s.lm_loop_ms))
+            new_views = []
+            if first_group:
+                for k, v in enumerate(ids):
+                    cams[v] = lp[k]; const[v] = lc[k]
+                    aligned.append(v); is_aligned[v] = True; new_views.append(v)
+                scene.align_views(new_views, cams[new_views], const[new_views])
+            else:
+                align_to_global(model, lp, [cams[v] if is_aligned[v] else None for v in ids])
+                for k, v in enumerate(ids):
+                    if not is_aligned[v]:
+                        cams[v] = lp[k]; const[v] = default_const_mask(model, euler_dof=euler_dof)
+                        aligned.append(v); is_aligned[v] = True; new_views.append(v)
+                scene.align_views(new_views, cams[new_views], const[new_views])
+            t0 = time.perf_counter()
+            bad = scene.triangulate(None if tri_full else new_views, check_full=check_incremental)
+            assert bad == 0, "incremental triangulation"
+            tri_full = False
+            tm.triangulate_s += time.perf_counter() - t0
+            if not first_group and processed % GLOBAL_BA_INTERVAL == 0:
+                t0 = time.perf_counter()
+                s, M, O = scene.global_adjustment(opt)
+                dt = time.perf_counter() - t0
+                tm.global_ba_s += dt
+                calls.append(BaCall("global", len(aligned), M, O, int(s.num_iterations), dt * 1e3, s.lm_loop_ms))
+                cams[aligned] = scene.cameras()[1]
+                tri_full = True
+                t0 = time.perf_counter()
+                scene.filter_outliers()
+                tm.outlier_filter_s += time.perf_counter() - t0
+                t0 = time.perf_counter()
+                scene.filter_reprojection(MAX_REPROJECTION_ERROR)      # no track seen by every camera: nothing is judged
+                tm.local_filter_s += time.perf_counter() - t0
+            if verbose:
+                print(f"group {processed}/{len(groups)} {ids}: {len(aligned)} cameras")
+        t0 = time.perf_counter()
+        s, M, O = scene.global_adjustment(opt)
+        dt = time.perf_counter() - t0
+        tm.global_ba_s += dt
+        calls.append(BaCall("final", len(aligned), M, O, int(s.num_iterations), dt * 1e3, s.lm_loop_ms))
+        cams[aligned] = scene.cameras()[1]
+        # the scene's state into the caller's table
+        t0 = time.perf_counter()
+        at, af, hp, pt = scene.download()
+        scene.close()
+        tt.alive_t[:] = at
+        tt.alive_f[:] = af
+        tt.live_f[:] = af & at[tt.track_of]
+        tt.has_point[:] = hp
+        tt.point[:] = pt
+        tt._lengths[:] = np.add.reduceat(tt.live_f.astype(np.int64), tt.offsets[:-1]) if tt.live_f.size else 0
+        tt._lengths[np.diff(tt.offsets) == 0] = 0
+        for k, v in enumerate(aligned):
+            tt.align_view(v, k)
+        tm.pose_host_s += time.perf_counter() - t0
+        tm.pose_s = time.perf_counter() - t_pose
+        return cams, aligned, groups, calls, captured
+
     processed = 0
     for g in groups:
         processed += 1
@@ -761,7 +846,7 @@ def _global_ba(tt, model, cams, const, aligned, W, H, V, solve, kind, opt, tm):
 
 def reconstruct(iset, solver=0, matcher="exhaustive", device=0, verify=True, rot_perturb_deg=2.0,
                 off_perturb=0.01, seed=7, capture=(), max_groups=None, verbose=False,
-                check_incremental=False) -> Result:
+                check_incremental=False, use_scene=True) -> Result:
     """orthosfm::reconstruct from the views' descriptors on: one wall clock over matching,
     track building, group ordering and the incremental pose estimation.
     solver 0: quaternion cameras (ORTHO_QUATERNION); 1..3: Euler cameras with that many
@@ -772,7 +857,7 @@ def reconstruct(iset, solver=0, matcher="exhaustive", device=0, verify=True, rot
     model = B.MODEL_QUATERNION if solver == 0 else B.MODEL_EULER
     cams, aligned, groups, calls, captured = run_pose_estimation(
         tt, iset, model, device, rot_perturb_deg, off_perturb, seed, tm, capture, max_groups, verbose,
-        euler_dof=euler_dof_of_solver(solver), check_incremental=check_incremental)
+        euler_dof=euler_dof_of_solver(solver), check_incremental=check_incremental, use_scene=use_scene)
     join_background()            # inside the clock: the matcher's memory is back when the job is done
     tm.total_s = time.perf_counter() - t_all
     return Result(cams, aligned, tt, groups, tm, calls, captured=captured, **info)

@@ -277,3 +277,25 @@ def test_cascade_mode_of_the_pipeline_equals_sequential_uploads():
     m2.set_view(2, iset.sift[2])
     assert (m2.pairwise_match(0, 1).matches_1_2 >= 0).sum() > 0
     m2.close()
+
+
+@pytest.mark.parametrize("solver", [0, 3])
+def test_scene_on_the_device_equals_the_per_call_form(iset, solver):
+    """The incremental reconstruction with the track table resident on the device (osfm_scene_*: every step selects
+    its observations from the flags there) against the per-call form (every step flattens its tracks on the host and
+    goes through osfm_ba_solve / osfm_ba_triangulate / osfm_filter_reprojection): the same cameras, alive flags,
+    hasPoint() and points to the bit, the same adjustments with the same iteration counts and problem sizes."""
+    from orthosfm_amd import pipeline as P
+    a = P.reconstruct(iset, solver=solver, seed=11, use_scene=True, check_incremental=True)
+    b = P.reconstruct(iset, solver=solver, seed=11, use_scene=False)
+    assert a.aligned_views == b.aligned_views
+    assert np.array_equal(a.cam_params, b.cam_params)
+    ta, tb = a.tracks, b.tracks
+    assert np.array_equal(ta.alive_t, tb.alive_t) and np.array_equal(ta.alive_f, tb.alive_f)
+    assert np.array_equal(ta.live_f, tb.live_f) and np.array_equal(ta.alive_lengths(), tb.alive_lengths())
+    assert np.array_equal(ta.has_point & ta.alive_t, tb.has_point & tb.alive_t)
+    sel = ta.has_point & ta.alive_t
+    assert sel.sum() > 100 and np.array_equal(ta.point[sel], tb.point[sel])
+    ca = [(c.kind, c.cameras, c.points, c.observations, c.iterations) for c in a.ba_calls]
+    cb = [(c.kind, c.cameras, c.points, c.observations, c.iterations) for c in b.ba_calls]
+    assert ca == cb
