@@ -299,3 +299,73 @@ def test_scene_on_the_device_equals_the_per_call_form(iset, solver):
     ca = [(c.kind, c.cameras, c.points, c.observations, c.iterations) for c in a.ba_calls]
     cb = [(c.kind, c.cameras, c.points, c.observations, c.iterations) for c in b.ba_calls]
     assert ca == cb
+
+
+def test_cpp_caller_of_the_scene(iset, tmp_path):
+    """tests/host/scene_check.cc -- a C++ program on the C ABI of the device-resident scene -- takes the steps of the
+    first two camera groups of runPoseEstimation (local adjustment, align, triangulate, second group, incremental
+    triangulation checked in full, global adjustment, both filters); the same steps through orthosfm_amd/scene.py:
+    same sizes, iteration counts, cameras, flags and points, bit for bit."""
+    import subprocess
+    from orthosfm_amd import ba as B, pipeline as P
+    from orthosfm_amd.scene import Scene
+    exe = os.path.join(os.path.dirname(__file__), "host", "scene_check")
+    assert os.path.exists(exe), "tests/host/scene_check missing: run __graft_entry__.build()"
+    model = B.MODEL_QUATERNION
+    tt, _ = P.match_and_build_tracks(iset, "exhaustive", 0, True)
+    P.join_background()
+    V, W, H = iset.num_views, iset.width, iset.height
+    gt, _ = P.canonical_ground_truth(iset, model)
+    rng = np.random.default_rng(5)
+    g1, g2 = np.array([0, 1, 2], np.int32), np.array([1, 2, 3], np.int32)
+
+    def start(v, fixed):
+        p = gt[v].copy()
+        if not fixed:
+            p[4:6] += 0.01 * rng.normal(size=2)
+        return p
+    p1 = np.array([start(v, v == 0) for v in g1])
+    p2 = np.array([start(v, False) for v in g2])
+    c1 = np.array([P.default_const_mask(model, fixed=(k == 0)) for k in range(3)])
+    c2 = np.array([P.default_const_mask(model) for _ in range(3)])
+    path = str(tmp_path / "scene.bin")
+    with open(path, "wb") as f:
+        np.array([model, V, tt.offsets.shape[0] - 1, W, H, 3], np.int32).tofile(f)
+        tt.offsets.astype(np.int64).tofile(f); tt.view.astype(np.int32).tofile(f); tt.xy.astype(np.float32).tofile(f)
+        for g, p, c in ((g1, p1, c1), (g2, p2, c2)):
+            g.tofile(f); p.astype(np.float64).tofile(f); c.astype(np.uint8).tofile(f)
+    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().split("\n")
+    # the same steps from Python
+    sc = Scene(model, np.full(V, W, np.int32), np.full(V, H, np.int32), tt.offsets, tt.view, tt.xy.astype(np.float32), 0)
+    o, ol = B.default_options(), B.default_options(retriangulate_points=1)
+    exp = []
+    q1 = p1.copy()
+    s, M, O = sc.local_adjustment(g1, q1, c1, 1.5, ol)
+    exp.append(f"local1 {M} {O} {s.num_iterations}")
+    sc.align_views(g1, q1, c1)
+    sc.triangulate()
+    cv, cp = sc.cameras()
+    q2 = p2.copy()
+    for i, v in enumerate(g2):
+        if v in cv:
+            q2[i] = cp[list(cv).index(v)]
+    s, M, O = sc.local_adjustment(g2, q2, c2, 1.5, ol)
+    exp.append(f"local2 {M} {O} {s.num_iterations}")
+    sc.align_views(g2[2:], q2[2:], c2[2:])
+    exp.append(f"incremental_mismatches {sc.triangulate(g2[2:], check_full=True)}")
+    s, M, O = sc.global_adjustment(o)
+    exp.append(f"global {M} {O} {s.num_iterations} {s.final_cost:.17g}")
+    exp.append(f"outliers {sc.filter_outliers()}")
+    sc.filter_reprojection(1.5)
+    cv, cp = sc.cameras()
+    for v, p in zip(cv, cp):
+        exp.append(f"cam {v} " + " ".join(f"{x:.17g}" for x in p))
+    at, af, hp, pt = sc.download()
+    exp.append(f"alive {int(at.sum())} {int(af.sum())} {int((at & hp).sum())}")
+    for t in np.flatnonzero(at & hp):
+        exp.append(f"pt {t} " + " ".join(f"{x:.17g}" for x in pt[t]))
+    sc.close()
+    assert len(lines) == len(exp) and int((at & hp).sum()) > 100
+    assert lines == exp
