@@ -19,6 +19,8 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -651,8 +653,14 @@ int osfm_scene_local_adjustment(osfm_scene *sc, int n, const int32_t *views, dou
     StreamLease sg;
     OSFM_RETURN_IF(sg.acquire());
     hipStream_t s = sg.s;
+    static const bool trace = getenv("OSFM_SCENE_TRACE") != nullptr;
+    auto lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "[osfm scene] %-22s %8.3f ms\n", what,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
     int O = 0;
     OSFM_RETURN_IF(reprojection_filter(sc, n, views, params, cam_const, max_error, false, s, &O));
+    lap("filter");
     // the features the filter leaves, their tracks numbered as they appear, every point at (0, 0, 0, 1): the
     // adjustment re-triangulates its copy first (runBundleAdjustment(..., true, true), reconstruct.cpp:212-219)
     int32_t *sel = sc->sel.as<int32_t>(), *scan = sc->scan.as<int32_t>(), *cnt = sc->cnt.as<int32_t>(), *tflag = sc->tflag.as<int32_t>();
@@ -666,16 +674,18 @@ int osfm_scene_local_adjustment(osfm_scene *sc, int n, const int32_t *views, dou
         o.huber_delta, pdim, &L, s, &P));
     if (num_points) *num_points = P.M;
     if (num_observations) *num_observations = P.O;
+    lap("problem");
     if (o.retriangulate_points && P.M > 0) {
         OSFM_HIP_CHECK(hipMemcpyAsync(P.D.points[1].ptr, P.D.points[0].ptr, (size_t)P.M * 32, hipMemcpyDeviceToDevice, s));
         launch_triangulate(P.D.dev, P.D.points[1].as<double>(), nullptr, s);
         OSFM_HIP_CHECK(hipMemcpyAsync(P.D.points[0].ptr, P.D.points[1].ptr, (size_t)P.M * 32, hipMemcpyDeviceToDevice, s));
     }
-    int64_t bound = 0;
-    OSFM_RETURN_IF(pair_bound_of(sc, P, s, &bound));
-    if (!pdim) bound = P.O;
+    // pair-list bound: a track has at most one feature per view, i.e. at most n observations here
+    const int64_t bound = pdim ? (int64_t)P.O * n : P.O;
     int cur = 0;
+    lap("bound");
     OSFM_RETURN_IF(ba_solve_core(P.D, o, sg, bound, sum, &cur));
+    lap("solve");
     OSFM_HIP_CHECK(hipMemcpyAsync(params, P.D.cams[cur].ptr, (size_t)n * 56, hipMemcpyDeviceToHost, s));
     OSFM_HIP_CHECK(hipStreamSynchronize(s));
     sum->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
