@@ -697,8 +697,11 @@ def end_to_end_bench(args, device_index, cpu_pairs_per_s, cpu_ransac_s_per_pair,
     if r_cap is not None:
         job["per_call_form"] = {"gpu_wall_s": r_cap.timings.total_s, "pose_estimation_s": r_cap.timings.pose_s,
                                 "identical_cameras": bool(np.array_equal(r.cam_params, r_cap.cam_params)),
+                                # (live features: alive features of alive tracks -- the per-call form works on compacted
+                                #  copies and leaves the feature flags of tracks that were dead at a compaction cleared)
                                 "identical_flags_and_points": bool(np.array_equal(r.tracks.alive_t, r_cap.tracks.alive_t) and
-                                                                   np.array_equal(r.tracks.alive_f, r_cap.tracks.alive_f) and
+                                                                   np.array_equal(r.tracks.live_f, r_cap.tracks.live_f) and
+                                                                   np.array_equal(r.tracks.alive_t & r.tracks.has_point, r_cap.tracks.alive_t & r_cap.tracks.has_point) and
                                                                    np.array_equal(r.tracks.point[r.tracks.alive_t & r.tracks.has_point],
                                                                                   r_cap.tracks.point[r_cap.tracks.alive_t & r_cap.tracks.has_point]))}
     gt, _ = P.canonical_ground_truth(iset, 0)

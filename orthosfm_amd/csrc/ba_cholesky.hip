@@ -524,8 +524,12 @@ __device__ __forceinline__ bool flow_wait_lanes(const CholFlow &f, FlowWaiter &w
         const int want_box = f.epoch | ((flow_xcc() + 1) << 24);
         for (int spins = 0;; ++spins) {
             if (!verdict) {
-                if (box_flag >= 0 && __hip_atomic_load(pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want_box) verdict = 2;
-                else if (__hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f.epoch) verdict = 1;
+                // both words asked for side by side: one round trip per poll, not two (a poll that found the mailbox
+                // flag unset went on to the second load only after the first had returned)
+                const int vb = __hip_atomic_load(pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int vs = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (box_flag >= 0 && vb == want_box) verdict = 2;
+                else if (vs == f.epoch) verdict = 1;
             }
             if (__ballot(verdict == 0) == 0) break;
             if ((spins & 15) == 15 && __hip_atomic_load(pab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f.epoch) { ok = false; break; }
