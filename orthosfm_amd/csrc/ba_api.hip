@@ -204,6 +204,12 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
     }
     int flow_epoch = 0;
     OSFM_HIP_CHECK(hipMemsetAsync(gmax_cam.ptr, 0, (size_t)std::max(C, 1) * 8, s));
+    // the cameras' derived tables, one per iterate buffer: whoever writes cameras writes their rows
+    OSFM_RETURN_IF(D.camder[0].alloc((size_t)std::max(C, 1) * kCamDer * 8));
+    OSFM_RETURN_IF(D.camder[1].alloc((size_t)std::max(C, 1) * kCamDer * 8));
+    d.camder2[0] = D.camder[0].as<double>(); d.camder2[1] = D.camder[1].as<double>();
+    d.camder = d.camder2[0];
+    launch_cam_derive(d, D.cams[0].as<double>(), d.camder2[0], s);
 
     PointPassArgs pa;
     memset(&pa, 0, sizeof(pa));
@@ -355,13 +361,14 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
         ba.y_c = y_c.as<double>(); ba.vinv = vinv.as<double>(); ba.ge = ge.as<double>(); ba.obsrec = obsrec.as<double>();
         ba.points_out = nullptr; ba.partials = partB.as<double>();
         if (fused) {
-            ba.fused = 1; ba.partials_cam = part_cam.as<double>(); ba.cost_partials = partC.as<double>();
+            ba.fused = 1; ba.cost_partials = partC.as<double>();
             ba.decide.lm = lm; ba.decide.prm = prm; ba.decide.sc = sc; ba.decide.host_out = eager ? nullptr : &h_state[slot];
             ba.decide.ticket = tickets.as<int32_t>(); ba.decide.enabled = 1;
+            if (!small) launch_cam_update(d, y_c.as<double>(), nullptr, nullptr, part_cam.as<double>(), s);
             launch_back_pass(d, ba, blocksM, s);
             OSFM_RETURN_IF(toc());
         } else {
-            if (!small) launch_cam_update(d, y_c.as<double>(), nullptr, part_cam.as<double>(), s);
+            if (!small) launch_cam_update(d, y_c.as<double>(), nullptr, nullptr, part_cam.as<double>(), s);
             launch_back_pass(d, ba, blocksM, s);
             OSFM_RETURN_IF(toc());
             launch_cost_pass(d, nullptr, nullptr, partC.as<double>(), blocksM, s);

@@ -324,8 +324,10 @@ chol_small_kernel(const double *A, int ld, int n, double *Ldiag, double *x, int 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // a failed factorisation is noticed by ba_lm_decide (chol_info); the candidates it then
     // ignores are written all the same, like the general path does
+    // (four lanes per camera: each a quarter of the candidate's table row)
     double *cams_out = d.lm->cur ? d.cams2[0] : d.cams2[1];
-    for (int c = lane; c < d.C; c += 64) cam_update_one(d, xs, cams_out, partials_cam, c);
+    double *table_out = d.lm->cur ? d.camder2[0] : d.camder2[1];
+    for (int c = lane >> 2; c < d.C; c += 16) cam_update_part(d, xs, c, lane & 3, cams_out, partials_cam, table_out, kCamDer);
 }
 
 // Step k of the right-looking factorisation as ONE launch: tile (i, j), k < j <= i <= nblk

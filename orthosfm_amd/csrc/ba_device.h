@@ -45,6 +45,9 @@ struct BaDev {
     // (lm == nullptr: cams / points above are used as they are)
     double *cams2[2];
     double *points2[2];
+    // per-camera derived tables (cam_derive below), one per iterate buffer; camder = that of `cams`
+    const double *camder;
+    double *camder2[2];
     const LmDev *lm;
     const double *obs_xy;        // [O][2]
     const int32_t *obs_cam;      // [O]
@@ -82,6 +85,7 @@ __device__ __forceinline__ bool lm_resolve(BaDev &d)
     const int cur = d.lm->cur;
     d.cams = cur ? d.cams2[1] : d.cams2[0];
     d.points = cur ? d.points2[1] : d.points2[0];
+    d.camder = cur ? d.camder2[1] : d.camder2[0];
     return true;
 }
 
@@ -266,6 +270,161 @@ eval_euler(const double *cam, const double *P, double W, double H, double ox, do
     e.JP[1][3] = -gy * (R1[0] * p[0] + R1[1] * p[1] + R1[2] * p[2]) * iw;
 }
 
+// ---------------------------------------------------------------------------
+// Per-camera derived table.  Both functors map the inhomogeneous point p LINEARLY into the camera, l = R p with R a
+// function of the camera alone, and every rotation column of the Jacobian is linear in p too: d l / d theta_c =
+// D_c p.  The linearisation used to derive all of it again per OBSERVATION -- the quaternion algebra with a dozen
+// divisions, or three sincos and six 3 x 3 products for the Euler model: ~900 double-precision instructions per
+// observation in a point pass that those bound (profiles/r04_pmc_ba.txt).  The table holds, per camera, the first
+// two rows of R and of D_0..D_2 and the scalars of the pixel map; an observation is then ~100 multiply-adds.  The
+// kernels that make cameras make their tables (ba_cam_update, the back pass, chol_small, ba_cam_derive for the
+// first iterate) by evaluating the functors' own expressions at the three unit points:
+//   [0..5]   R[i][k]      i = 0, 1 (rows of l), k = 0..2
+//   [6] 1 / s   [7] offX   [8] offY   [9] W   [10] H
+//   [11] 1.0 when the camera's free columns are the first n full columns in order (colmap[t] == t), else 0.0
+//   -- up to here: all a COST needs (kCamCost doubles; the candidate's table in the back pass is just these) --
+//   [12..29] D_c[i][k]    at 12 + 6 c + 3 i + k, c = 0..2 (quaternion: the tangent of
+//            EigenQuaternionParameterization; Euler: phi, theta, rho)
+// 30 doubles: 16-byte aligned rows whose LDS copies do not all start in the same bank (32 would).
+// ---------------------------------------------------------------------------
+constexpr int kCamDer = 30;
+constexpr int kCamCost = 12;
+
+// l_{0,1} = (R p)_{0,1} and (want_j) d l_{0,1} / d (rotation tangent c): the camera part of eval_quat
+__device__ __forceinline__ void
+quat_local(const double *cam, const double p[3], bool want_j, double l[2], double dl[2][3])
+{
+    const double qx = cam[0], qy = cam[1], qz = cam[2], qw = cam[3];
+    const double n2 = qx * qx + qy * qy + qz * qz + qw * qw;
+    const double a[3] = { -qx / n2, -qy / n2, -qz / n2 };
+    const double b = qw / n2;
+    double t[3];
+    cross3(a, p, t);
+    double t2[3] = { 2.0 * t[0], 2.0 * t[1], 2.0 * t[2] };
+    double at2[3];
+    cross3(a, t2, at2);
+    l[0] = p[0] + b * t2[0] + at2[0];
+    l[1] = p[1] + b * t2[1] + at2[1];
+    if (!want_j) return;
+    double dl_da[3][2];
+    for (int k = 0; k < 3; ++k) {
+        double ek[3] = { 0.0, 0.0, 0.0 };
+        ek[k] = 1.0;
+        double ekp[3], ekt[3], aekp[3];
+        cross3(ek, p, ekp);
+        cross3(ek, t, ekt);
+        cross3(a, ekp, aekp);
+        dl_da[k][0] = 2.0 * b * ekp[0] + 2.0 * (ekt[0] + aekp[0]);
+        dl_da[k][1] = 2.0 * b * ekp[1] + 2.0 * (ekt[1] + aekp[1]);
+    }
+    const double dl_db[2] = { 2.0 * t[0], 2.0 * t[1] };
+    const double u[3] = { qx, qy, qz };
+    const double in2 = 1.0 / n2, in4 = in2 * in2;
+    double Jq[2][4];
+    for (int m = 0; m < 3; ++m) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            const double dai = (i == m ? -in2 : 0.0) + 2.0 * u[i] * u[m] * in4;
+            s0 += dl_da[i][0] * dai;
+            s1 += dl_da[i][1] * dai;
+        }
+        const double dbm = -2.0 * qw * u[m] * in4;
+        Jq[0][m] = s0 + dl_db[0] * dbm;
+        Jq[1][m] = s1 + dl_db[1] * dbm;
+    }
+    {
+        double s0 = 0.0, s1 = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            const double dai = 2.0 * u[i] * qw * in4;
+            s0 += dl_da[i][0] * dai;
+            s1 += dl_da[i][1] * dai;
+        }
+        const double dbw = in2 - 2.0 * qw * qw * in4;
+        Jq[0][3] = s0 + dl_db[0] * dbw;
+        Jq[1][3] = s1 + dl_db[1] * dbw;
+    }
+    const double PJ[4][3] = { { qw, qz, -qy }, { -qz, qw, qx }, { qy, -qx, qw }, { -qx, -qy, -qz } };
+    for (int c = 0; c < 3; ++c) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int i = 0; i < 4; ++i) { s0 += Jq[0][i] * PJ[i][c]; s1 += Jq[1][i] * PJ[i][c]; }
+        dl[0][c] = s0;
+        dl[1][c] = s1;
+    }
+}
+
+// the camera part of eval_euler
+__device__ __forceinline__ void
+euler_local(const double *cam, const double p[3], bool want_j, double l[2], double dl[2][3])
+{
+    const double phi = cam[0], theta = cam[1], rho = cam[2];
+    const double om = theta + 1.57079632679489661923;     // M_PI_2
+    double so, co, sr, cr, sp, cp;
+    sincos(om, &so, &co);
+    sincos(rho, &sr, &cr);
+    sincos(phi, &sp, &cp);
+    const double Rx[3][3] = { { 1, 0, 0 }, { 0, co, -so }, { 0, so, co } };
+    const double Ry[3][3] = { { cr, -sr, 0 }, { sr, cr, 0 }, { 0, 0, 1 } };
+    const double Rz[3][3] = { { cp, -sp, 0 }, { sp, cp, 0 }, { 0, 0, 1 } };
+    double A[3][3], S[3][3];
+    mat3_mul(Rz, Rx, A);
+    mat3_mul(A, Ry, S);
+    const double tp[3] = { p[0], -p[2], p[1] };            // T * p
+    for (int i = 0; i < 2; ++i) l[i] = S[0][i] * tp[0] + S[1][i] * tp[1] + S[2][i] * tp[2];
+    if (!want_j) return;
+    const double dRx[3][3] = { { 0, 0, 0 }, { 0, -so, -co }, { 0, co, -so } };
+    const double dRy[3][3] = { { -sr, -cr, 0 }, { cr, -sr, 0 }, { 0, 0, 0 } };
+    const double dRz[3][3] = { { -sp, -cp, 0 }, { cp, -sp, 0 }, { 0, 0, 0 } };
+    double B1[3][3], dS[3][3];
+    mat3_mul(dRz, Rx, B1);
+    mat3_mul(B1, Ry, dS);
+    dl[0][0] = dS[0][0] * tp[0] + dS[1][0] * tp[1] + dS[2][0] * tp[2];
+    dl[1][0] = dS[0][1] * tp[0] + dS[1][1] * tp[1] + dS[2][1] * tp[2];
+    mat3_mul(Rz, dRx, B1);
+    mat3_mul(B1, Ry, dS);
+    dl[0][1] = dS[0][0] * tp[0] + dS[1][0] * tp[1] + dS[2][0] * tp[2];
+    dl[1][1] = dS[0][1] * tp[0] + dS[1][1] * tp[1] + dS[2][1] * tp[2];
+    mat3_mul(A, dRy, dS);
+    dl[0][2] = dS[0][0] * tp[0] + dS[1][0] * tp[1] + dS[2][0] * tp[2];
+    dl[1][2] = dS[0][1] * tp[0] + dS[1][1] * tp[1] + dS[2][1] * tp[2];
+}
+
+// Part `part` of a camera's table (cam: its 7 parameters): parts 0..2 probe the unit point e_part and store column
+// `part` of R (and of D_0..D_2 when want_j); part 3 stores the scalars.  Four neighbouring lanes make a table
+// together, or one lane calls all four parts.  out: the camera's row, stride given (kCamDer, or kCamCost for a
+// cost-only copy).
+__device__ __forceinline__ void
+cam_derive_part(int model, const double *cam, double W, double H, const int8_t *colmap, int n, int part, bool want_j,
+    double *out)
+{
+    if (part < 3) {
+        const double pk[3] = { part == 0 ? 1.0 : 0.0, part == 1 ? 1.0 : 0.0, part == 2 ? 1.0 : 0.0 };
+        double l[2], dl[2][3];
+        if (model == kModelQuat) quat_local(cam, pk, want_j, l, dl);
+        else euler_local(cam, pk, want_j, l, dl);
+        out[part] = l[0];
+        out[3 + part] = l[1];
+        if (want_j) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { out[12 + 6 * c + part] = dl[0][c]; out[12 + 6 * c + 3 + part] = dl[1][c]; }
+        }
+        return;
+    }
+    const double s = model == kModelQuat ? cam[6] : cam[5];
+    out[6] = 1.0 / s;
+    out[7] = model == kModelQuat ? cam[4] : cam[3];
+    out[8] = model == kModelQuat ? cam[5] : cam[4];
+    out[9] = W;
+    out[10] = H;
+    bool ident = true;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) ident = ident && (t >= n || colmap[t] == t);
+    out[11] = ident ? 1.0 : 0.0;
+}
+
+// What a track gives each of its observations: p = P / w and G = (1 / w) HJ diag(scale_p), HJ the tangent basis of
+// the homogeneous point -- the whole point side of the Jacobian but for the camera's R.
+struct PointDer { double p[3]; double G[4][3]; };
+
 // internal::ComputeHouseholderVector for a 4-vector (ceres householder_vector.h)
 __device__ __forceinline__ void householder4(const double *x, double v[4], double &beta)
 {
@@ -343,34 +502,67 @@ struct ObsLin {
     int off;      // offset of the camera in the tangent vector
 };
 
-// the robustified residual of observation k at camera parameters cams[obs_cam[k]] and the point P itself (a
-// candidate still in registers): what linearize_obs(..., want_j = false) leaves in o.rho0
+// p = P / w of a track and, for a linearisation, the point side of its observations' Jacobians
+__device__ __forceinline__ void point_der(const BaDev &d, int j, const double *P, bool want_j, PointDer &pd)
+{
+    pd.p[0] = P[0] / P[3]; pd.p[1] = P[1] / P[3]; pd.p[2] = P[2] / P[3];
+    if (!want_j) return;
+    if (!d.pdim) {
+        for (int k = 0; k < 4; ++k)
+            for (int t = 0; t < 3; ++t) pd.G[k][t] = 0.0;
+        return;
+    }
+    const double iw = 1.0 / P[3];
+    double HJ[4][3];
+    homog_jacobian(P, HJ);
+    for (int t = 0; t < 3; ++t) {
+        const double sc = iw * d.scale_p[3 * j + t];
+        for (int k = 0; k < 4; ++k) pd.G[k][t] = sc * HJ[k][t];
+    }
+}
+
+// the pixel residual of the functors (pixel_residual above) from a camera's table row: l = R p, 1 / s a factor
+__device__ __forceinline__ void
+table_residual(const double *cd, const double p[3], double ox, double oy, double l[2], double r[2])
+{
+    l[0] = cd[0] * p[0] + cd[1] * p[1] + cd[2] * p[2];
+    l[1] = cd[3] * p[0] + cd[4] * p[1] + cd[5] * p[2];
+    r[0] = cd[9] * ((((l[0] * cd[6]) - cd[7]) * (-0.5)) + 0.5) - ox;
+    r[1] = cd[10] * ((((l[1] * cd[6]) - cd[8]) * (-0.5)) + 0.5) - oy;
+}
+
+// the robustified squared residual of observation k at the cameras whose table rows (stride doubles apart, the cost
+// part is enough) are at tab, and the point p = P / w: what linearize_obs(..., want_j = false) leaves in o.rho0
 __device__ __forceinline__ double
-obs_cost_at(const BaDev &d, int k, const double *cams, const double (&P)[4])
+obs_cost_at(const BaDev &d, int k, const double *tab, int stride, const double p[3])
 {
     const int c = d.obs_cam[k];
-    ObsFull e;
-    if (d.model == kModelQuat)
-        eval_quat(cams + 7 * c, P, (double)d.img_w[c], (double)d.img_h[c], d.obs_xy[2 * k], d.obs_xy[2 * k + 1], false, e);
-    else
-        eval_euler(cams + 7 * c, P, (double)d.img_w[c], (double)d.img_h[c], d.obs_xy[2 * k], d.obs_xy[2 * k + 1], false, e);
-    const double s = e.r[0] * e.r[0] + e.r[1] * e.r[1];
+    const double2 *q = reinterpret_cast<const double2 *>(tab + (size_t)stride * c);
+    double cd[kCamCost];
+#pragma unroll
+    for (int i = 0; i < kCamCost / 2; ++i) { const double2 v = q[i]; cd[2 * i] = v.x; cd[2 * i + 1] = v.y; }
+    double l[2], r[2];
+    table_residual(cd, p, d.obs_xy[2 * k], d.obs_xy[2 * k + 1], l, r);
+    const double s = r[0] * r[0] + r[1] * r[1];
     const double a = d.huber, b = a * a;
     return s > b ? 2.0 * a * sqrt(s) - b : s;
 }
 
+// tab: full table rows (kCamDer apart) of the cameras; pd: point_der of the observation's track
 __device__ __forceinline__ void
-linearize_obs(const BaDev &d, int k, const double *cams, const double *points, bool want_j, ObsLin &o)
+linearize_obs(const BaDev &d, int k, const double *tab, const PointDer &pd, ObsLin &o)
 {
-    const int c = d.obs_cam[k], j = d.obs_pt[k];
-    const double *cam = cams + 7 * c;
-    const double *P = points + 4 * j;
-    ObsFull e;
-    if (d.model == kModelQuat)
-        eval_quat(cam, P, (double)d.img_w[c], (double)d.img_h[c], d.obs_xy[2 * k], d.obs_xy[2 * k + 1], want_j, e);
-    else
-        eval_euler(cam, P, (double)d.img_w[c], (double)d.img_h[c], d.obs_xy[2 * k], d.obs_xy[2 * k + 1], want_j, e);
-    const double s = e.r[0] * e.r[0] + e.r[1] * e.r[1];
+    const int c = d.obs_cam[k];
+    const double2 *q = reinterpret_cast<const double2 *>(tab + (size_t)kCamDer * c);
+    double cd[kCamDer];
+#pragma unroll
+    for (int i = 0; i < kCamDer / 2; ++i) { const double2 v = q[i]; cd[2 * i] = v.x; cd[2 * i + 1] = v.y; }
+    const double2 xy = reinterpret_cast<const double2 *>(d.obs_xy)[k];
+    o.n = d.cam_ldim[c];
+    o.off = d.cam_off[c];
+    double l[2], r[2];
+    table_residual(cd, pd.p, xy.x, xy.y, l, r);
+    const double s = r[0] * r[0] + r[1] * r[1];
     const double a = d.huber, b = a * a;
     double rho1 = 1.0;
     if (s > b) {
@@ -381,39 +573,56 @@ linearize_obs(const BaDev &d, int k, const double *cams, const double *points, b
         o.rho0 = s;
     }
     const double sq = sqrt(rho1);
-    o.r[0] = sq * e.r[0];
-    o.r[1] = sq * e.r[1];
-    o.n = d.cam_ldim[c];
-    o.off = d.cam_off[c];
-    if (!want_j) return;
+    o.r[0] = sq * r[0];
+    o.r[1] = sq * r[1];
+    // d r / d l = (-W / 2s, -H / 2s), with the robustifier's factor in it
+    const double g[2] = { sq * (-0.5 * (cd[9] * cd[6])), sq * (-0.5 * (cd[10] * cd[6])) };
+    // the six full columns: rotation tangent (D_c p), offX, offY, scale
+    double J[2][6];
 #pragma unroll
-    for (int t = 0; t < 6; ++t) {
-        if (t < o.n) {
-            const int f = d.cam_colmap[6 * c + t];
-            const double sc = sq * d.scale_c[o.off + t];
-            // column f of the full Jacobian by a select chain: indexing the register
-            // array with f would put it (and this kernel's hot loop) into scratch memory
-            double j0 = e.Jc[0][0], j1 = e.Jc[1][0];
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-            for (int ff = 1; ff < 6; ++ff) { j0 = f == ff ? e.Jc[0][ff] : j0; j1 = f == ff ? e.Jc[1][ff] : j1; }
-            o.Jc[0][t] = sc * j0;
-            o.Jc[1][t] = sc * j1;
-        } else {
-            o.Jc[0][t] = 0.0;
-            o.Jc[1][t] = 0.0;
+        for (int cc = 0; cc < 3; ++cc) {
+            const double *D = cd + 12 + 6 * cc + 3 * i;
+            J[i][cc] = g[i] * (D[0] * pd.p[0] + D[1] * pd.p[1] + D[2] * pd.p[2]);
         }
+        J[i][5] = -(g[i] * l[i]) * cd[6];
     }
-    if (d.pdim) {
-        double HJ[4][3];
-        homog_jacobian(P, HJ);
-        for (int t = 0; t < 3; ++t) {
-            const double sc = sq * d.scale_p[3 * j + t];
-            o.Jp[0][t] = sc * (e.JP[0][0] * HJ[0][t] + e.JP[0][1] * HJ[1][t] + e.JP[0][2] * HJ[2][t] + e.JP[0][3] * HJ[3][t]);
-            o.Jp[1][t] = sc * (e.JP[1][0] * HJ[0][t] + e.JP[1][1] * HJ[1][t] + e.JP[1][2] * HJ[2][t] + e.JP[1][3] * HJ[3][t]);
+    J[0][3] = sq * (0.5 * cd[9]); J[1][3] = 0.0;
+    J[0][4] = 0.0;                J[1][4] = sq * (0.5 * cd[10]);
+    // restricted to the camera's free columns.  Almost every camera frees a prefix of the full columns in order
+    // (table entry 11); a camera that does not sends its wave through the select chain -- indexing the register
+    // array with the column number would put it (and this kernel's hot loop) into scratch memory
+    if (__all(cd[11] != 0.0)) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const double sc = t < o.n ? d.scale_c[o.off + t] : 0.0;
+            o.Jc[0][t] = sc * J[0][t];
+            o.Jc[1][t] = sc * J[1][t];
         }
     } else {
-        for (int t = 0; t < 3; ++t) { o.Jp[0][t] = 0.0; o.Jp[1][t] = 0.0; }
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            if (t < o.n) {
+                const int f = d.cam_colmap[6 * c + t];
+                const double sc = d.scale_c[o.off + t];
+                double j0 = J[0][0], j1 = J[1][0];
+#pragma unroll
+                for (int ff = 1; ff < 6; ++ff) { j0 = f == ff ? J[0][ff] : j0; j1 = f == ff ? J[1][ff] : j1; }
+                o.Jc[0][t] = sc * j0;
+                o.Jc[1][t] = sc * j1;
+            } else {
+                o.Jc[0][t] = 0.0;
+                o.Jc[1][t] = 0.0;
+            }
+        }
     }
+    // point: d r_i / d P = g_i (R_i, -l_i) / w, times the tangent basis and the point's column scales (pd.G)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            o.Jp[i][t] = g[i] * (cd[3 * i] * pd.G[0][t] + cd[3 * i + 1] * pd.G[1][t] + cd[3 * i + 2] * pd.G[2][t] - l[i] * pd.G[3][t]);
 }
 
 // inverse of a symmetric positive definite 3x3 via Cholesky; false if not PD
@@ -443,13 +652,12 @@ __device__ __forceinline__ bool inv3_spd(const double A[3][3], double inv[3][3])
     return true;
 }
 
-// Candidate of one camera: x+ = Plus(x, scale * step), step = -y, and the camera's share of
-// the step / parameter norms (ambient coordinates of the non-constant blocks).
+// Candidate of one camera: x+ = Plus(x, scale * step), step = -y, into out[7]; sn / xn: the camera's share of the
+// step / parameter norms (ambient coordinates of the non-constant blocks).
 __device__ __forceinline__ void
-cam_update_one(const BaDev &d, const double *y_c, double *cams_out, double *partials_cam, int c, double *cams_out2 = nullptr)
+cam_candidate(const BaDev &d, const double *y_c, int c, double (&out)[7], double &sn, double &xn)
 {
     const double *cam = d.cams + 7 * c;
-    double out[7];
     for (int i = 0; i < 7; ++i) out[i] = cam[i];
     const int n = d.cam_ldim[c], off = d.cam_off[c];
     double dl[6];
@@ -458,7 +666,7 @@ cam_update_one(const BaDev &d, const double *y_c, double *cams_out, double *part
     if (d.model == kModelQuat && n > 0 && d.cam_colmap[6 * c] == 0) { quat_plus(cam, dl, out); t0 = 3; }
     // unrolled with selects: out[slot] / act[f] with a run-time index would put the arrays into scratch memory
     // norms over the ambient coordinates of the non-constant blocks
-    double sn = 0.0, xn = 0.0;
+    sn = 0.0; xn = 0.0;
     bool act[7] = { false, false, false, false, false, false, false };
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
@@ -474,16 +682,32 @@ cam_update_one(const BaDev &d, const double *y_c, double *cams_out, double *part
         }
     }
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        cams_out[7 * c + i] = out[i];
-        if (cams_out2) cams_out2[7 * c + i] = out[i];
+    for (int i = 0; i < 7; ++i)
         if (act[i]) { sn += (cam[i] - out[i]) * (cam[i] - out[i]); xn += cam[i] * cam[i]; }
+}
+
+// Lane `part` (0..3) of the four that make camera c's candidate: all four compute it (a hundred instructions),
+// part 0 stores it and its norms, and each stores its part of the candidate's table row.
+//   cams_out / partials_cam / table_out may each be null (table_stride: kCamDer with the Jacobian part, kCamCost
+//   without)
+__device__ __forceinline__ void
+cam_update_part(const BaDev &d, const double *y_c, int c, int part, double *cams_out, double *partials_cam,
+    double *table_out, int table_stride)
+{
+    double out[7], sn, xn;
+    cam_candidate(d, y_c, c, out, sn, xn);
+    if (part == 0) {
+        if (cams_out)
+            for (int i = 0; i < 7; ++i) cams_out[7 * c + i] = out[i];
+        if (partials_cam) {
+            // (write-through: the workgroup that decides reads them in the same launch, maybe from another XCD)
+            store_sc1(&partials_cam[2 * c], sn);
+            store_sc1(&partials_cam[2 * c + 1], xn);
+        }
     }
-    if (partials_cam) {
-        // (write-through: the workgroup that decides reads them in the same launch, maybe from another XCD)
-        store_sc1(&partials_cam[2 * c], sn);
-        store_sc1(&partials_cam[2 * c + 1], xn);
-    }
+    if (table_out)
+        cam_derive_part(d.model, out, (double)d.img_w[c], (double)d.img_h[c], d.cam_colmap + 6 * c, d.cam_ldim[c], part,
+            table_stride == kCamDer, table_out + (size_t)table_stride * c);
 }
 
 }  // namespace osfm

@@ -110,11 +110,10 @@ struct BackPassArgs {
     const double *obsrec;     // [O][kObsRec]
     double *points_out;       // [M][4] candidate points
     double *partials;         // [3][blocks]: model cost change, |dx|^2, |x|^2
-    // fused form (LM solve whose camera tables, candidates included, fit LDS): the launch also makes the candidate
-    // cameras (every workgroup for itself, in LDS; workgroup 0 writes them out), evaluates the candidate's cost
-    // (the cost pass: a launch and a pass over the observations less) and, in its last workgroup, decides
+    // fused form (LM solve whose camera tables fit LDS): the launch also evaluates the candidate's cost from the
+    // table rows ba_cam_update / chol_small left for the candidate cameras (the cost pass: a launch and a pass over
+    // the observations less) and, in its last workgroup, decides
     int fused;
-    double *partials_cam;     // [C][2]
     double *cost_partials;    // [blocks]
     LmTail decide;
 };
@@ -126,12 +125,16 @@ void launch_lm_clear_abort(LmDev *lm, hipStream_t s);
 
 void launch_point_pass(const BaDev &d, const PointPassArgs &a, int blocks, hipStream_t s);
 void launch_pair_pass(const BaDev &d, const PairPassArgs &a, hipStream_t s);
-// cams_out == nullptr (LM solve): the candidate goes to the iterate buffer that is not current
-void launch_cam_update(const BaDev &d, const double *y_c, double *cams_out, double *partials_cam, hipStream_t s);
+// candidate cameras, their derived table rows (ba_device.h: cam_derive_part) and their share of the step norms;
+// cams_out / table_out == nullptr (LM solve): into the iterate buffers that are not current
+void launch_cam_update(const BaDev &d, const double *y_c, double *cams_out, double *table_out, double *partials_cam, hipStream_t s);
+// the table rows of the cameras at `cams`
+void launch_cam_derive(const BaDev &d, const double *cams, double *table_out, hipStream_t s);
 void launch_back_pass(const BaDev &d, const BackPassArgs &a, int blocks, hipStream_t s);
 size_t lm_ticket_bytes();
-bool back_pass_can_fuse(const BaDev &d);      // the camera tables and the candidate cameras fit LDS
-void launch_cost_pass(const BaDev &d, const double *cams, const double *points, double *partials,
+bool back_pass_can_fuse(const BaDev &d);      // the camera tables fit LDS
+// table: derived table rows of the cameras to evaluate at (ignored in an LM solve: the candidate's)
+void launch_cost_pass(const BaDev &d, const double *table, const double *points, double *partials,
     int blocks, hipStream_t s);
 void launch_reduce(const double *partials, int n, int num_slots, unsigned max_mask, double *out,
     const double *extra, int extra_n, int extra_stride, int extra_slots, hipStream_t s);

@@ -16,6 +16,7 @@
 // All sums that cross threads use fixed-order two-level reductions (no
 // floating-point atomics): the solve is bit-reproducible run to run.
 #include "ba_kernels.h"
+#include <cstdlib>
 
 namespace osfm {
 
@@ -152,14 +153,32 @@ size_t lm_ticket_bytes() { return (size_t)(kTicketShards + 1) * kTicketStride * 
 // ---------------------------------------------------------------------------
 constexpr size_t kCamStageLimit = 64 * 1024;
 
-// with_candidates: room for a second set of camera parameters behind the tables (the fused back pass)
-static size_t cam_stage_bytes(const BaDev &d, bool with_y, bool with_candidates = false)
+// what a kernel wants in LDS (cam_ldim / cam_off always come along)
+enum {
+    kStageTable = 1,        // the cameras' derived table rows, whole (linearisation)
+    kStageCost = 2,         // the cost part of the table rows only (kCamCost of kCamDer doubles)
+    kStageScale = 4,        // scale_c
+    kStageY = 8,            // the solution vector y_c
+    kStageColmap = 16,
+};
+
+static size_t cam_stage_bytes(const BaDev &d, int what)
 {
     auto r8 = [](size_t bytes) { return (bytes + 7) / 8 * 8; };      // stage_array rounds every table up
-    const size_t b = 8 * ((size_t)7 * d.C * (with_candidates ? 2 : 1) + (size_t)d.nc * (with_y ? 2 : 1)) + 4 * r8((size_t)4 * d.C) + r8((size_t)6 * d.C);
+    size_t b = 2 * r8((size_t)4 * d.C);
+    if (what & kStageTable) b += (size_t)8 * kCamDer * d.C;
+    if (what & kStageCost) b += (size_t)8 * kCamCost * d.C;
+    if (what & kStageScale) b += (size_t)8 * d.nc;
+    if (what & kStageY) b += (size_t)8 * d.nc;
+    if (what & kStageColmap) b += r8((size_t)6 * d.C);
+    static const int mask = getenv("OSFM_BA_STAGE_MASK") ? atoi(getenv("OSFM_BA_STAGE_MASK")) : 2;   // 1: point pass, 2: back / cost pass.
+    // Measured (200 cameras, 750k observations): the point pass with its 60 KB of table rows staged runs two
+    // waves per SIMD and takes 114 us, reading the rows from L2 98 us; the back pass's 30 KB pay (104 against 114 us)
+    if (!(mask & ((what & kStageTable) ? 1 : 2))) return 0;
     return b <= kCamStageLimit ? b : 0;
 }
-bool back_pass_can_fuse(const BaDev &d) { return d.C > 0 && cam_stage_bytes(d, true, true) != 0; }
+constexpr int kStageBack = kStageY, kStageBackFused = kStageY | kStageCost, kStagePoint = kStageTable | kStageScale | kStageColmap;
+bool back_pass_can_fuse(const BaDev &d) { return d.C > 0; }
 
 template <typename T>
 __device__ __forceinline__ const T *stage_array(const T *src, int n, char *&lds)
@@ -178,23 +197,42 @@ __device__ __forceinline__ const T *stage_array(const T *src, int n, char *&lds)
     return dst;
 }
 
-// d with its per-camera arrays (and cams / y_c, if given) replaced by LDS copies
-__device__ __forceinline__ BaDev stage_cameras(const BaDev &d, char *lds, bool staged, const double *&cams,
-    const double **y_c, char **lds_end = nullptr)
+// the first kCamCost doubles of every table row, packed
+__device__ __forceinline__ const double *stage_cost_rows(const double *table, int C, char *&lds)
+{
+    double *dst = reinterpret_cast<double *>(lds);
+    const int n = kCamCost * C;
+    constexpr int kB = 4;
+    for (int i0 = 0; i0 < n; i0 += kB * 256) {
+        double v[kB];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+            const int i = min(i0 + u * 256 + (int)threadIdx.x, n - 1), row = i / kCamCost;
+            v[u] = table[(size_t)row * kCamDer + (i - row * kCamCost)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kB; ++u) { const int i = i0 + u * 256 + (int)threadIdx.x; if (i < n) dst[i] = v[u]; }
+    }
+    lds += (size_t)n * 8;
+    return dst;
+}
+
+// d with the per-camera arrays named in `what` replaced by LDS copies (what == 0: d as it is).
+//   table: the table rows to stage (kStageTable: whole, returned in o.camder with stride kCamDer; kStageCost: their
+//   cost parts, returned in *cost_rows with stride kCamCost)
+__device__ __forceinline__ BaDev stage_cameras(const BaDev &d, char *lds, int what, const double *table,
+    const double **cost_rows, const double **y_c)
 {
     BaDev o = d;
-    if (lds_end) *lds_end = lds;
-    if (!staged || d.C <= 0) return o;
-    cams = stage_array(cams, 7 * d.C, lds);
-    o.cams = cams;
-    if (d.nc > 0) o.scale_c = stage_array(d.scale_c, d.nc, lds);
-    if (y_c && d.nc > 0) *y_c = stage_array(*y_c, d.nc, lds);
-    o.img_w = stage_array(d.img_w, d.C, lds);
-    o.img_h = stage_array(d.img_h, d.C, lds);
+    if (!what || d.C <= 0) return o;
+    if (what & kStageTable) o.camder = stage_array(table, kCamDer * d.C, lds);
+    if (what & kStageCost) *cost_rows = stage_cost_rows(table, d.C, lds);
+    if ((what & kStageScale) && d.nc > 0) o.scale_c = stage_array(d.scale_c, d.nc, lds);
+    if ((what & kStageY) && d.nc > 0) *y_c = stage_array(*y_c, d.nc, lds);
     o.cam_ldim = stage_array(d.cam_ldim, d.C, lds);
     o.cam_off = stage_array(d.cam_off, d.C, lds);
-    o.cam_colmap = stage_array(d.cam_colmap, 6 * d.C, lds);
-    if (lds_end) *lds_end = lds;
+    if (what & kStageColmap) o.cam_colmap = stage_array(d.cam_colmap, 6 * d.C, lds);
     __syncthreads();
     return o;
 }
@@ -392,8 +430,7 @@ ba_point_pass_kernel(BaDev dg, PointPassArgs a, int staged)
         // the LM state decides what this linearisation is for
         a.radius = dg.lm->radius; a.update_diag = dg.lm->update_diag; a.want_gradient = dg.lm->want_gradient;
     }
-    const double *cams = dg.cams;
-    const BaDev d = stage_cameras(dg, cam_lds, staged != 0, cams, nullptr);
+    const BaDev d = stage_cameras(dg, cam_lds, staged ? kStagePoint : 0, dg.camder, nullptr, nullptr);
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = gt / kPointLanes, sub = gt % kPointLanes;       // a quad never straddles j < M
     double cost = 0.0, gmax = 0.0;
@@ -401,9 +438,11 @@ ba_point_pass_kernel(BaDev dg, PointPassArgs a, int staged)
     if (j < d.M) {
         const int k0 = d.pt_start[j], k1 = d.pt_start[j + 1];
         double V[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } }, g[3] = { 0, 0, 0 };
+        PointDer pd;
+        point_der(d, j, d.points + 4 * j, true, pd);
         for (int k = k0 + sub; k < k1; k += kPointLanes) {
             ObsLin o;
-            linearize_obs(d, k, d.cams, d.points, true, o);
+            linearize_obs(d, k, d.camder, pd, o);
             cost += 0.5 * o.rho0;
             // the record (16-byte aligned: 26 doubles) in 16-byte stores
             {
@@ -486,7 +525,7 @@ ba_point_pass_kernel(BaDev dg, PointPassArgs a, int staged)
 
 void launch_point_pass(const BaDev &d, const PointPassArgs &a, int blocks, hipStream_t s)
 {
-    const size_t lds = cam_stage_bytes(d, false);
+    const size_t lds = cam_stage_bytes(d, kStagePoint);
     hipLaunchKernelGGL(ba_point_pass_kernel, dim3(blocks), dim3(256), lds, s, d, a, lds ? 1 : 0);
 }
 
@@ -775,19 +814,41 @@ void launch_pair_pass(const BaDev &d, const PairPassArgs &a, hipStream_t s)
 // ---------------------------------------------------------------------------
 // candidate cameras: x+ = Plus(x, scale * step), step = -y
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void
-ba_cam_update_kernel(BaDev d, const double *y_c, double *cams_out, double *partials_cam)
+__global__ __launch_bounds__(64) void
+ba_cam_update_kernel(BaDev d, const double *y_c, double *cams_out, double *table_out, double *partials_cam)
 {
     if (!lm_resolve(d)) return;
-    if (d.lm) { if (d.lm->lin_failed) return; cams_out = d.lm->cur ? d.cams2[0] : d.cams2[1]; }
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d.lm) {
+        if (d.lm->lin_failed) return;
+        cams_out = d.lm->cur ? d.cams2[0] : d.cams2[1];
+        table_out = d.lm->cur ? d.camder2[0] : d.camder2[1];
+    }
+    // four lanes per camera: each makes the candidate, and a quarter of its table
+    const int q = blockIdx.x * blockDim.x + threadIdx.x, c = q >> 2;
     if (c >= d.C) return;
-    cam_update_one(d, y_c, cams_out, partials_cam, c);
+    cam_update_part(d, y_c, c, q & 3, cams_out, partials_cam, table_out, kCamDer);
 }
 
-void launch_cam_update(const BaDev &d, const double *y_c, double *cams_out, double *partials_cam, hipStream_t s)
+void launch_cam_update(const BaDev &d, const double *y_c, double *cams_out, double *table_out, double *partials_cam, hipStream_t s)
 {
-    hipLaunchKernelGGL(ba_cam_update_kernel, dim3((d.C + 127) / 128), dim3(128), 0, s, d, y_c, cams_out, partials_cam);
+    if (d.C > 0) hipLaunchKernelGGL(ba_cam_update_kernel, dim3((4 * d.C + 63) / 64), dim3(64), 0, s, d, y_c, cams_out, table_out, partials_cam);
+}
+
+// the table rows of cameras given as they are (the first iterate of a solve)
+__global__ __launch_bounds__(64) void
+ba_cam_derive_kernel(BaDev d, const double *cams, double *table_out)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x, c = q >> 2;
+    if (c >= d.C) return;
+    double cam[7];
+    for (int i = 0; i < 7; ++i) cam[i] = cams[7 * c + i];
+    cam_derive_part(d.model, cam, (double)d.img_w[c], (double)d.img_h[c], d.cam_colmap + 6 * c, d.cam_ldim[c], q & 3, true,
+        table_out + (size_t)kCamDer * c);
+}
+
+void launch_cam_derive(const BaDev &d, const double *cams, double *table_out, hipStream_t s)
+{
+    if (d.C > 0) hipLaunchKernelGGL(ba_cam_derive_kernel, dim3((4 * d.C + 63) / 64), dim3(64), 0, s, d, cams, table_out);
 }
 
 // ---------------------------------------------------------------------------
@@ -809,19 +870,12 @@ ba_back_pass_kernel(BaDev dg, BackPassArgs a, int staged)
         if (fused && blockIdx.x == 0) lm_decide_block<true>(a.decide.lm, a.decide.prm, a.decide.sc, a.decide.host_out, sh);
         return;
     }
-    double *cams_global_out = nullptr;
-    if (dg.lm) { a.points_out = dg.lm->cur ? dg.points2[0] : dg.points2[1]; cams_global_out = dg.lm->cur ? dg.cams2[0] : dg.cams2[1]; }
-    const double *cams = dg.cams;
-    char *lds_end = nullptr;
-    const BaDev d = stage_cameras(dg, cam_lds, staged != 0, cams, &a.y_c, &lds_end);
-    // fused: the candidate cameras Plus(x, -step), every workgroup for itself behind its camera tables; workgroup 0
-    // also writes them (and the cameras' share of the step norms) where the cost pass / ba_cam_update did
-    double *cand = reinterpret_cast<double *>(lds_end);
-    if (fused) {
-        for (int c = threadIdx.x; c < d.C; c += 256)
-            cam_update_one(d, a.y_c, cand, blockIdx.x == 0 ? a.partials_cam : nullptr, c, blockIdx.x == 0 ? cams_global_out : nullptr);
-        __syncthreads();
-    }
+    // fused: the cost parts of the CANDIDATE cameras' table rows (ba_cam_update / chol_small made them just before)
+    const double *cand = nullptr;
+    int cand_stride = kCamDer;
+    if (dg.lm) { a.points_out = dg.lm->cur ? dg.points2[0] : dg.points2[1]; cand = dg.lm->cur ? dg.camder2[0] : dg.camder2[1]; }
+    const BaDev d = stage_cameras(dg, cam_lds, staged ? (fused ? kStageBackFused : kStageBack) : 0, cand, &cand, &a.y_c);
+    if (staged && fused) cand_stride = kCamCost;
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = gt / kPointLanes, sub = gt % kPointLanes;
     double mcc = 0.0, sn = 0.0, xn = 0.0, ccost = 0.0;
@@ -883,7 +937,8 @@ ba_back_pass_kernel(BaDev dg, BackPassArgs a, int staged)
         if (fused) {
             // the cost of the candidate (ba_cost_pass_kernel's sum, lane by lane): the candidate point is in the
             // registers of all four lanes of the track, the candidate cameras are in LDS
-            for (int k = k0 + sub; k < k1; k += kPointLanes) ccost += 0.5 * obs_cost_at(d, k, cand, out);
+            const double pc[3] = { out[0] / out[3], out[1] / out[3], out[2] / out[3] };
+            for (int k = k0 + sub; k < k1; k += kPointLanes) ccost += 0.5 * obs_cost_at(d, k, cand, cand_stride, pc);
         }
     }
     if (!fused) {
@@ -903,7 +958,7 @@ ba_back_pass_kernel(BaDev dg, BackPassArgs a, int staged)
 
 void launch_back_pass(const BaDev &d, const BackPassArgs &a, int blocks, hipStream_t s)
 {
-    const size_t lds = cam_stage_bytes(d, true, a.fused != 0);
+    const size_t lds = cam_stage_bytes(d, a.fused ? kStageBackFused : kStageBack);
     hipLaunchKernelGGL(ba_back_pass_kernel, dim3(blocks), dim3(256), lds, s, d, a, lds ? 1 : 0);
 }
 
@@ -911,34 +966,35 @@ void launch_back_pass(const BaDev &d, const BackPassArgs &a, int blocks, hipStre
 // cost at (cams, points) given explicitly
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void
-ba_cost_pass_kernel(BaDev dg, const double *cams, const double *points, double *partials, int staged)
+ba_cost_pass_kernel(BaDev dg, const double *table, const double *points, double *partials, int staged)
 {
     extern __shared__ __attribute__((aligned(16))) char cam_lds[];
     __shared__ double sh[4];
     if (dg.lm) {
         // LM solve: the cost of the CANDIDATE (the iterate buffer that is not current)
         if (dg.lm->stop || dg.lm->lin_failed || dg.lm->flow_aborted) return;
-        cams = dg.lm->cur ? dg.cams2[0] : dg.cams2[1]; points = dg.lm->cur ? dg.points2[0] : dg.points2[1];
+        table = dg.lm->cur ? dg.camder2[0] : dg.camder2[1]; points = dg.lm->cur ? dg.points2[0] : dg.points2[1];
     }
-    const BaDev d = stage_cameras(dg, cam_lds, staged != 0, cams, nullptr);
+    const double *rows = table;
+    const BaDev d = stage_cameras(dg, cam_lds, staged ? kStageCost : 0, table, &rows, nullptr);
+    const int stride = staged ? kCamCost : kCamDer;
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = gt / kPointLanes, sub = gt % kPointLanes;
     double cost = 0.0;
     if (j < d.M) {
-        for (int k = d.pt_start[j] + sub; k < d.pt_start[j + 1]; k += kPointLanes) {
-            ObsLin o;
-            linearize_obs(d, k, cams, points, false, o);
-            cost += 0.5 * o.rho0;
-        }
+        const double *P = points + 4 * j;
+        const double p[3] = { P[0] / P[3], P[1] / P[3], P[2] / P[3] };
+        for (int k = d.pt_start[j] + sub; k < d.pt_start[j + 1]; k += kPointLanes) cost += 0.5 * obs_cost_at(d, k, rows, stride, p);
     }
     block_partial<false>(cost, partials, 0, sh);
 }
 
-void launch_cost_pass(const BaDev &d, const double *cams, const double *points, double *partials,
+// table: the derived table rows of the cameras (ba_cam_derive / ba_cam_update)
+void launch_cost_pass(const BaDev &d, const double *table, const double *points, double *partials,
     int blocks, hipStream_t s)
 {
-    const size_t lds = cam_stage_bytes(d, false);
-    hipLaunchKernelGGL(ba_cost_pass_kernel, dim3(blocks), dim3(256), lds, s, d, cams, points, partials, lds ? 1 : 0);
+    const size_t lds = cam_stage_bytes(d, kStageCost);
+    hipLaunchKernelGGL(ba_cost_pass_kernel, dim3(blocks), dim3(256), lds, s, d, table, points, partials, lds ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------

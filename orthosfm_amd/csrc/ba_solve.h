@@ -43,6 +43,7 @@ struct Layout {
 struct DeviceProblem {
     DevArray cams[2], points[2], obs_xy, obs_cam, obs_pt, pt_start, img_w, img_h;
     DevArray cam_ldim, cam_off, colmap, scale_c, scale_p;
+    DevArray camder[2];       // the cameras' derived table rows, per iterate buffer (ba_solve_core)
     BaDev dev;
 };
 
