@@ -167,14 +167,35 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
     hipStream_t s = sg.s;
     BaDev &d = D.dev;
     const int C = d.C, M = d.M, nc = d.nc, pdim = d.pdim;
+    // observation windows of the per-point passes (ba_kernels.h): one workgroup, one partial slot each.  Laid out
+    // by a kernel queued in front of the pair lists; the count of windows that need the other kernels comes back
+    // with the pair lists' own synchronisation
+    if (nc >= (1 << 24)) { set_error("ba_solve: more than 2^24 camera unknowns"); return OSFM_E_ARG; }
+    const int max_slots = o.max_num_iterations + 3;
+    OSFM_RETURN_IF(sg.set->ensure_pinned((size_t)max_slots * sizeof(LmDev)));
+    LmDev *h_state = static_cast<LmDev *>(sg.set->pinned);
+    ObsWindows win;
+    win.num = obs_windows_count(d.O);
+    DevArray win_desc, win_over, win_count, obs_lay;
+    OSFM_RETURN_IF(win_desc.alloc((size_t)win.num * sizeof(WinDesc)));
+    OSFM_RETURN_IF(win_over.alloc((size_t)win.num * 4));
+    OSFM_RETURN_IF(win_count.alloc(16));
+    OSFM_RETURN_IF(obs_lay.alloc((size_t)std::max(d.O, 1) * 4));
+    OSFM_HIP_CHECK(hipMemsetAsync(win_count.ptr, 0, 16, s));
+    launch_obs_windows(d, win.num, win_desc.as<WinDesc>(), win_over.as<int32_t>(), win_count.as<int32_t>(), obs_lay.as<int32_t>(), s);
+    int32_t *h_over = reinterpret_cast<int32_t *>(&h_state[max_slots - 1]);
+    OSFM_HIP_CHECK(hipMemcpyAsync(h_over, win_count.ptr, 4, hipMemcpyDeviceToHost, s));
+    win.desc = win_desc.as<WinDesc>(); win.over_list = win_over.as<int32_t>(); win.obs_lay = obs_lay.as<int32_t>();
     // camera-pair lists of the Schur complement, built on the device
     PairListsDev PL;
     OSFM_RETURN_IF(pair_lists_build(d, pdim != 0, std::max<int64_t>(pair_bound, 1), &PL, s));
     const int num_pairs = PL.num_pairs;
     sum->num_pair_entries = PL.num_entries;
+    OSFM_HIP_CHECK(hipStreamSynchronize(s));     // (pair_lists_build has synchronised: this returns at once)
+    win.num_over = *h_over;
     lap("pair lists (device)");
 
-    const int blocksM = std::max(1, (int)(((int64_t)M * kPointLanes + 255) / 256));
+    const int blocksM = win.num;
     const int N = cholesky_padded_dim(std::max(nc, 1));
     DevArray Lmat;
     DevArray obsrec, diag_c, diag_p, vinv, ge, S, Ldiag, y_c, partA, partB, partC, part_cam, gmax_cam, scalars, info;
@@ -247,10 +268,7 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
     init.radius = o.initial_trust_region_radius; init.decrease_factor = 2.0;
     init.update_diag = 1; init.want_gradient = 1; init.term = OSFM_BA_NO_CONVERGENCE;
     LmDev *lm = lmdev.as<LmDev>();
-    const int max_slots = o.max_num_iterations + 3;
-    OSFM_RETURN_IF(sg.set->ensure_pinned((size_t)max_slots * sizeof(LmDev)));
     OSFM_RETURN_IF(sg.set->ensure_events((size_t)max_slots + (o.verbose ? 8 * (size_t)max_slots : 0)));
-    LmDev *h_state = static_cast<LmDev *>(sg.set->pinned);
     memcpy(&h_state[0], &init, sizeof(init));
     OSFM_HIP_CHECK(hipMemcpyAsync(lm, &h_state[0], sizeof(LmDev), hipMemcpyHostToDevice, s));
     d.cams2[0] = D.cams[0].as<double>(); d.cams2[1] = D.cams[1].as<double>();
@@ -302,7 +320,7 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
     auto linearize = [&](bool reset, int post, LmDev *host_out) -> int {
         pa.mode = kPassNormal; qa.mode = kPassNormal;
         OSFM_RETURN_IF(tic(0));
-        launch_point_pass(d, pa, blocksM, s);
+        launch_point_pass(d, pa, win, s);
         OSFM_RETURN_IF(toc());
         if (reset) launch_reset_system(S.as<double>(), s_elems, N, nc, N, s);
         memset(&qa.post, 0, sizeof(qa.post));
@@ -322,12 +340,12 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
     if (o.jacobi_scaling) {
         pa.mode = kPassScaleInit; qa.mode = kPassScaleInit;
         pa.radius = qa.radius = o.initial_trust_region_radius;
-        launch_point_pass(d, pa, blocksM, s);
+        launch_point_pass(d, pa, win, s);
         launch_pair_pass(d, qa, s);
         OSFM_HIP_CHECK(hipGetLastError());
     }
     d.lm = lm;
-    const bool fused = back_pass_can_fuse(d) && getenv("OSFM_BA_SEPARATE_BACK") == nullptr;
+    const bool fused = C > 0 && getenv("OSFM_BA_SEPARATE_BACK") == nullptr;
     lap("alloc + lists up");
     OSFM_RETURN_IF(linearize(true, kPostInitial, nullptr));
     OSFM_HIP_CHECK(hipGetLastError());
@@ -365,13 +383,13 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
             ba.decide.lm = lm; ba.decide.prm = prm; ba.decide.sc = sc; ba.decide.host_out = eager ? nullptr : &h_state[slot];
             ba.decide.ticket = tickets.as<int32_t>(); ba.decide.enabled = 1;
             if (!small) launch_cam_update(d, y_c.as<double>(), nullptr, nullptr, part_cam.as<double>(), s);
-            launch_back_pass(d, ba, blocksM, s);
+            launch_back_pass(d, ba, win, s);
             OSFM_RETURN_IF(toc());
         } else {
             if (!small) launch_cam_update(d, y_c.as<double>(), nullptr, nullptr, part_cam.as<double>(), s);
-            launch_back_pass(d, ba, blocksM, s);
+            launch_back_pass(d, ba, win, s);
             OSFM_RETURN_IF(toc());
-            launch_cost_pass(d, nullptr, nullptr, partC.as<double>(), blocksM, s);
+            launch_cost_pass(d, nullptr, nullptr, partC.as<double>(), win, s);
             // the kernels write the state they leave straight into the host's slot
             launch_lm_decide(lm, prm, sc, eager ? nullptr : &h_state[slot], s);
         }

@@ -531,8 +531,19 @@ table_residual(const double *cd, const double p[3], double ox, double oy, double
     r[1] = cd[10] * ((((l[1] * cd[6]) - cd[8]) * (-0.5)) + 0.5) - oy;
 }
 
-// the robustified squared residual of observation k at the cameras whose table rows (stride doubles apart, the cost
-// part is enough) are at tab, and the point p = P / w: what linearize_obs(..., want_j = false) leaves in o.rho0
+// the robustified squared residual of an observation (ox, oy) from the cost part of its camera's table row and the
+// point p = P / w: what linearize_obs leaves in o.rho0
+__device__ __forceinline__ double
+row_cost(const double (&cd)[kCamCost], const double p[3], double ox, double oy, double huber)
+{
+    double l[2], r[2];
+    table_residual(cd, p, ox, oy, l, r);
+    const double s = r[0] * r[0] + r[1] * r[1];
+    const double b = huber * huber;
+    return s > b ? 2.0 * huber * sqrt(s) - b : s;
+}
+
+// ... of observation k, at the cameras whose table rows (stride doubles apart, the cost part is enough) are at tab
 __device__ __forceinline__ double
 obs_cost_at(const BaDev &d, int k, const double *tab, int stride, const double p[3])
 {
@@ -541,25 +552,26 @@ obs_cost_at(const BaDev &d, int k, const double *tab, int stride, const double p
     double cd[kCamCost];
 #pragma unroll
     for (int i = 0; i < kCamCost / 2; ++i) { const double2 v = q[i]; cd[2 * i] = v.x; cd[2 * i + 1] = v.y; }
-    double l[2], r[2];
-    table_residual(cd, p, d.obs_xy[2 * k], d.obs_xy[2 * k + 1], l, r);
-    const double s = r[0] * r[0] + r[1] * r[1];
-    const double a = d.huber, b = a * a;
-    return s > b ? 2.0 * a * sqrt(s) - b : s;
+    const double2 xy = reinterpret_cast<const double2 *>(d.obs_xy)[k];
+    return row_cost(cd, p, xy.x, xy.y, d.huber);
 }
 
-// tab: full table rows (kCamDer apart) of the cameras; pd: point_der of the observation's track
+// Observation k of camera c (lay: cam_off | cam_ldim << 24 of that camera); tab: full table rows (kCamDer apart)
+// of the cameras; pd: point_der of the observation's track
 __device__ __forceinline__ void
-linearize_obs(const BaDev &d, int k, const double *tab, const PointDer &pd, ObsLin &o)
+linearize_obs(const BaDev &d, int k, int c, int lay, const double *tab, const PointDer &pd, ObsLin &o)
 {
-    const int c = d.obs_cam[k];
     const double2 *q = reinterpret_cast<const double2 *>(tab + (size_t)kCamDer * c);
     double cd[kCamDer];
 #pragma unroll
     for (int i = 0; i < kCamDer / 2; ++i) { const double2 v = q[i]; cd[2 * i] = v.x; cd[2 * i + 1] = v.y; }
     const double2 xy = reinterpret_cast<const double2 *>(d.obs_xy)[k];
-    o.n = d.cam_ldim[c];
-    o.off = d.cam_off[c];
+    o.n = lay >> 24;
+    o.off = lay & 0xffffff;
+    // (the camera's column scales: behind the layout word, beside the table row)
+    double scl[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) scl[t] = t < o.n ? d.scale_c[o.off + t] : 0.0;
     double l[2], r[2];
     table_residual(cd, pd.p, xy.x, xy.y, l, r);
     const double s = r[0] * r[0] + r[1] * r[1];
@@ -596,21 +608,19 @@ linearize_obs(const BaDev &d, int k, const double *tab, const PointDer &pd, ObsL
     if (__all(cd[11] != 0.0)) {
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
-            const double sc = t < o.n ? d.scale_c[o.off + t] : 0.0;
-            o.Jc[0][t] = sc * J[0][t];
-            o.Jc[1][t] = sc * J[1][t];
+            o.Jc[0][t] = scl[t] * J[0][t];
+            o.Jc[1][t] = scl[t] * J[1][t];
         }
     } else {
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
             if (t < o.n) {
                 const int f = d.cam_colmap[6 * c + t];
-                const double sc = d.scale_c[o.off + t];
                 double j0 = J[0][0], j1 = J[1][0];
 #pragma unroll
                 for (int ff = 1; ff < 6; ++ff) { j0 = f == ff ? J[0][ff] : j0; j1 = f == ff ? J[1][ff] : j1; }
-                o.Jc[0][t] = sc * j0;
-                o.Jc[1][t] = sc * j1;
+                o.Jc[0][t] = scl[t] * j0;
+                o.Jc[1][t] = scl[t] * j1;
             } else {
                 o.Jc[0][t] = 0.0;
                 o.Jc[1][t] = 0.0;
@@ -625,30 +635,35 @@ linearize_obs(const BaDev &d, int k, const double *tab, const PointDer &pd, ObsL
             o.Jp[i][t] = g[i] * (cd[3 * i] * pd.G[0][t] + cd[3 * i + 1] * pd.G[1][t] + cd[3 * i + 2] * pd.G[2][t] - l[i] * pd.G[3][t]);
 }
 
-// inverse of a symmetric positive definite 3x3 via Cholesky; false if not PD
+// inverse of a symmetric positive definite 3x3 via Cholesky (A = L L^T, inv = L^-T L^-1); false if not PD.
+// The three pivots' reciprocals are the only divisions: the substitutions of the unit vectors, written out, are
+// the entries of L^-1 (the column-by-column form was 21 divisions, 300 of the point pass's instructions).
 __device__ __forceinline__ bool inv3_spd(const double A[3][3], double inv[3][3])
 {
     double l00 = A[0][0];
     if (!(l00 > 0.0)) return false;
     l00 = sqrt(l00);
-    const double l10 = A[1][0] / l00, l20 = A[2][0] / l00;
+    const double i0 = 1.0 / l00;
+    const double l10 = A[1][0] * i0, l20 = A[2][0] * i0;
     double l11 = A[1][1] - l10 * l10;
     if (!(l11 > 0.0)) return false;
     l11 = sqrt(l11);
-    const double l21 = (A[2][1] - l20 * l10) / l11;
+    const double i1 = 1.0 / l11;
+    const double l21 = (A[2][1] - l20 * l10) * i1;
     double l22 = A[2][2] - l20 * l20 - l21 * l21;
     if (!(l22 > 0.0)) return false;
     l22 = sqrt(l22);
-    for (int c = 0; c < 3; ++c) {
-        const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;
-        const double y0 = e0 / l00;
-        const double y1 = (e1 - l10 * y0) / l11;
-        const double y2 = (e2 - l20 * y0 - l21 * y1) / l22;
-        const double x2 = y2 / l22;
-        const double x1 = (y1 - l21 * x2) / l11;
-        const double x0 = (y0 - l10 * x1 - l20 * x2) / l00;
-        inv[0][c] = x0; inv[1][c] = x1; inv[2][c] = x2;
-    }
+    const double i2 = 1.0 / l22;
+    // M = L^-1 (lower triangular)
+    const double m10 = -(l10 * i0) * i1;
+    const double m20 = -(l20 * i0 + l21 * m10) * i2;
+    const double m21 = -(l21 * i1) * i2;
+    inv[0][0] = i0 * i0 + m10 * m10 + m20 * m20;
+    inv[1][0] = inv[0][1] = m10 * i1 + m20 * m21;
+    inv[2][0] = inv[0][2] = m20 * i2;
+    inv[1][1] = i1 * i1 + m21 * m21;
+    inv[2][1] = inv[1][2] = m21 * i2;
+    inv[2][2] = i2 * i2;
     return true;
 }
 

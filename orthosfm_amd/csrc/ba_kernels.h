@@ -17,9 +17,24 @@ constexpr int kObsRec = 26;
 constexpr int kRecJp = 0, kRecJc = 6, kRecQ = 18, kRecR = 24;
 
 
-// lanes per track in the per-point kernels (point / back / cost pass): their grids are
-// ceil(M * kPointLanes / 256) workgroups of 256 threads, and so are their partials
+// The per-point kernels (point / back / cost pass) give every observation a lane: a workgroup of 256 threads takes
+// the tracks whose first observation lies in a window of kWinObs consecutive observations -- at most 256
+// observations unless a track runs more than 256 - kWinObs past the window's end; those windows (listed once per
+// solve) go to kernels that give every track kPointLanes lanes instead.  Their grids and their partials: one
+// workgroup / one slot per window.
+constexpr int kWinObs = 224;
 constexpr int kPointLanes = 4;
+struct WinDesc { int32_t jf, jn, ka, kb; };     // tracks [jf, jn), observations [ka, kb)
+struct ObsWindows {
+    const WinDesc *desc;          // [num]
+    const int32_t *over_list;     // [num_over] windows of more than 256 observations
+    const int32_t *obs_lay;       // [O] cam_off | cam_ldim << 24 of the observation's camera
+    int32_t num, num_over;
+};
+int obs_windows_count(int O);
+// desc / over_list: [num], *over_count zeroed by the caller, obs_lay: [O]
+void launch_obs_windows(const BaDev &d, int num, WinDesc *desc, int32_t *over_list, int32_t *over_count, int32_t *obs_lay,
+    hipStream_t s);
 
 struct PointPassArgs {
     int mode;                 // kPassScaleInit: only derive the Jacobi scaling
@@ -110,7 +125,7 @@ struct BackPassArgs {
     const double *obsrec;     // [O][kObsRec]
     double *points_out;       // [M][4] candidate points
     double *partials;         // [3][blocks]: model cost change, |dx|^2, |x|^2
-    // fused form (LM solve whose camera tables fit LDS): the launch also evaluates the candidate's cost from the
+    // fused form (LM solve): the launch also evaluates the candidate's cost from the
     // table rows ba_cam_update / chol_small left for the candidate cameras (the cost pass: a launch and a pass over
     // the observations less) and, in its last workgroup, decides
     int fused;
@@ -123,19 +138,18 @@ void launch_lm_decide(LmDev *lm, const LmParams &prm, const LmScratch &sc, LmDev
 void launch_lm_post(LmDev *lm, const LmParams &prm, const LmScratch &sc, int initial, LmDev *host_out, hipStream_t s);
 void launch_lm_clear_abort(LmDev *lm, hipStream_t s);
 
-void launch_point_pass(const BaDev &d, const PointPassArgs &a, int blocks, hipStream_t s);
+void launch_point_pass(const BaDev &d, const PointPassArgs &a, const ObsWindows &w, hipStream_t s);
 void launch_pair_pass(const BaDev &d, const PairPassArgs &a, hipStream_t s);
 // candidate cameras, their derived table rows (ba_device.h: cam_derive_part) and their share of the step norms;
 // cams_out / table_out == nullptr (LM solve): into the iterate buffers that are not current
 void launch_cam_update(const BaDev &d, const double *y_c, double *cams_out, double *table_out, double *partials_cam, hipStream_t s);
 // the table rows of the cameras at `cams`
 void launch_cam_derive(const BaDev &d, const double *cams, double *table_out, hipStream_t s);
-void launch_back_pass(const BaDev &d, const BackPassArgs &a, int blocks, hipStream_t s);
+void launch_back_pass(const BaDev &d, const BackPassArgs &a, const ObsWindows &w, hipStream_t s);
 size_t lm_ticket_bytes();
-bool back_pass_can_fuse(const BaDev &d);      // the camera tables fit LDS
 // table: derived table rows of the cameras to evaluate at (ignored in an LM solve: the candidate's)
 void launch_cost_pass(const BaDev &d, const double *table, const double *points, double *partials,
-    int blocks, hipStream_t s);
+    const ObsWindows &w, hipStream_t s);
 void launch_reduce(const double *partials, int n, int num_slots, unsigned max_mask, double *out,
     const double *extra, int extra_n, int extra_stride, int extra_slots, hipStream_t s);
 void launch_max_reduce(const double *v, int n, double *out, hipStream_t s);

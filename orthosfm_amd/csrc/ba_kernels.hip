@@ -16,6 +16,7 @@
 // All sums that cross threads use fixed-order two-level reductions (no
 // floating-point atomics): the solve is bit-reproducible run to run.
 #include "ba_kernels.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace osfm {
@@ -93,9 +94,9 @@ __device__ __forceinline__ double quad_sum(double v)
     return v;
 }
 
-// per-block partial -> partials[slot * gridDim.x + blockIdx.x]
+// per-block partial -> partials[slot * count + index] (index: the workgroup's window)
 template <bool IS_MAX, bool SC1 = false>
-__device__ __forceinline__ void block_partial(double v, double *partials, int slot, double *sh)
+__device__ __forceinline__ void block_partial(double v, double *partials, int slot, double *sh, int index, int count)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     v = IS_MAX ? wave_max(v) : wave_sum(v);
@@ -105,8 +106,8 @@ __device__ __forceinline__ void block_partial(double v, double *partials, int sl
     if (threadIdx.x == 0) {
         double t = sh[0];
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = IS_MAX ? fmax(t, sh[w]) : t + sh[w];
-        if (SC1) store_sc1(&partials[(size_t)slot * gridDim.x + blockIdx.x], t);
-        else partials[(size_t)slot * gridDim.x + blockIdx.x] = t;
+        if (SC1) store_sc1(&partials[(size_t)slot * count + index], t);
+        else partials[(size_t)slot * count + index] = t;
     }
 }
 
@@ -141,101 +142,6 @@ __device__ __forceinline__ bool last_workgroup(int32_t *ticket, int *lds_flag)
     return *lds_flag != 0;
 }
 size_t lm_ticket_bytes() { return (size_t)(kTicketShards + 1) * kTicketStride * 4; }
-
-// ---------------------------------------------------------------------------
-// Camera tables in LDS.  The per-point kernels walk a track's observations one
-// after the other, and every observation gathers its camera's parameters,
-// image size, tangent layout and column scales through its camera index --
-// chains of dependent global loads, several per observation.  A few hundred
-// cameras are a few tens of KB: each workgroup copies the tables into LDS once
-// (loads issued in batches) and the gathers never leave the CU.  Problems whose
-// tables do not fit keep reading global memory (same code: generic pointers).
-// ---------------------------------------------------------------------------
-constexpr size_t kCamStageLimit = 64 * 1024;
-
-// what a kernel wants in LDS (cam_ldim / cam_off always come along)
-enum {
-    kStageTable = 1,        // the cameras' derived table rows, whole (linearisation)
-    kStageCost = 2,         // the cost part of the table rows only (kCamCost of kCamDer doubles)
-    kStageScale = 4,        // scale_c
-    kStageY = 8,            // the solution vector y_c
-    kStageColmap = 16,
-};
-
-static size_t cam_stage_bytes(const BaDev &d, int what)
-{
-    auto r8 = [](size_t bytes) { return (bytes + 7) / 8 * 8; };      // stage_array rounds every table up
-    size_t b = 2 * r8((size_t)4 * d.C);
-    if (what & kStageTable) b += (size_t)8 * kCamDer * d.C;
-    if (what & kStageCost) b += (size_t)8 * kCamCost * d.C;
-    if (what & kStageScale) b += (size_t)8 * d.nc;
-    if (what & kStageY) b += (size_t)8 * d.nc;
-    if (what & kStageColmap) b += r8((size_t)6 * d.C);
-    static const int mask = getenv("OSFM_BA_STAGE_MASK") ? atoi(getenv("OSFM_BA_STAGE_MASK")) : 2;   // 1: point pass, 2: back / cost pass.
-    // Measured (200 cameras, 750k observations): the point pass with its 60 KB of table rows staged runs two
-    // waves per SIMD and takes 114 us, reading the rows from L2 98 us; the back pass's 30 KB pay (104 against 114 us)
-    if (!(mask & ((what & kStageTable) ? 1 : 2))) return 0;
-    return b <= kCamStageLimit ? b : 0;
-}
-constexpr int kStageBack = kStageY, kStageBackFused = kStageY | kStageCost, kStagePoint = kStageTable | kStageScale | kStageColmap;
-bool back_pass_can_fuse(const BaDev &d) { return d.C > 0; }
-
-template <typename T>
-__device__ __forceinline__ const T *stage_array(const T *src, int n, char *&lds)
-{
-    T *dst = reinterpret_cast<T *>(lds);
-    constexpr int kB = 8;
-    for (int i0 = 0; i0 < n; i0 += kB * 256) {
-        T v[kB];
-#pragma unroll
-        for (int u = 0; u < kB; ++u) v[u] = src[min(i0 + u * 256 + (int)threadIdx.x, n - 1)];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < kB; ++u) { const int i = i0 + u * 256 + (int)threadIdx.x; if (i < n) dst[i] = v[u]; }
-    }
-    lds += ((size_t)n * sizeof(T) + 7) / 8 * 8;
-    return dst;
-}
-
-// the first kCamCost doubles of every table row, packed
-__device__ __forceinline__ const double *stage_cost_rows(const double *table, int C, char *&lds)
-{
-    double *dst = reinterpret_cast<double *>(lds);
-    const int n = kCamCost * C;
-    constexpr int kB = 4;
-    for (int i0 = 0; i0 < n; i0 += kB * 256) {
-        double v[kB];
-#pragma unroll
-        for (int u = 0; u < kB; ++u) {
-            const int i = min(i0 + u * 256 + (int)threadIdx.x, n - 1), row = i / kCamCost;
-            v[u] = table[(size_t)row * kCamDer + (i - row * kCamCost)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < kB; ++u) { const int i = i0 + u * 256 + (int)threadIdx.x; if (i < n) dst[i] = v[u]; }
-    }
-    lds += (size_t)n * 8;
-    return dst;
-}
-
-// d with the per-camera arrays named in `what` replaced by LDS copies (what == 0: d as it is).
-//   table: the table rows to stage (kStageTable: whole, returned in o.camder with stride kCamDer; kStageCost: their
-//   cost parts, returned in *cost_rows with stride kCamCost)
-__device__ __forceinline__ BaDev stage_cameras(const BaDev &d, char *lds, int what, const double *table,
-    const double **cost_rows, const double **y_c)
-{
-    BaDev o = d;
-    if (!what || d.C <= 0) return o;
-    if (what & kStageTable) o.camder = stage_array(table, kCamDer * d.C, lds);
-    if (what & kStageCost) *cost_rows = stage_cost_rows(table, d.C, lds);
-    if ((what & kStageScale) && d.nc > 0) o.scale_c = stage_array(d.scale_c, d.nc, lds);
-    if ((what & kStageY) && d.nc > 0) *y_c = stage_array(*y_c, d.nc, lds);
-    o.cam_ldim = stage_array(d.cam_ldim, d.C, lds);
-    o.cam_off = stage_array(d.cam_off, d.C, lds);
-    if (what & kStageColmap) o.cam_colmap = stage_array(d.cam_colmap, 6 * d.C, lds);
-    __syncthreads();
-    return o;
-}
 
 // ---------------------------------------------------------------------------
 // LM control on the device.  Fixed-order reductions of the per-block partials, then the
@@ -418,44 +324,240 @@ void launch_lm_post(LmDev *lm, const LmParams &prm, const LmScratch &sc, int ini
 }
 
 // ---------------------------------------------------------------------------
-// point pass
+// Observation windows.  The per-point passes (point, back, cost) give every OBSERVATION a lane: a workgroup takes
+// the tracks whose first observation falls into a window of kWinObs consecutive observations (observations are
+// grouped by track), which are at most 256 observations while no track runs more than 256 - kWinObs past the
+// window's end.  One round per wave -- where four lanes per track walked the track's observations three at a
+// time, each step a chain of dependent loads, with 62 % of the lanes busy (tracks of 3..12) -- and a track's sums
+// are added in observation order from LDS by every lane of the track, so they do not depend on the packing.
+// Windows that hold more (a long track at their end) are listed once per solve and taken by the *_over kernels:
+// the four-lanes-per-track form, any length.  The window layout is the same in every iteration of a solve.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void
-ba_point_pass_kernel(BaDev dg, PointPassArgs a, int staged)
+ba_windows_kernel(BaDev d, int num, WinDesc *desc, int32_t *over_list, int32_t *over_count)
 {
-    extern __shared__ __attribute__((aligned(16))) char cam_lds[];
-    __shared__ double sh[4];
-    if (!lm_resolve(dg)) return;
-    if (dg.lm && a.mode == kPassNormal) {
-        // the LM state decides what this linearisation is for
-        a.radius = dg.lm->radius; a.update_diag = dg.lm->update_diag; a.want_gradient = dg.lm->want_gradient;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= num) return;
+    const int64_t k0 = (int64_t)b * kWinObs, k1 = k0 + kWinObs;
+    WinDesc w;
+    // the first track that starts at or behind observation k0: the one behind the track of observation k0 - 1
+    w.jf = k0 == 0 ? 0 : d.obs_pt[k0 - 1] + 1;
+    w.jn = k1 >= d.O ? d.M : d.obs_pt[k1 - 1] + 1;        // the last window also takes the empty tracks at the end
+    w.ka = d.pt_start[w.jf];
+    w.kb = d.pt_start[w.jn];
+    desc[b] = w;
+    if (w.kb - w.ka > 256) over_list[atomicAdd(over_count, 1)] = b;
+}
+
+// obs_lay[k] = cam_off | cam_ldim << 24 of the observation's camera: one coalesced load instead of two gathers
+// behind the camera index
+__global__ __launch_bounds__(256) void
+ba_obs_lay_kernel(BaDev d, int32_t *obs_lay)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= d.O) return;
+    const int c = d.obs_cam[k];
+    obs_lay[k] = d.cam_off[c] | (d.cam_ldim[c] << 24);
+}
+
+int obs_windows_count(int O) { return std::max(1, (O + kWinObs - 1) / kWinObs); }
+
+void launch_obs_windows(const BaDev &d, int num, WinDesc *desc, int32_t *over_list, int32_t *over_count, int32_t *obs_lay,
+    hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_windows_kernel, dim3((num + 255) / 256), dim3(256), 0, s, d, num, desc, over_list, over_count);
+    if (d.O > 0) hipLaunchKernelGGL(ba_obs_lay_kernel, dim3((d.O + 255) / 256), dim3(256), 0, s, d, obs_lay);
+}
+
+// ---------------------------------------------------------------------------
+// point pass
+// ---------------------------------------------------------------------------
+// what a track's lanes do once its sums are complete (V lower triangle, g): the LM diagonal, (V + D^2 / radius)^-1,
+// the stores of the track's first lane (`leader`), the point's share of the gradient norm.  Returns false when V is
+// not positive definite.
+// |Plus(x, -g) - x|_inf of a point with the UNSCALED gradient g / scale
+__device__ __forceinline__ double point_gradient_norm(const BaDev &d, int j, const double (&g)[3])
+{
+    double dl[3], out[4], m = 0.0;
+    for (int x = 0; x < 3; ++x) dl[x] = -g[x] / d.scale_p[3 * j + x];
+    homog_plus(d.points + 4 * j, dl, out);
+    for (int x = 0; x < 4; ++x) m = fmax(m, fabs(d.points[4 * j + x] - out[x]));
+    return m;
+}
+
+__device__ __forceinline__ bool
+point_track_finish(const BaDev &d, const PointPassArgs &a, int j, bool leader, bool empty, double (&V)[3][3],
+    const double (&g)[3], double (&Vi)[3][3], double &gmax, bool with_gmax = true)
+{
+    bool ok = true;
+    V[0][1] = V[1][0]; V[0][2] = V[2][0]; V[1][2] = V[2][1];
+    if (a.mode == kPassScaleInit) {
+        // Jacobi scaling, computed once from the unscaled column norms
+        // (TrustRegionMinimizer::EvaluateGradientAndJacobian, iteration 0)
+        if (leader)
+            for (int x = 0; x < 3; ++x) a.scale_p_out[3 * j + x] = 1.0 / (1.0 + sqrt(V[x][x]));
+        return true;
     }
-    const BaDev d = stage_cameras(dg, cam_lds, staged ? kStagePoint : 0, dg.camder, nullptr, nullptr);
-    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = gt / kPointLanes, sub = gt % kPointLanes;       // a quad never straddles j < M
+    for (int x = 0; x < 3; ++x) {
+        // every lane derives the diagonal itself (the leader's store is not read back)
+        const double dp = a.update_diag ? fmin(fmax(V[x][x], a.min_diag), a.max_diag) : a.diag_p[3 * j + x];
+        if (a.update_diag && leader) a.diag_p[3 * j + x] = dp;
+        V[x][x] += dp / a.radius;
+    }
+    if (!empty) {
+        ok = inv3_spd(V, Vi);
+    } else {
+        for (int x = 0; x < 3; ++x)
+            for (int y = 0; y < 3; ++y) Vi[x][y] = x == y ? 1.0 / V[x][x] : 0.0;
+    }
+    if (leader)
+        for (int x = 0; x < 3; ++x) {
+            a.ge[3 * j + x] = g[x];
+            for (int y = 0; y < 3; ++y) a.vinv[9 * j + 3 * x + y] = ok ? Vi[x][y] : 0.0;
+        }
+    if (a.want_gradient && leader && with_gmax) gmax = fmax(gmax, point_gradient_norm(d, j, g));
+    return ok;
+}
+
+// the record of one observation (16-byte aligned: 26 doubles) in 16-byte stores
+__device__ __forceinline__ void
+store_record(double *obsrec, int k, const ObsLin &o, const double (&qv)[6])
+{
+    double w[kObsRec];
+#pragma unroll
+    for (int x = 0; x < 6; ++x) { w[kRecJc + x] = o.Jc[0][x]; w[kRecJc + 6 + x] = o.Jc[1][x]; w[kRecQ + x] = qv[x]; }
+#pragma unroll
+    for (int x = 0; x < 3; ++x) { w[kRecJp + x] = o.Jp[0][x]; w[kRecJp + 3 + x] = o.Jp[1][x]; }
+    w[kRecR] = o.r[0]; w[kRecR + 1] = o.r[1];
+    double2 *dst = reinterpret_cast<double2 *>(obsrec + (size_t)k * kObsRec);
+#pragma unroll
+    for (int i = 0; i < kObsRec / 2; ++i) dst[i] = make_double2(w[2 * i], w[2 * i + 1]);
+}
+
+// the tracks of a window without observations (point or back pass: lane per track)
+template <typename F>
+__device__ __forceinline__ void for_empty_tracks(const BaDev &d, const WinDesc &wd, F f)
+{
+    for (int j = wd.jf + (int)threadIdx.x; j < wd.jn; j += 256)
+        if (d.pt_start[j + 1] == d.pt_start[j]) f(j);
+}
+
+__global__ __launch_bounds__(256) void
+ba_point_win_kernel(BaDev d, PointPassArgs a, ObsWindows w)
+{
+    // what an observation adds to its track's sums -- Jp^T Jp (lower triangle: 6) and Jp^T r (3) -- piece i of
+    // lane t at [i][t]: the lanes' 16-byte accesses are consecutive
+    __shared__ double2 obs_lds[5][256];
+    __shared__ double sh[4];
+    if (!lm_resolve(d)) return;
+    if (d.lm && a.mode == kPassNormal) {
+        // the LM state decides what this linearisation is for
+        a.radius = d.lm->radius; a.update_diag = d.lm->update_diag; a.want_gradient = d.lm->want_gradient;
+    }
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const WinDesc wd = w.desc[b];
+    if (wd.kb - wd.ka > 256) return;              // ba_point_over_kernel's
+    const int k = wd.ka + tid;
+    const bool live = k < wd.kb;
     double cost = 0.0, gmax = 0.0;
     int bad = 0;
-    if (j < d.M) {
+    int j = 0, ks = 0, ke = 0;
+    ObsLin o;
+    if (live) {
+        j = d.obs_pt[k];
+        ks = d.pt_start[j]; ke = d.pt_start[j + 1];
+        PointDer pd;
+        point_der(d, j, d.points + 4 * j, true, pd);
+        linearize_obs(d, k, d.obs_cam[k], w.obs_lay[k], d.camder, pd, o);
+        cost = 0.5 * o.rho0;
+        double pr[10];
+        int q = 0;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+#pragma unroll
+            for (int y = 0; y <= x; ++y) pr[q++] = o.Jp[0][x] * o.Jp[0][y] + o.Jp[1][x] * o.Jp[1][y];
+        }
+#pragma unroll
+        for (int x = 0; x < 3; ++x) pr[6 + x] = o.Jp[0][x] * o.r[0] + o.Jp[1][x] * o.r[1];
+        pr[9] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) obs_lds[i][tid] = make_double2(pr[2 * i], pr[2 * i + 1]);
+    }
+    __syncthreads();
+    if (live) {
+        double qv[6] = { 0, 0, 0, 0, 0, 0 };
+        if (d.pdim) {
+            // the track's sums, in observation order, in every lane of the track
+            double sm[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+            for (int i = ks - wd.ka; i < ke - wd.ka; ++i) {
+#pragma unroll
+                for (int u = 0; u < 5; ++u) { const double2 v = obs_lds[u][i]; sm[2 * u] += v.x; sm[2 * u + 1] += v.y; }
+            }
+            double V[3][3], Vi[3][3];
+            V[0][0] = sm[0]; V[1][0] = sm[1]; V[1][1] = sm[2]; V[2][0] = sm[3]; V[2][1] = sm[4]; V[2][2] = sm[5];
+            const double g[3] = { sm[6], sm[7], sm[8] };
+            // (the points' gradient norm: by a lane per track, below)
+            if (!point_track_finish(d, a, j, k == ks, false, V, g, Vi, gmax, false)) bad = 1;
+            if (a.mode != kPassScaleInit) {
+                // Q = Jp V^-1
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        qv[3 * rr + t] = bad ? 0.0 : o.Jp[rr][0] * Vi[0][t] + o.Jp[rr][1] * Vi[1][t] + o.Jp[rr][2] * Vi[2][t];
+            }
+        }
+        store_record(a.obsrec, k, o, qv);
+    }
+    if (d.pdim) {
+        // a lane per TRACK: the tracks without observations, and every point's share of the gradient norm (sine,
+        // cosine and two roots that all four waves went through for their few first lanes) from the gradient its
+        // first lane has just stored
+        const bool with_gmax = a.mode != kPassScaleInit && a.want_gradient;
+        if (with_gmax) __syncthreads();
+        for (int je = wd.jf + tid; je < wd.jn; je += 256) {
+            if (d.pt_start[je + 1] == d.pt_start[je]) {
+                double V[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } }, Vi[3][3];
+                const double g[3] = { 0, 0, 0 };
+                point_track_finish(d, a, je, true, true, V, g, Vi, gmax, false);
+            } else if (with_gmax) {
+                const double g[3] = { a.ge[3 * je], a.ge[3 * je + 1], a.ge[3 * je + 2] };
+                gmax = fmax(gmax, point_gradient_norm(d, je, g));
+            }
+        }
+    }
+    block_partial<false>(cost, a.partials, 0, sh, b, w.num);
+    block_partial<true>(gmax, a.partials, 1, sh, b, w.num);
+    block_partial<true>((double)bad, a.partials, 2, sh, b, w.num);
+}
+
+// the windows of more than 256 observations: four neighbouring lanes per track, 64 tracks at a time
+__global__ __launch_bounds__(256) void
+ba_point_over_kernel(BaDev d, PointPassArgs a, ObsWindows w)
+{
+    __shared__ double sh[4];
+    if (!lm_resolve(d)) return;
+    if (d.lm && a.mode == kPassNormal) {
+        a.radius = d.lm->radius; a.update_diag = d.lm->update_diag; a.want_gradient = d.lm->want_gradient;
+    }
+    const int b = w.over_list[blockIdx.x];
+    const WinDesc wd = w.desc[b];
+    const int sub = threadIdx.x % kPointLanes;
+    double cost = 0.0, gmax = 0.0;
+    int bad = 0;
+    for (int jb = wd.jf; jb < wd.jn; jb += 256 / kPointLanes) {
+        const int j = jb + (int)threadIdx.x / kPointLanes;          // a quad never straddles j < jn
+        if (j >= wd.jn) continue;
         const int k0 = d.pt_start[j], k1 = d.pt_start[j + 1];
         double V[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } }, g[3] = { 0, 0, 0 };
         PointDer pd;
         point_der(d, j, d.points + 4 * j, true, pd);
+        const double zero6[6] = { 0, 0, 0, 0, 0, 0 };
         for (int k = k0 + sub; k < k1; k += kPointLanes) {
             ObsLin o;
-            linearize_obs(d, k, d.camder, pd, o);
+            linearize_obs(d, k, d.obs_cam[k], w.obs_lay[k], d.camder, pd, o);
             cost += 0.5 * o.rho0;
-            // the record (16-byte aligned: 26 doubles) in 16-byte stores
-            {
-                double w[kRecQ];
-#pragma unroll
-                for (int x = 0; x < 6; ++x) { w[kRecJc + x] = o.Jc[0][x]; w[kRecJc + 6 + x] = o.Jc[1][x]; }
-#pragma unroll
-                for (int x = 0; x < 3; ++x) { w[kRecJp + x] = o.Jp[0][x]; w[kRecJp + 3 + x] = o.Jp[1][x]; }
-                double2 *dst = reinterpret_cast<double2 *>(a.obsrec + (size_t)k * kObsRec);
-#pragma unroll
-                for (int i = 0; i < kRecQ / 2; ++i) dst[i] = make_double2(w[2 * i], w[2 * i + 1]);
-                dst[kRecR / 2] = make_double2(o.r[0], o.r[1]);
-            }
+            store_record(a.obsrec, k, o, zero6);
             if (d.pdim) {
                 for (int x = 0; x < 3; ++x) {
                     g[x] += o.Jp[0][x] * o.r[0] + o.Jp[1][x] * o.r[1];
@@ -463,70 +565,40 @@ ba_point_pass_kernel(BaDev dg, PointPassArgs a, int staged)
                 }
             }
         }
-        if (d.pdim) {
-            // the track's sums, identical in its four lanes from here on
-            for (int x = 0; x < 3; ++x) {
-                g[x] = quad_sum(g[x]);
-                for (int y = 0; y <= x; ++y) V[x][y] = quad_sum(V[x][y]);
-            }
-            V[0][1] = V[1][0]; V[0][2] = V[2][0]; V[1][2] = V[2][1];
-            if (a.mode == kPassScaleInit) {
-                // Jacobi scaling, computed once from the unscaled column norms
-                // (TrustRegionMinimizer::EvaluateGradientAndJacobian, iteration 0)
-                if (sub == 0)
-                    for (int x = 0; x < 3; ++x) a.scale_p_out[3 * j + x] = 1.0 / (1.0 + sqrt(V[x][x]));
-            } else {
-                for (int x = 0; x < 3; ++x) {
-                    // every lane derives the diagonal itself (lane 0's store is not read back)
-                    const double dp = a.update_diag ? fmin(fmax(V[x][x], a.min_diag), a.max_diag) : a.diag_p[3 * j + x];
-                    if (a.update_diag && sub == 0) a.diag_p[3 * j + x] = dp;
-                    V[x][x] += dp / a.radius;
-                }
-                double Vi[3][3];
-                if (k1 > k0) {
-                    if (!inv3_spd(V, Vi)) bad = 1;
-                } else {
-                    for (int x = 0; x < 3; ++x)
-                        for (int y = 0; y < 3; ++y) Vi[x][y] = x == y ? 1.0 / V[x][x] : 0.0;
-                }
-                if (sub == 0)
-                    for (int x = 0; x < 3; ++x) {
-                        a.ge[3 * j + x] = g[x];
-                        for (int y = 0; y < 3; ++y) a.vinv[9 * j + 3 * x + y] = bad ? 0.0 : Vi[x][y];
-                    }
-                // Q = Jp V^-1 for every observation of the track (each lane its own records)
-                for (int k = k0 + sub; k < k1; k += kPointLanes) {
-                    double2 *rec2 = reinterpret_cast<double2 *>(a.obsrec + (size_t)k * kObsRec);
-                    double jp[6], qv[6];
+        if (!d.pdim) continue;
+        // the track's sums, identical in its four lanes from here on
+        for (int x = 0; x < 3; ++x) {
+            g[x] = quad_sum(g[x]);
+            for (int y = 0; y <= x; ++y) V[x][y] = quad_sum(V[x][y]);
+        }
+        double Vi[3][3];
+        const bool ok = point_track_finish(d, a, j, sub == 0, k1 == k0, V, g, Vi, gmax);
+        if (!ok) bad = 1;
+        if (a.mode == kPassScaleInit) continue;
+        // Q = Jp V^-1 for every observation of the track (each lane its own records)
+        for (int k = k0 + sub; k < k1; k += kPointLanes) {
+            double2 *rec2 = reinterpret_cast<double2 *>(a.obsrec + (size_t)k * kObsRec);
+            double jp[6], qv[6];
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) { const double2 v = rec2[kRecJp / 2 + i]; jp[2 * i] = v.x; jp[2 * i + 1] = v.y; }
+            for (int i = 0; i < 3; ++i) { const double2 v = rec2[kRecJp / 2 + i]; jp[2 * i] = v.x; jp[2 * i + 1] = v.y; }
 #pragma unroll
-                    for (int rr = 0; rr < 2; ++rr)
+            for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-                        for (int t = 0; t < 3; ++t)
-                            qv[3 * rr + t] = bad ? 0.0 : jp[3 * rr] * Vi[0][t] + jp[3 * rr + 1] * Vi[1][t] + jp[3 * rr + 2] * Vi[2][t];
+                for (int t = 0; t < 3; ++t)
+                    qv[3 * rr + t] = !ok ? 0.0 : jp[3 * rr] * Vi[0][t] + jp[3 * rr + 1] * Vi[1][t] + jp[3 * rr + 2] * Vi[2][t];
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) rec2[kRecQ / 2 + i] = make_double2(qv[2 * i], qv[2 * i + 1]);
-                }
-                if (a.want_gradient && sub == 0) {
-                    // |Plus(x, -g) - x|_inf with the UNSCALED gradient g / scale
-                    double dl[3], out[4];
-                    for (int x = 0; x < 3; ++x) dl[x] = -g[x] / d.scale_p[3 * j + x];
-                    homog_plus(d.points + 4 * j, dl, out);
-                    for (int x = 0; x < 4; ++x) gmax = fmax(gmax, fabs(d.points[4 * j + x] - out[x]));
-                }
-            }
+            for (int i = 0; i < 3; ++i) rec2[kRecQ / 2 + i] = make_double2(qv[2 * i], qv[2 * i + 1]);
         }
     }
-    block_partial<false>(cost, a.partials, 0, sh);
-    block_partial<true>(gmax, a.partials, 1, sh);
-    block_partial<true>((double)bad, a.partials, 2, sh);
+    block_partial<false>(cost, a.partials, 0, sh, b, w.num);
+    block_partial<true>(gmax, a.partials, 1, sh, b, w.num);
+    block_partial<true>((double)bad, a.partials, 2, sh, b, w.num);
 }
 
-void launch_point_pass(const BaDev &d, const PointPassArgs &a, int blocks, hipStream_t s)
+void launch_point_pass(const BaDev &d, const PointPassArgs &a, const ObsWindows &w, hipStream_t s)
 {
-    const size_t lds = cam_stage_bytes(d, kStagePoint);
-    hipLaunchKernelGGL(ba_point_pass_kernel, dim3(blocks), dim3(256), lds, s, d, a, lds ? 1 : 0);
+    hipLaunchKernelGGL(ba_point_win_kernel, dim3(w.num), dim3(256), 0, s, d, a, w);
+    if (w.num_over > 0) hipLaunchKernelGGL(ba_point_over_kernel, dim3(w.num_over), dim3(256), 0, s, d, a, w);
 }
 
 // ---------------------------------------------------------------------------
@@ -852,52 +924,166 @@ void launch_cam_derive(const BaDev &d, const double *cams, double *table_out, hi
 }
 
 // ---------------------------------------------------------------------------
-// back substitution + model cost change + candidate points
+// back substitution + model cost change + candidate points (+ fused: the candidate's cost and the LM decision)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void
-ba_back_pass_kernel(BaDev dg, BackPassArgs a, int staged)
+// u = Jc y of one observation (lay: obs_lay, rec: its record's [0, kRecQ) part)
+__device__ __forceinline__ void
+obs_camera_step(const double *y_c, int lay, const double *rec, double &u0, double &u1)
 {
-    extern __shared__ __attribute__((aligned(16))) char cam_lds[];
-    __shared__ double sh[256];
-    __shared__ int lds_last;
-    const bool fused = a.fused != 0;
-    if (!lm_resolve(dg)) {
+    const int off = lay & 0xffffff, n = lay >> 24;
+    u0 = 0.0; u1 = 0.0;
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+        if (x < n) { const double yx = y_c[off + x]; u0 += rec[kRecJc + x] * yx; u1 += rec[kRecJc + 6 + x] * yx; }
+}
+
+// the state every back-pass kernel starts from; false: nothing to do (a stopped solve, or no step)
+__device__ __forceinline__ bool
+back_pass_begin(BaDev &d, BackPassArgs &a, const double *&cand, double *sh)
+{
+    const bool fused = a.fused != 0 && a.decide.enabled;
+    if (!lm_resolve(d)) {
         if (fused && blockIdx.x == 0) lm_decide_block<true>(a.decide.lm, a.decide.prm, a.decide.sc, a.decide.host_out, sh);   // publishes the stopped state
-        return;
+        return false;
     }
-    if (dg.lm && dg.lm->lin_failed) {
+    if (d.lm && d.lm->lin_failed) {
         // the linearisation failed: there is no step; the decision (an invalid step) is one workgroup's work
         if (fused && blockIdx.x == 0) lm_decide_block<true>(a.decide.lm, a.decide.prm, a.decide.sc, a.decide.host_out, sh);
+        return false;
+    }
+    // fused: the table rows of the CANDIDATE cameras (ba_cam_update / chol_small made them just before)
+    cand = nullptr;
+    if (d.lm) { a.points_out = d.lm->cur ? d.points2[0] : d.points2[1]; cand = d.lm->cur ? d.camder2[0] : d.camder2[1]; }
+    return true;
+}
+
+// behind a back-pass kernel's sums: the partials, and ba_lm_decide in the tail of the workgroup that finishes last
+__device__ __forceinline__ void
+back_pass_end(const BackPassArgs &a, double mcc, double sn, double xn, double ccost, int index, int count, double *sh, int *lds_last)
+{
+    if (!a.fused) {
+        block_partial<false>(mcc, a.partials, 0, sh, index, count);
+        block_partial<false>(sn, a.partials, 1, sh, index, count);
+        block_partial<false>(xn, a.partials, 2, sh, index, count);
         return;
     }
-    // fused: the cost parts of the CANDIDATE cameras' table rows (ba_cam_update / chol_small made them just before)
-    const double *cand = nullptr;
-    int cand_stride = kCamDer;
-    if (dg.lm) { a.points_out = dg.lm->cur ? dg.points2[0] : dg.points2[1]; cand = dg.lm->cur ? dg.camder2[0] : dg.camder2[1]; }
-    const BaDev d = stage_cameras(dg, cam_lds, staged ? (fused ? kStageBackFused : kStageBack) : 0, cand, &cand, &a.y_c);
-    if (staged && fused) cand_stride = kCamCost;
-    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = gt / kPointLanes, sub = gt % kPointLanes;
+    block_partial<false, true>(mcc, a.partials, 0, sh, index, count);
+    block_partial<false, true>(sn, a.partials, 1, sh, index, count);
+    block_partial<false, true>(xn, a.partials, 2, sh, index, count);
+    block_partial<false, true>(ccost, a.cost_partials, 0, sh, index, count);
+    if (!a.decide.enabled) return;           // (the launch behind this one carries the decision)
+    if (!last_workgroup(a.decide.ticket, lds_last)) return;
+    lm_decide_block<true>(a.decide.lm, a.decide.prm, a.decide.sc, a.decide.host_out, sh);
+}
+
+__global__ __launch_bounds__(256) void
+ba_back_win_kernel(BaDev d, BackPassArgs a, ObsWindows w)
+{
+    __shared__ double t_lds[3][256];       // - Jp^T (Jc y) of the window's observations
+    __shared__ double sh[256];
+    __shared__ int lds_last;
+    const double *cand;
+    if (!back_pass_begin(d, a, cand, sh)) return;
+    const bool fused = a.fused != 0;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const WinDesc wd = w.desc[b];
+    const int nobs = wd.kb - wd.ka;
+    const int k = wd.ka + tid;
+    const bool live = nobs <= 256 && k < wd.kb;              // windows of more: ba_back_over_kernel's
     double mcc = 0.0, sn = 0.0, xn = 0.0, ccost = 0.0;
-    if (j < d.M) {
+    int j = 0, ks = 0, ke = 0;
+    double r[kObsRec], u0 = 0.0, u1 = 0.0, cd[kCamCost];
+    double2 xy = make_double2(0.0, 0.0);
+    if (live) {
+        // Jc, Jp and the residual of the record, the loads issued together
+        const double2 *src = reinterpret_cast<const double2 *>(a.obsrec + (size_t)k * kObsRec);
+#pragma unroll
+        for (int i = 0; i < kRecQ / 2; ++i) { const double2 v = src[i]; r[2 * i] = v.x; r[2 * i + 1] = v.y; }
+        { const double2 v = src[kRecR / 2]; r[kRecR] = v.x; r[kRecR + 1] = v.y; }
+        j = d.obs_pt[k];
+        if (fused) {
+            const double2 *q = reinterpret_cast<const double2 *>(cand + (size_t)kCamDer * d.obs_cam[k]);
+#pragma unroll
+            for (int i = 0; i < kCamCost / 2; ++i) { const double2 v = q[i]; cd[2 * i] = v.x; cd[2 * i + 1] = v.y; }
+            xy = reinterpret_cast<const double2 *>(d.obs_xy)[k];
+        }
+        ks = d.pt_start[j]; ke = d.pt_start[j + 1];
+        obs_camera_step(a.y_c, w.obs_lay[k], r, u0, u1);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) t_lds[t][tid] = -(r[kRecJp + t] * u0 + r[kRecJp + 3 + t] * u1);
+    }
+    __syncthreads();
+    if (live) {
+        double step_p[3] = { 0, 0, 0 };
+        if (d.pdim) {
+            double t3[3] = { 0, 0, 0 };
+            for (int i = ks - wd.ka; i < ke - wd.ka; ++i)
+                for (int t = 0; t < 3; ++t) t3[t] += t_lds[t][i];
+            for (int t = 0; t < 3; ++t) t3[t] = a.ge[3 * j + t] + t3[t];
+            const double *Vi = a.vinv + 9 * j;
+            for (int x = 0; x < 3; ++x) step_p[x] = -(Vi[3 * x] * t3[0] + Vi[3 * x + 1] * t3[1] + Vi[3 * x + 2] * t3[2]);
+        }
+        // model_cost_change = -(J step)^T (r + J step / 2)  (scaled J, scaled step)
+        double m0 = -u0, m1 = -u1;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { m0 += r[kRecJp + t] * step_p[t]; m1 += r[kRecJp + 3 + t] * step_p[t]; }
+        mcc = -(m0 * (r[kRecR] + m0 / 2.0) + m1 * (r[kRecR + 1] + m1 / 2.0));
+        // the candidate point, in every lane of the track; its first lane stores it
+        const double *P = d.points + 4 * j;
+        double out[4] = { P[0], P[1], P[2], P[3] };
+        const bool leader = k == ks;
+        if (d.pdim) {
+            double dl[3];
+            for (int x = 0; x < 3; ++x) dl[x] = step_p[x] * d.scale_p[3 * j + x];
+            homog_plus(P, dl, out);
+            if (leader)
+                for (int x = 0; x < 4; ++x) { sn += (P[x] - out[x]) * (P[x] - out[x]); xn += P[x] * P[x]; }
+        }
+        if (leader)
+            for (int x = 0; x < 4; ++x) a.points_out[4 * j + x] = out[x];
+        if (fused) {
+            const double pc[3] = { out[0] / out[3], out[1] / out[3], out[2] / out[3] };
+            ccost = 0.5 * row_cost(cd, pc, xy.x, xy.y, d.huber);
+        }
+    }
+    if (nobs <= 256)
+        for_empty_tracks(d, wd, [&](int je) {
+            // no observations: no step (ge = 0)
+            const double *P = d.points + 4 * je;
+            for (int x = 0; x < 4; ++x) { a.points_out[4 * je + x] = P[x]; if (d.pdim) xn += P[x] * P[x]; }
+        });
+    if (nobs > 256) return;        // (then the over kernel's launch carries the decision: launch_back_pass)
+    back_pass_end(a, mcc, sn, xn, ccost, b, w.num, sh, &lds_last);
+}
+
+__global__ __launch_bounds__(256) void
+ba_back_over_kernel(BaDev d, BackPassArgs a, ObsWindows w)
+{
+    __shared__ double sh[256];
+    __shared__ int lds_last;
+    const double *cand;
+    if (!back_pass_begin(d, a, cand, sh)) return;
+    const bool fused = a.fused != 0;
+    const int b = w.over_list[blockIdx.x];
+    const WinDesc wd = w.desc[b];
+    const int sub = threadIdx.x % kPointLanes;
+    double mcc = 0.0, sn = 0.0, xn = 0.0, ccost = 0.0;
+    for (int jb = wd.jf; jb < wd.jn; jb += 256 / kPointLanes) {
+        const int j = jb + (int)threadIdx.x / kPointLanes;
+        if (j >= wd.jn) continue;
         const int k0 = d.pt_start[j], k1 = d.pt_start[j + 1];
         double step_p[3] = { 0, 0, 0 };
         if (d.pdim) {
             double t3[3] = { 0, 0, 0 };
             for (int k = k0 + sub; k < k1; k += kPointLanes) {
-                // Jc and Jp of the record as nine 16-byte loads issued together (loads under
-                // the x < n tests came out as load, wait, use one by one)
                 double r[kRecQ];
                 {
                     const double2 *src = reinterpret_cast<const double2 *>(a.obsrec + (size_t)k * kObsRec);
 #pragma unroll
                     for (int i = 0; i < kRecQ / 2; ++i) { const double2 v = src[i]; r[2 * i] = v.x; r[2 * i + 1] = v.y; }
                 }
-                const int c = d.obs_cam[k], n = d.cam_ldim[c], off = d.cam_off[c];
-                double u0 = 0.0, u1 = 0.0;
-#pragma unroll
-                for (int x = 0; x < 6; ++x)
-                    if (x < n) { const double yx = a.y_c[off + x]; u0 += r[kRecJc + x] * yx; u1 += r[kRecJc + 6 + x] * yx; }
+                double u0, u1;
+                obs_camera_step(a.y_c, w.obs_lay[k], r, u0, u1);
 #pragma unroll
                 for (int t = 0; t < 3; ++t) t3[t] -= r[kRecJp + t] * u0 + r[kRecJp + 3 + t] * u1;
             }
@@ -905,7 +1091,6 @@ ba_back_pass_kernel(BaDev dg, BackPassArgs a, int staged)
             const double *Vi = a.vinv + 9 * j;
             for (int x = 0; x < 3; ++x) step_p[x] = -(Vi[3 * x] * t3[0] + Vi[3 * x + 1] * t3[1] + Vi[3 * x + 2] * t3[2]);
         }
-        // model_cost_change = -(J step)^T (r + J step / 2)  (scaled J, scaled step)
         for (int k = k0 + sub; k < k1; k += kPointLanes) {
             double r[kObsRec];
             {
@@ -914,11 +1099,9 @@ ba_back_pass_kernel(BaDev dg, BackPassArgs a, int staged)
                 for (int i = 0; i < kRecQ / 2; ++i) { const double2 v = src[i]; r[2 * i] = v.x; r[2 * i + 1] = v.y; }
                 const double2 v = src[kRecR / 2]; r[kRecR] = v.x; r[kRecR + 1] = v.y;
             }
-            const int c = d.obs_cam[k], n = d.cam_ldim[c], off = d.cam_off[c];
-            double m0 = 0.0, m1 = 0.0;
-#pragma unroll
-            for (int x = 0; x < 6; ++x)
-                if (x < n) { const double yx = a.y_c[off + x]; m0 -= r[kRecJc + x] * yx; m1 -= r[kRecJc + 6 + x] * yx; }
+            double u0, u1;
+            obs_camera_step(a.y_c, w.obs_lay[k], r, u0, u1);
+            double m0 = -u0, m1 = -u1;
 #pragma unroll
             for (int t = 0; t < 3; ++t) { m0 += r[kRecJp + t] * step_p[t]; m1 += r[kRecJp + 3 + t] * step_p[t]; }
             mcc -= m0 * (r[kRecR] + m0 / 2.0) + m1 * (r[kRecR + 1] + m1 / 2.0);
@@ -935,66 +1118,49 @@ ba_back_pass_kernel(BaDev dg, BackPassArgs a, int staged)
         if (sub == 0)
             for (int x = 0; x < 4; ++x) a.points_out[4 * j + x] = out[x];
         if (fused) {
-            // the cost of the candidate (ba_cost_pass_kernel's sum, lane by lane): the candidate point is in the
-            // registers of all four lanes of the track, the candidate cameras are in LDS
             const double pc[3] = { out[0] / out[3], out[1] / out[3], out[2] / out[3] };
-            for (int k = k0 + sub; k < k1; k += kPointLanes) ccost += 0.5 * obs_cost_at(d, k, cand, cand_stride, pc);
+            for (int k = k0 + sub; k < k1; k += kPointLanes) ccost += 0.5 * obs_cost_at(d, k, cand, kCamDer, pc);
         }
     }
-    if (!fused) {
-        block_partial<false>(mcc, a.partials, 0, sh);
-        block_partial<false>(sn, a.partials, 1, sh);
-        block_partial<false>(xn, a.partials, 2, sh);
-        return;
-    }
-    block_partial<false, true>(mcc, a.partials, 0, sh);
-    block_partial<false, true>(sn, a.partials, 1, sh);
-    block_partial<false, true>(xn, a.partials, 2, sh);
-    block_partial<false, true>(ccost, a.cost_partials, 0, sh);
-    // ---- ba_lm_decide in the tail of the workgroup that finishes last ----
-    if (!last_workgroup(a.decide.ticket, &lds_last)) return;
-    lm_decide_block<true>(a.decide.lm, a.decide.prm, a.decide.sc, a.decide.host_out, sh);
+    back_pass_end(a, mcc, sn, xn, ccost, b, w.num, sh, &lds_last);
 }
 
-void launch_back_pass(const BaDev &d, const BackPassArgs &a, int blocks, hipStream_t s)
+void launch_back_pass(const BaDev &d, const BackPassArgs &a, const ObsWindows &w, hipStream_t s)
 {
-    const size_t lds = cam_stage_bytes(d, a.fused ? kStageBackFused : kStageBack);
-    hipLaunchKernelGGL(ba_back_pass_kernel, dim3(blocks), dim3(256), lds, s, d, a, lds ? 1 : 0);
+    // the decision rides in the tail of the launch that comes last
+    BackPassArgs first = a;
+    if (w.num_over > 0) first.decide.enabled = 0;
+    hipLaunchKernelGGL(ba_back_win_kernel, dim3(w.num), dim3(256), 0, s, d, first, w);
+    if (w.num_over > 0) hipLaunchKernelGGL(ba_back_over_kernel, dim3(w.num_over), dim3(256), 0, s, d, a, w);
 }
 
 // ---------------------------------------------------------------------------
-// cost at (cams, points) given explicitly
+// cost at (cameras with table rows `table`, points) given explicitly: a lane per observation
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void
-ba_cost_pass_kernel(BaDev dg, const double *table, const double *points, double *partials, int staged)
+ba_cost_pass_kernel(BaDev d, const double *table, const double *points, double *partials, ObsWindows w)
 {
-    extern __shared__ __attribute__((aligned(16))) char cam_lds[];
     __shared__ double sh[4];
-    if (dg.lm) {
+    if (d.lm) {
         // LM solve: the cost of the CANDIDATE (the iterate buffer that is not current)
-        if (dg.lm->stop || dg.lm->lin_failed || dg.lm->flow_aborted) return;
-        table = dg.lm->cur ? dg.camder2[0] : dg.camder2[1]; points = dg.lm->cur ? dg.points2[0] : dg.points2[1];
+        if (d.lm->stop || d.lm->lin_failed || d.lm->flow_aborted) return;
+        table = d.lm->cur ? d.camder2[0] : d.camder2[1]; points = d.lm->cur ? d.points2[0] : d.points2[1];
     }
-    const double *rows = table;
-    const BaDev d = stage_cameras(dg, cam_lds, staged ? kStageCost : 0, table, &rows, nullptr);
-    const int stride = staged ? kCamCost : kCamDer;
-    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = gt / kPointLanes, sub = gt % kPointLanes;
+    const WinDesc wd = w.desc[blockIdx.x];
     double cost = 0.0;
-    if (j < d.M) {
-        const double *P = points + 4 * j;
+    for (int k = wd.ka + (int)threadIdx.x; k < wd.kb; k += 256) {
+        const double *P = points + 4 * d.obs_pt[k];
         const double p[3] = { P[0] / P[3], P[1] / P[3], P[2] / P[3] };
-        for (int k = d.pt_start[j] + sub; k < d.pt_start[j + 1]; k += kPointLanes) cost += 0.5 * obs_cost_at(d, k, rows, stride, p);
+        cost += 0.5 * obs_cost_at(d, k, table, kCamDer, p);
     }
-    block_partial<false>(cost, partials, 0, sh);
+    block_partial<false>(cost, partials, 0, sh, blockIdx.x, w.num);
 }
 
 // table: the derived table rows of the cameras (ba_cam_derive / ba_cam_update)
 void launch_cost_pass(const BaDev &d, const double *table, const double *points, double *partials,
-    int blocks, hipStream_t s)
+    const ObsWindows &w, hipStream_t s)
 {
-    const size_t lds = cam_stage_bytes(d, kStageCost);
-    hipLaunchKernelGGL(ba_cost_pass_kernel, dim3(blocks), dim3(256), lds, s, d, table, points, partials, lds ? 1 : 0);
+    hipLaunchKernelGGL(ba_cost_pass_kernel, dim3(w.num), dim3(256), 0, s, d, table, points, partials, w);
 }
 
 // ---------------------------------------------------------------------------
