@@ -8,6 +8,7 @@
 // order inside one camera pair is the track order on every run.
 // (Host-side construction of the same lists cost ~14 ms for 3.6 M entries;
 // here it is a few launches.)
+#include <cstdlib>
 #include <hipcub/hipcub.hpp>
 
 #include "ba_kernels.h"
@@ -42,8 +43,18 @@ pair_count_kernel(BaDev d, int with_points, int32_t *counts)
     counts[a] = n;
 }
 
+// Key of the camera pair (ca, cb), ca >= cb: the sorted order is the order the pair pass's waves take the pairs
+// in, an XCD a contiguous range each.  Rows of `group` cameras ca go through the cameras cb together -- (ca / group,
+// cb, ca % group) -- so that the records of a camera cb, fetched into an XCD's L2 for one pair, serve the
+// other pairs of the group while they are there: in plain (ca, cb) order the b side of every pair came from
+// beyond the L2 (a global adjustment of 500 cameras streams 7 GB of them per pass).
+__host__ __device__ __forceinline__ uint32_t pair_key_of(uint32_t ca, uint32_t cb, uint32_t C, uint32_t group)
+{
+    return ((ca / group) * C + cb) * group + ca % group;
+}
+
 __global__ void
-pair_fill_kernel(BaDev d, int with_points, const int32_t *offsets, uint32_t *keys, uint64_t *vals)
+pair_fill_kernel(BaDev d, int with_points, int group, const int32_t *offsets, uint32_t *keys, uint64_t *vals)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= d.O) return;
@@ -55,7 +66,7 @@ pair_fill_kernel(BaDev d, int with_points, const int32_t *offsets, uint32_t *key
     for (int b = k0; b < k1; ++b) {
         const int cb = d.obs_cam[b];
         if (d.cam_ldim[cb] == 0 || ca < cb) continue;
-        keys[pos] = (uint32_t)ca * (uint32_t)d.C + (uint32_t)cb;
+        keys[pos] = pair_key_of((uint32_t)ca, (uint32_t)cb, (uint32_t)d.C, (uint32_t)group);
         vals[pos] = ((uint64_t)(uint32_t)a << 32) | (uint32_t)b;
         pos++;
     }
@@ -73,7 +84,7 @@ pair_chunk_count_kernel(const int32_t *runs, int num_pairs, int chunk, int32_t *
 // chunk (= wave) -> pair, so that a pair-pass wave finds its work with one load
 __global__ void
 pair_chunk_fill_kernel(const int32_t *chunk_start, int num_pairs, int32_t *chunk_pair, const int32_t *pair_start,
-    const uint32_t *pair_key, int num_cameras, int chunk, PairChunkDesc *desc)
+    const uint32_t *pair_key, int num_cameras, int group, int chunk, PairChunkDesc *desc)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= num_pairs) return;
@@ -84,7 +95,8 @@ pair_chunk_fill_kernel(const int32_t *chunk_start, int num_pairs, int32_t *chunk
         chunk_pair[c] = i;
         PairChunkDesc dsc;
         dsc.pi = i; dsc.e0 = p0 + (c - c0) * chunk; dsc.e1 = min(p1, dsc.e0 + chunk); dsc.nchunks = c1 - c0;
-        dsc.c1 = (int)(key / (uint32_t)num_cameras); dsc.c2 = (int)(key % (uint32_t)num_cameras);
+        dsc.c1 = (int)((key / ((uint32_t)num_cameras * (uint32_t)group)) * (uint32_t)group + key % (uint32_t)group);
+        dsc.c2 = (int)((key / (uint32_t)group) % (uint32_t)num_cameras);
         dsc.first = c0; dsc.pad1 = 0;
         desc[c] = dsc;
     }
@@ -122,7 +134,9 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
     size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     int32_t *counts = out->counts.as<int32_t>(), *offsets = out->offsets.as<int32_t>();
     int bits = 1;
-    while ((1ull << bits) < (unsigned long long)d.C * (unsigned long long)d.C) ++bits;
+    static const int group = getenv("OSFM_BA_PAIR_GROUP") ? std::max(1, atoi(getenv("OSFM_BA_PAIR_GROUP"))) : 8;
+    if (((unsigned long long)d.C + group) * (unsigned long long)d.C >= (1ull << 32)) { set_error("ba_solve: too many cameras for 32-bit pair keys"); return OSFM_E_RANGE; }
+    while ((1ull << bits) < ((unsigned long long)d.C + group) * (unsigned long long)d.C) ++bits;
     OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, t1, counts, offsets, M, s));
     OSFM_RETURN_IF(out->temp.reserve(t1 + 256));
     size_t tb = out->temp.bytes;
@@ -148,7 +162,7 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
     OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, t4, out->runs.as<int32_t>(), out->starts.as<int32_t>(),
         (int)max_runs, s));
     OSFM_RETURN_IF(out->temp.reserve(std::max(std::max(t1, t2), std::max(t3, t4)) + 256));
-    hipLaunchKernelGGL(pair_fill_kernel, dim3(blocks), dim3(256), 0, s, d, with_points ? 1 : 0, offsets, kin, vin);
+    hipLaunchKernelGGL(pair_fill_kernel, dim3(blocks), dim3(256), 0, s, d, with_points ? 1 : 0, group, offsets, kin, vin);
     tb = out->temp.bytes;
     OSFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(out->temp.ptr, tb, kin, kout, vin, vout, E, 0, bits, s));
     tb = out->temp.bytes;
@@ -184,7 +198,7 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
     OSFM_HIP_CHECK(hipMemsetAsync(out->chunk_desc.ptr, 0, (size_t)(out->max_chunks + 4) * sizeof(PairChunkDesc), s));
     hipLaunchKernelGGL(pair_chunk_fill_kernel, dim3((h_runs + 255) / 256), dim3(256), 0, s,
         out->chunk_start.as<int32_t>(), h_runs, out->chunk_pair.as<int32_t>(), out->starts.as<int32_t>(),
-        out->unique.as<uint32_t>(), d.C, out->chunk, out->chunk_desc.as<PairChunkDesc>());
+        out->unique.as<uint32_t>(), d.C, group, out->chunk, out->chunk_desc.as<PairChunkDesc>());
     // (nothing more to read back: the pairs with several chunks finish themselves, by ticket, inside the pair pass)
     OSFM_HIP_CHECK(hipGetLastError());
     return OSFM_OK;

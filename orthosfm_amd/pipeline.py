@@ -508,6 +508,11 @@ def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, ti
     info = {"num_pairs": int(pf.shape[0]), "matched_pairs": int(builder.num_pairs), "correspondences": int(builder.num_matches),
             "num_mve_tracks": int(summary.num_tracks), "invalid_mve_tracks": int(summary.num_invalid_tracks),
             "pair_status": status}
+    try:
+        st = m.stats()
+        info["match_stats"] = {f[0]: getattr(st, f[0]) for f in st._fields_ if not f[0].startswith("reserved")}
+    except Exception:
+        pass
     builder.close()
     # the matcher's device memory (the bank, 16 GB of partial-result scratch) goes back on a thread of its
     # own: freeing it takes 0.1 s that the pose estimation need not wait for
@@ -860,6 +865,7 @@ def reconstruct(iset, solver=0, matcher="exhaustive", device=0, verify=True, rot
         euler_dof=euler_dof_of_solver(solver), check_incremental=check_incremental, use_scene=use_scene)
     join_background()            # inside the clock: the matcher's memory is back when the job is done
     tm.total_s = time.perf_counter() - t_all
+    info.pop("match_stats", None)
     return Result(cams, aligned, tt, groups, tm, calls, captured=captured, **info)
 
 
