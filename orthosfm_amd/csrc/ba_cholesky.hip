@@ -487,6 +487,23 @@ __device__ __forceinline__ int flow_x_flag(const CholFlow &f, int k) { return fl
 __device__ __forceinline__ int flow_xbox_flag(const CholFlow &f, int k) { return flow_abort_flag(f) + 1 + f.nblk + k; }
 __device__ __forceinline__ double *flow_xbox(const CholFlow &f, int k) { return f.mailbox + (size_t)(f.nblk + 1) * (kFlowW + 1) * NB * NB + (size_t)k * NB; }
 __device__ __forceinline__ int flow_xcc() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15; }
+// ... and as GRANULES in the flag block (zero at the start of a solve like the flags): 16 bytes { value, tag } per
+// entry, the data is the flag (cdna_hip_programming.md R2; 16-byte stores and sc1 loads observed untorn on gfx950).
+// Two copies per block: [0] stored plain, tag = epoch | producer's XCD -- a reader behind the same L2 sees it there;
+// [1] stored sc1, tag = epoch, for everybody.  A reader asks for both side by side: ONE round trip per hand-off,
+// where a flag poll followed by the load of the 32 doubles was two.
+typedef unsigned int flow_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int flow_granule_base(const CholFlow &f) { return (flow_abort_flag(f) + 1 + 2 * f.nblk + 3) & ~3; }
+__device__ __forceinline__ flow_u4 *flow_x_granules(const CholFlow &f, int k, int copy)
+{
+    return reinterpret_cast<flow_u4 *>(f.flags + flow_granule_base(f)) + ((size_t)k * 2 + copy) * NB;
+}
+__device__ __forceinline__ flow_u4 flow_granule(double v, int tag)
+{
+    flow_u4 g;
+    g.x = (unsigned)__double2loint(v); g.y = (unsigned)__double2hiint(v); g.z = (unsigned)tag; g.w = 0u;
+    return g;
+}
 
 // plain store / flag for a reader behind the same L2 (no cache-policy bits)
 __device__ __forceinline__ void store_flag_plain(int *p, int v)
@@ -833,12 +850,75 @@ flow_d_forward(const CholFlow &f, FlowWaiter &w, const FlowPos &p, int row, Flow
 
 // Backward substitution for block `row` of the solution by the D workgroup that owns the row:
 // x_k = inv(L_kk)^T (y_k - sum_{i > k} L_ik^T x_i).  inv(L_kk) is in Li (li_resident) or fetched from the
-// workgroup's own sc1 copy; y_k is row 0 of the right-hand side tile (nblk, k); the tiles L(i, k) of ITS column
-// come in from i = nblk - 1 downwards, each fetched while the workgroup waits for x_i (two LDS buffers), so that
-// a step costs the hand-off of 32 doubles and two 32 x 32 matrix-vector products.
+// workgroup's own sc1 copy; y_k is row 0 of the right-hand side tile (nblk, k).  The blocks of the solution are a
+// chain -- x_k cannot start before x_(k+1) is there -- and a link of it was a flag poll, the load of the 32
+// doubles, two 32 x 32 matrix-vector products of 32 dependent multiply-adds each with a barrier between them,
+// a store, a drain and a flag: 2.4 us, 77 of the 277 us of a 32-block system.  Now everything that does not
+// need x_(k+1) is done before it arrives: the tiles L(i, k), i > k + 1, are applied as their x_i come in (each fetched
+// while the workgroup waits), u = inv(L_kk)^T s and M = inv(L_kk)^T L(k+1, k)^T are formed, and the link itself is one
+// wave's work: the granules of x_(k+1) (value and tag in one 16-byte word: one round trip), x_k = u - M x_(k+1) with
+// four partial sums per lane, the granules of x_k.
+__device__ __forceinline__ bool
+flow_wait_x(const CholFlow &f, FlowWaiter &w, int i, double *xv, bool with_barrier)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (w.pending_flag >= 0) {
+        lds_barrier();
+        if (threadIdx.x == 0) __hip_atomic_store(f.flags + w.pending_flag, f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w.pending_flag = -1;
+    }
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        bool have = lane >= NB, ok = true;
+        double val = 0.0;
+        const flow_u4 *gp = flow_x_granules(f, i, 0) + (lane & (NB - 1)), *gs = flow_x_granules(f, i, 1) + (lane & (NB - 1));
+        const int *pab = f.flags + flow_abort_flag(f);
+        const unsigned want_box = (unsigned)(f.epoch | ((flow_xcc() + 1) << 24));
+        for (int spins = 0;; ++spins) {
+            if (!have) {
+                flow_u4 a, b;
+                asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                    : "=&v"(a), "=&v"(b) : "v"(gp), "v"(gs) : "memory");
+                if (a.z == want_box) { val = __hiloint2double((int)a.y, (int)a.x); have = true; }
+                else if (b.z == (unsigned)f.epoch) { val = __hiloint2double((int)b.y, (int)b.x); have = true; }
+            }
+            if (__ballot(!have) == 0) break;
+            if ((spins & 15) == 15 && __hip_atomic_load(pab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f.epoch) { ok = false; break; }
+            if (spins > f.spin_limit) {
+                if (lane == 0) __hip_atomic_store(f.flags + flow_abort_flag(f), f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok && lane == 0) atomicMax(f.info, kFlowAborted);      // the caller repeats the factorisation launch by launch
+        if (lane < NB) xv[lane] = val;
+        if (lane < 8) w.how[(w.phase ^ 1) * 8 + lane] = ok ? 1 : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    w.phase ^= 1;
+    if (with_barrier) lds_barrier();
+    return true;
+}
+
+// the 32 lanes' dot products acc[lane] -= sum_r T[r][lane] x[r] (or T[lane][r]: ROWS), four partial sums each
+template <bool ROWS>
+__device__ __forceinline__ double flow_matvec_sub(double acc, const double (*T)[NB + 1], const double *xv, int lane)
+{
+    double a0 = acc, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+    for (int r = 0; r < NB; r += 4) {
+        a0 = fma(-(ROWS ? T[lane][r] : T[r][lane]), xv[r], a0);
+        a1 = fma(-(ROWS ? T[lane][r + 1] : T[r + 1][lane]), xv[r + 1], a1);
+        a2 = fma(-(ROWS ? T[lane][r + 2] : T[r + 2][lane]), xv[r + 2], a2);
+        a3 = fma(-(ROWS ? T[lane][r + 3] : T[r + 3][lane]), xv[r + 3], a3);
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
 __device__ __forceinline__ bool
 flow_d_backward(const CholFlow &f, FlowWaiter &w, const FlowPos &p, int row, bool li_resident, FlowLds Xr, FlowLds Xc, FlowLds Li,
-    double *sv, double *xv)
+    FlowLds Mx, double *sv, double *xv)
 {
     const int nblk = f.nblk, ld = f.ld, tid = threadIdx.x;
     const int my_tag = f.epoch | ((flow_xcc() + 1) << 24);
@@ -846,53 +926,109 @@ flow_d_backward(const CholFlow &f, FlowWaiter &w, const FlowPos &p, int row, boo
         lds_barrier();
         flow_load_tile(f.Ldiag + (size_t)row * NB * NB, NB, Li, p);
     }
-    auto tile_into = [&](int i, FlowLds dst) -> bool {
-        const bool from_d = i - row <= kFlowW;
-        const int how = flow_wait(f, w, flow_tile_flag(f, i, row), from_d ? flow_box_flag(f, i, i - row) : -1);
-        if (!how) return false;
-        if (how == 2) flow_load_tile(flow_box(f, i, i - row), NB, dst, p);
-        else flow_load_tile(f.Lmat + (size_t)(i * NB) * ld + row * NB, ld, dst, p);
-        return true;
-    };
     {
         const bool from_d = nblk - row <= kFlowW;
         const int how = flow_wait(f, w, flow_tile_flag(f, nblk, row), from_d ? flow_box_flag(f, nblk, nblk - row) : -1);
         if (!how) return false;
         if (tid < NB) sv[tid] = load_sc1(how == 2 ? flow_box(f, nblk, nblk - row) + tid : f.Lmat + (size_t)(nblk * NB) * ld + row * NB + tid);
     }
-    int cur = 0;
-    if (nblk - 1 > row && !tile_into(nblk - 1, Xr)) return false;
-    for (int i = nblk - 1; i > row; --i) {
-        FlowLds T = cur ? Xc : Xr;
-        if (i - 1 > row && !tile_into(i - 1, cur ? Xr : Xc)) return false;
-        const int how = flow_wait(f, w, flow_x_flag(f, i), flow_xbox_flag(f, i));
-        if (!how) return false;
-        if (tid < NB) xv[tid] = load_sc1(how == 2 ? flow_xbox(f, i) + tid : f.x + (size_t)i * NB + tid);
+    const bool linked = row + 1 < nblk;
+    // every tile of the column is final by the time the first block of the solution exists; their flags are looked
+    // at once, 64 per poll (the sc1 copies: no mailbox verdicts), and the tiles then fetched without waiting
+    for (int i0 = row + 1; i0 < nblk; i0 += 64) {
+        const int i = i0 + tid;
+        if (!flow_wait_lanes(f, w, tid < 64 && i < nblk ? flow_tile_flag(f, i, row) : -1, -1)) return false;
+    }
+    auto fetch = [&](int i) { return flow_fetch_tile(f.Lmat + (size_t)(i * NB) * ld + row * NB, ld, p); };
+    if (linked) {
+        // M[m][r] = sum_{c >= m} inv(L)[c][m] L(row + 1, row)[r][c]: the link's matrix, long before the link
+        flow_put_tile(fetch(row + 1), Xr, p);
         lds_barrier();
-        if (tid < NB) {
-            double a = sv[tid];
+        const int m = tid & (NB - 1);
 #pragma unroll
-            for (int r = 0; r < NB; ++r) a = fma(-T[r][tid], xv[r], a);
-            sv[tid] = a;
+        for (int q = 0; q < 4; ++q) {
+            const int r = (tid >> 5) + 8 * q;
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int c = 0; c < NB; c += 2) {
+                a0 = fma(c >= m ? Li[c][m] : 0.0, Xr[r][c], a0);
+                a1 = fma(c + 1 >= m ? Li[c + 1][m] : 0.0, Xr[r][c + 1], a1);
+            }
+            Mx[m][r] = a0 + a1;
         }
+        lds_barrier();
+    }
+    // the tiles above the link, as their blocks of the solution come in: the next tile is on its way while this one's
+    // x is awaited
+    int cur = 0;
+    if (nblk - 1 > row + 1) flow_put_tile(fetch(nblk - 1), Xr, p);
+    for (int i = nblk - 1; i > row + 1; --i) {
+        FlowLds T = cur ? Xc : Xr;
+        FlowTile next;
+        const bool more = i - 1 > row + 1;
+        if (more) next = fetch(i - 1);
+        flow_wait_x(f, w, i, xv, true);
+        if (!flow_how(w, 0)) return false;
+        if (tid < 64) {
+            // both halves of wave 0: lane c + 32 h adds the products of rows 16 h .. 16 h + 15
+            const int c = tid & (NB - 1), r0 = (tid >> 5) * (NB / 2);
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+            for (int r = 0; r < NB / 2; r += 4) {
+                a0 = fma(T[r0 + r][c], xv[r0 + r], a0);
+                a1 = fma(T[r0 + r + 1][c], xv[r0 + r + 1], a1);
+                a2 = fma(T[r0 + r + 2][c], xv[r0 + r + 2], a2);
+                a3 = fma(T[r0 + r + 3][c], xv[r0 + r + 3], a3);
+            }
+            const double part = (a0 + a1) + (a2 + a3);
+            const double tot = part + __shfl_xor(part, 32);
+            if (tid < NB) sv[tid] -= tot;
+        }
+        if (more) flow_put_tile(next, cur ? Xr : Xc, p);
         lds_barrier();
         cur ^= 1;
     }
     lds_barrier();
+    // u = inv(L)^T s, then the link: one wave
+    double u = 0.0;
     if (tid < NB) {
-        // x_k[m] = sum_{c >= m} inv(L)[c][m] * s[c]
-        double v = 0.0;
+        double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-        for (int c = 0; c < NB; ++c) v += (c >= tid) ? Li[c][tid] * sv[c] : 0.0;
-        flow_xbox(f, row)[tid] = v;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) store_flag_plain(f.flags + flow_xbox_flag(f, row), my_tag);
-        store_sc1(f.x + (size_t)row * NB + tid, v);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) __hip_atomic_store(f.flags + flow_x_flag(f, row), f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int c = 0; c < NB; c += 2) {
+            a0 = fma(c >= tid ? Li[c][tid] : 0.0, sv[c], a0);
+            a1 = fma(c + 1 >= tid ? Li[c + 1][tid] : 0.0, sv[c + 1], a1);
+        }
+        u = a0 + a1;
     }
-    return true;
+    if (linked) flow_wait_x(f, w, row + 1, xv, false);
+    if (tid < 64) {
+        // both halves of the wave: lane m + 32 h sums the products of entries 16 h .. 16 h + 15
+        const bool ok = !linked || flow_how(w, 0) != 0;
+        const int m = tid & (NB - 1), r0 = (tid >> 5) * (NB / 2);
+        double v = u;
+        if (linked) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+            for (int r = 0; r < NB / 2; r += 4) {
+                a0 = fma(Mx[m][r0 + r], xv[r0 + r], a0);
+                a1 = fma(Mx[m][r0 + r + 1], xv[r0 + r + 1], a1);
+                a2 = fma(Mx[m][r0 + r + 2], xv[r0 + r + 2], a2);
+                a3 = fma(Mx[m][r0 + r + 3], xv[r0 + r + 3], a3);
+            }
+            const double part = (a0 + a1) + (a2 + a3);
+            v = u - (part + __shfl_xor(part, 32));
+        }
+        if (ok && tid < NB) {
+            const flow_u4 gp = flow_granule(v, my_tag), gs = flow_granule(v, f.epoch);
+            asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(flow_x_granules(f, row, 0) + tid), "v"(gp) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(flow_x_granules(f, row, 1) + tid), "v"(gs) : "memory");
+            f.x[(size_t)row * NB + tid] = v;         // for the kernels behind this launch
+        }
+    }
+    lds_barrier();
+    return !linked || flow_how(w, 0) != 0;
 }
+
 
 // Two workgroups per CU (256 registers per lane): at three (168) the kernel spilled -- into scratch memory inside the
 // diagonal factor, of all places -- and since a workgroup works through a list of tiles the grid no longer needs the room.
@@ -938,7 +1074,7 @@ chol_flow_kernel(CholFlow f)
     if (f.x == nullptr) return;
     for (int row = last; row >= 0; row -= f.num_d) {
         if (row >= nblk) continue;                                  // the right-hand side's row has no unknowns
-        if (!flow_d_backward(f, w, p, row, row == last, Xr, Xc, Li, sv, xv)) return;
+        if (!flow_d_backward(f, w, p, row, row == last, Xr, Xc, Li, Mt, sv, xv)) return;
     }
 }
 
@@ -982,7 +1118,8 @@ int chol_flow_capacity()
 int chol_flow_flag_count(int n)
 {
     const int nblk = cholesky_padded_dim(n) / NB;
-    return (nblk + 2) * nblk + (nblk + 1) * (kFlowW + 1) + 1 + 2 * nblk + 16;
+    // flags, then (16-byte aligned) the granules of the solution: 2 copies x 32 entries x 4 words per block
+    return (nblk + 2) * nblk + (nblk + 1) * (kFlowW + 1) + 1 + 2 * nblk + 16 + nblk * 2 * NB * 4;
 }
 
 size_t chol_flow_mailbox_bytes(int n)
