@@ -260,6 +260,17 @@ int read_total(const int32_t *scan, int64_t n, hipStream_t s, int *out)
     return OSFM_OK;
 }
 
+// two of them behind ONE synchronisation
+int read_totals2(const int32_t *scan_a, int64_t na, const int32_t *scan_b, int64_t nb, hipStream_t s, int *out_a, int *out_b)
+{
+    int32_t v[2] = { 0, 0 };
+    OSFM_HIP_CHECK(hipMemcpyAsync(&v[0], scan_a + na, 4, hipMemcpyDeviceToHost, s));
+    OSFM_HIP_CHECK(hipMemcpyAsync(&v[1], scan_b + nb, 4, hipMemcpyDeviceToHost, s));
+    OSFM_HIP_CHECK(hipStreamSynchronize(s));
+    *out_a = v[0]; *out_b = v[1];
+    return OSFM_OK;
+}
+
 int reserve_scratch(osfm_scene *sc)
 {
     const size_t F1 = (size_t)sc->F + 1, T1 = (size_t)sc->T + 1;
@@ -281,18 +292,25 @@ struct Compact {
     DeviceProblem D;
     DevArray point_track;
     int O = 0, M = 0, C = 0;
+    std::vector<int32_t> w, h;       // image sizes of the cameras: the source of copies that may still be queued
 };
 
 // sel / scan: per-feature flags and their scan; tflag: per-track point flags (T + 1 entries); point_in: start
-// values by track (nullptr: (0, 0, 0, 1)); cameras: C x 7 on the host (h_cams) or on the device (d_cams)
+// values by track (nullptr: (0, 0, 0, 1)); cameras: C x 7 on the host (h_cams) or on the device (d_cams).
+// known_M >= 0: the caller has scanned tflag into sc->tslot and read its total already (with another count,
+// behind one synchronisation).  Nothing is synchronised here: *out, *L, h_cams and h_const have to outlive the
+// stream's next synchronisation.
 int build_problem(osfm_scene *sc, const int32_t *sel, const int32_t *scan, int O, const int32_t *tflag,
     const double *point_in, int C, const double *h_cams, const double *d_cams, const uint8_t *h_const,
-    const int32_t *cam_views, const int32_t *cam_map, double huber, int pdim, Layout *L, hipStream_t s, Compact *out)
+    const int32_t *cam_views, const int32_t *cam_map, double huber, int pdim, Layout *L, hipStream_t s, Compact *out,
+    int known_M = -1)
 {
     int32_t *tslot = sc->tslot.as<int32_t>();
-    OSFM_RETURN_IF(exclusive_scan(sc, tflag, tslot, (int64_t)sc->T + 1, s));
-    int M = 0;
-    OSFM_RETURN_IF(read_total(tslot, sc->T, s, &M));
+    int M = known_M;
+    if (M < 0) {
+        OSFM_RETURN_IF(exclusive_scan(sc, tflag, tslot, (int64_t)sc->T + 1, s));
+        OSFM_RETURN_IF(read_total(tslot, sc->T, s, &M));
+    }
     out->O = O; out->M = M; out->C = C;
     DeviceProblem &D = out->D;
     OSFM_RETURN_IF(D.obs_xy.alloc((size_t)std::max(O, 1) * 16));
@@ -307,14 +325,14 @@ int build_problem(osfm_scene *sc, const int32_t *sel, const int32_t *scan, int O
         scan, tflag, tslot, point_in, D.pt_start.as<int32_t>(), out->point_track.as<int32_t>(), D.points[0].as<double>());
     if (h_cams) OSFM_HIP_CHECK(hipMemcpyAsync(D.cams[0].ptr, h_cams, (size_t)C * 56, hipMemcpyHostToDevice, s));
     else if (C) OSFM_HIP_CHECK(hipMemcpyAsync(D.cams[0].ptr, d_cams, (size_t)C * 56, hipMemcpyDeviceToDevice, s));
-    std::vector<int32_t> w(C), h(C);
+    std::vector<int32_t> &w = out->w, &h = out->h;
+    w.resize(C); h.resize(C);
     for (int c = 0; c < C; ++c) { w[c] = sc->img_w[cam_views[c]]; h[c] = sc->img_h[cam_views[c]]; }
     OSFM_RETURN_IF(upload(D.img_w, w.data(), (size_t)C, s));
     OSFM_RETURN_IF(upload(D.img_h, h.data(), (size_t)C, s));
     build_camera_layout(sc->model, C, h_const, L);
     OSFM_RETURN_IF(upload_camera_layout(*L, C, s, &D));
     OSFM_RETURN_IF(finish_device_problem(sc->model, C, M, O, L->nc, huber, pdim, s, &D));
-    OSFM_HIP_CHECK(hipStreamSynchronize(s));            // w / h (and the layout's vectors) leave scope with the caller
     return OSFM_OK;
 }
 
@@ -348,12 +366,13 @@ int triangulate_pass(osfm_scene *sc, const uint8_t *tmask, bool clear_all, uint8
     hipLaunchKernelGGL(scene_track_count_kernel, dim3(blocks_for(T)), dim3(kThreads), 0, s, T, sc->offsets.as<int32_t>(), scan, cnt);
     hipLaunchKernelGGL(scene_track_flag_kernel, dim3(blocks_for(T + 1)), dim3(kThreads), 0, s, T, (int)kFlagCountPositive, 0, cnt,
         nullptr, nullptr, tflag);
-    int O = 0;
-    OSFM_RETURN_IF(read_total(scan, F, s, &O));
+    int O = 0, M = 0;
+    OSFM_RETURN_IF(exclusive_scan(sc, tflag, sc->tslot.as<int32_t>(), (int64_t)T + 1, s));
+    OSFM_RETURN_IF(read_totals2(scan, F, sc->tslot.as<int32_t>(), T, s, &O, &M));
     Compact P;
     Layout L;
     OSFM_RETURN_IF(build_problem(sc, sel, scan, O, tflag, nullptr, C, nullptr, sc->cams.as<double>(), sc->h_const.data(),
-        sc->aligned.data(), sc->cam_of_view.as<int32_t>(), 1.0, 3, &L, s, &P));
+        sc->aligned.data(), sc->cam_of_view.as<int32_t>(), 1.0, 3, &L, s, &P, M));
     DevArray valid;
     OSFM_RETURN_IF(valid.alloc((size_t)std::max(P.M, 1)));
     if (P.M) {
@@ -371,7 +390,7 @@ int triangulate_pass(osfm_scene *sc, const uint8_t *tmask, bool clear_all, uint8
 // filterTracksWithReprojectionError on the scene for the cameras (views, params, const masks); permanent: the flags
 // are cleared.  Leaves sel / scan (the features the adjustment behind it works on) and *num_selected.
 int reprojection_filter(osfm_scene *sc, int n, const int32_t *views, const double *params, const uint8_t *cconst,
-    double max_error, bool permanent, hipStream_t s, int *num_selected)
+    double max_error, bool permanent, hipStream_t s, int *num_selected, int *num_tracks_selected = nullptr)
 {
     const int64_t F = sc->F;
     const int T = sc->T;
@@ -405,22 +424,23 @@ int reprojection_filter(osfm_scene *sc, int n, const int32_t *views, const doubl
             sc->alive_f.as<uint8_t>(), sc->alive_t.as<uint8_t>(), cam_map, fullmask, sel_full);
     }
     OSFM_RETURN_IF(exclusive_scan(sc, sel_full, scan2, F + 1, s));
-    int O1 = 0;
-    OSFM_RETURN_IF(read_total(scan2, F, s, &O1));
+    int O1 = 0, M1 = 0;
+    OSFM_RETURN_IF(exclusive_scan(sc, tflag, sc->tslot.as<int32_t>(), (int64_t)T + 1, s));
+    OSFM_RETURN_IF(read_totals2(scan2, F, sc->tslot.as<int32_t>(), T, s, &O1, &M1));
     DevArray err;
     OSFM_RETURN_IF(err.alloc((size_t)std::max(O1, 1) * 8));
+    // (P's arrays go back to the pool when this function returns: behind the synchronisation at its end)
+    Compact P;
+    Layout L;
     if (O1 > 0) {
-        Compact P;
-        Layout L;
         OSFM_RETURN_IF(build_problem(sc, sel_full, scan2, O1, tflag, sc->point.as<double>(), n, params, nullptr, cconst, views, cam_map,
-            1.0, 3, &L, s, &P));
+            1.0, 3, &L, s, &P, M1));
         // triangulateTracks(cameras, fullSizeTracks, true) + evaluateReprojectionError per feature (osfm_filter_reprojection)
         OSFM_HIP_CHECK(hipMemcpyAsync(P.D.points[1].ptr, P.D.points[0].ptr, (size_t)P.M * 32, hipMemcpyDeviceToDevice, s));
         launch_triangulate(P.D.dev, P.D.points[1].as<double>(), nullptr, s);
         OSFM_HIP_CHECK(hipMemcpyAsync(P.D.points[0].ptr, P.D.points[1].ptr, (size_t)P.M * 32, hipMemcpyDeviceToDevice, s));
         launch_reproj(P.D.dev, err.as<double>(), nullptr, s);
         OSFM_HIP_CHECK(hipGetLastError());
-        OSFM_HIP_CHECK(hipStreamSynchronize(s));            // P's arrays go back to the pool with this scope
     }
     hipLaunchKernelGGL(scene_keep_kernel, gF, b, 0, s, F, in_set, sel_full, scan2, err.as<double>(), max_error, keep);
     OSFM_RETURN_IF(exclusive_scan(sc, keep, scan, F + 1, s));
@@ -434,7 +454,16 @@ int reprojection_filter(osfm_scene *sc, int n, const int32_t *views, const doubl
         hipLaunchKernelGGL(scene_kill_features_kernel, gF, b, 0, s, F, in_set, keep, sc->alive_f.as<uint8_t>());
     }
     OSFM_HIP_CHECK(hipGetLastError());
-    OSFM_RETURN_IF(read_total(scan, F, s, num_selected));
+    if (num_tracks_selected) {
+        // the tracks of the selection, numbered as they appear (what the adjustment behind this builds its points
+        // from): flags in sc->tflag, their scan in sc->tslot, both totals behind one synchronisation
+        hipLaunchKernelGGL(scene_track_count_kernel, gT, b, 0, s, T, sc->offsets.as<int32_t>(), scan, cnt_set);
+        hipLaunchKernelGGL(scene_track_flag_kernel, gT, b, 0, s, T, (int)kFlagCountPositive, 0, cnt_set, nullptr, nullptr, tflag);
+        OSFM_RETURN_IF(exclusive_scan(sc, tflag, sc->tslot.as<int32_t>(), (int64_t)T + 1, s));
+        OSFM_RETURN_IF(read_totals2(scan, F, sc->tslot.as<int32_t>(), T, s, num_selected, num_tracks_selected));
+    } else {
+        OSFM_RETURN_IF(read_total(scan, F, s, num_selected));
+    }
     return OSFM_OK;
 }
 
@@ -658,20 +687,18 @@ int osfm_scene_local_adjustment(osfm_scene *sc, int n, const int32_t *views, dou
         if (trace) fprintf(stderr, "[osfm scene] %-22s %8.3f ms\n", what,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     };
-    int O = 0;
-    OSFM_RETURN_IF(reprojection_filter(sc, n, views, params, cam_const, max_error, false, s, &O));
+    int O = 0, M = 0;
+    OSFM_RETURN_IF(reprojection_filter(sc, n, views, params, cam_const, max_error, false, s, &O, &M));
     lap("filter");
-    // the features the filter leaves, their tracks numbered as they appear, every point at (0, 0, 0, 1): the
-    // adjustment re-triangulates its copy first (runBundleAdjustment(..., true, true), reconstruct.cpp:212-219)
-    int32_t *sel = sc->sel.as<int32_t>(), *scan = sc->scan.as<int32_t>(), *cnt = sc->cnt.as<int32_t>(), *tflag = sc->tflag.as<int32_t>();
-    hipLaunchKernelGGL(scene_track_count_kernel, dim3(blocks_for(sc->T)), dim3(kThreads), 0, s, sc->T, sc->offsets.as<int32_t>(), scan, cnt);
-    hipLaunchKernelGGL(scene_track_flag_kernel, dim3(blocks_for(sc->T + 1)), dim3(kThreads), 0, s, sc->T, (int)kFlagCountPositive, 0, cnt,
-        nullptr, nullptr, tflag);
+    // the features the filter leaves, their tracks numbered as they appear (the filter has flagged and counted them),
+    // every point at (0, 0, 0, 1): the adjustment re-triangulates its copy first (runBundleAdjustment(..., true, true),
+    // reconstruct.cpp:212-219)
+    int32_t *sel = sc->sel.as<int32_t>(), *scan = sc->scan.as<int32_t>(), *tflag = sc->tflag.as<int32_t>();
     Compact P;
     Layout L;
     const int pdim = o.optimize_points ? 3 : 0;
     OSFM_RETURN_IF(build_problem(sc, sel, scan, O, tflag, nullptr, n, params, nullptr, cam_const, views, sc->cam_map.as<int32_t>(),
-        o.huber_delta, pdim, &L, s, &P));
+        o.huber_delta, pdim, &L, s, &P, M));
     if (num_points) *num_points = P.M;
     if (num_observations) *num_observations = P.O;
     lap("problem");
@@ -717,13 +744,14 @@ int osfm_scene_global_adjustment(osfm_scene *sc, const osfm_ba_options *opt, osf
     hipLaunchKernelGGL(scene_select_kernel, dim3(blocks_for(F + 1)), dim3(kThreads), 0, s, F, sc->feat_view.as<int32_t>(),
         sc->track_of.as<int32_t>(), sc->alive_f.as<uint8_t>(), sc->alive_t.as<uint8_t>(), sc->cam_of_view.as<int32_t>(), tmask, sel);
     OSFM_RETURN_IF(exclusive_scan(sc, sel, scan, F + 1, s));
-    int O = 0;
-    OSFM_RETURN_IF(read_total(scan, F, s, &O));
+    int O = 0, M = 0;
+    OSFM_RETURN_IF(exclusive_scan(sc, tflag, sc->tslot.as<int32_t>(), (int64_t)T + 1, s));
+    OSFM_RETURN_IF(read_totals2(scan, F, sc->tslot.as<int32_t>(), T, s, &O, &M));
     Compact P;
     Layout L;
     const int pdim = o.optimize_points ? 3 : 0;
     OSFM_RETURN_IF(build_problem(sc, sel, scan, O, tflag, sc->point.as<double>(), C, nullptr, sc->cams.as<double>(), sc->h_const.data(),
-        sc->aligned.data(), sc->cam_of_view.as<int32_t>(), o.huber_delta, pdim, &L, s, &P));
+        sc->aligned.data(), sc->cam_of_view.as<int32_t>(), o.huber_delta, pdim, &L, s, &P, M));
     if (num_points) *num_points = P.M;
     if (num_observations) *num_observations = P.O;
     int64_t bound = 0;
