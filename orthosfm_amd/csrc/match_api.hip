@@ -6,6 +6,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -1576,6 +1577,12 @@ int match_all_single(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osf
         // (not in cascade-hashing mode: its bucket kernels want the large launch)
         if (o.pairs_per_batch <= 0 && !o.geometric_verification && o.matcher_type != OSFM_MATCHER_CASCADE_HASHING && n_full >= 768)
             bs = std::min<int>(bs, (int)((n_full + 2) / 3));
+        // parts of equal size: a call of 3898 pairs at 1875 per part ran 1875 + 1875 + 148, and the short part took
+        // 17.5 ms where its pairs are worth 8 (a launch's fixed costs and tail): 0.3 s of a 500-view job
+        if (o.pairs_per_batch <= 0 && n_full > (size_t)bs) {
+            const size_t parts = (n_full + bs - 1) / bs;
+            bs = (int)((n_full + parts - 1) / parts);
+        }
         return bs;
     };
 
@@ -1620,8 +1627,15 @@ int match_all_single(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osf
             const int n = (int)(end - start);
             chunk.clear();
             for (size_t k = start; k < end; ++k) chunk.push_back(pairs[full_idx[k]]);
+            static const bool trace = getenv("OSFM_MATCH_TRACE") != nullptr;
+            const auto t_chunk = std::chrono::steady_clock::now();
+            auto lap = [&](const char *what) {
+                if (trace) fprintf(stderr, "[osfm match] %-18s %9.3f ms\n", what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_chunk).count());
+            };
             BatchResult res;
             OSFM_RETURN_IF(run_batch(m, chunk.data(), n, BatchMode(), &res));
+            lap("matched");
             h_m12_off.assign(n, 0); h_corr_off.assign(n, 0); h_len12.assign(n, 0); h_keep.assign(n, 0);
             int64_t chunk_corr = 0;
             for (int k = 0; k < n; ++k) {
@@ -1707,7 +1721,9 @@ int match_all_single(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osf
                 OSFM_HIP_CHECK(hipGetLastError());
                 std::vector<int32_t> h_cnt(jobs.size());
                 OSFM_HIP_CHECK(hipMemcpyAsync(h_cnt.data(), m->d_inl_count.ptr, jobs.size() * 4, hipMemcpyDeviceToHost, s));
+                lap("ransac queued");
                 OSFM_HIP_CHECK(hipStreamSynchronize(s));
+                lap("ransac done");
                 // keep pairs with enough inliers; gather their inlier correspondences
                 const int min_inl = std::max(8, o.min_matching_inliers);
                 std::vector<int64_t> g_src, g_dst;     // per job: source offset (corr / inlier ids), destination
@@ -1738,6 +1754,7 @@ int match_all_single(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osf
                     OSFM_HIP_CHECK(hipMemcpyAsync(corr + 2 * written_out, m->d_corr2.ptr, (size_t)chunk_out * 8,
                         hipMemcpyDeviceToHost, s));
                     OSFM_HIP_CHECK(hipStreamSynchronize(s));
+                    lap("lists on the host");
                 }
                 written_out += chunk_out;
             }

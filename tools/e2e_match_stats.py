@@ -6,11 +6,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from orthosfm_amd import pipeline as P, synth
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+DEV = [0] * int(os.environ["SHARDS"]) if os.environ.get("SHARDS") else 0
 iset = synth.make_image_set(V, 20000, config_id=3)
-for rep in range(2):
+for rep in range(int(sys.argv[2]) if len(sys.argv) > 2 else 2):
     tm = P.Timings()
     t0 = time.perf_counter()
-    tt, info = P.match_and_build_tracks(iset, "exhaustive", 0, True, tm)
+    tt, info = P.match_and_build_tracks(iset, "exhaustive", DEV, True, tm)
     wall = time.perf_counter() - t0
     P.join_background()
     st = info.get("match_stats", {})
