@@ -188,9 +188,19 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
     win.desc = win_desc.as<WinDesc>(); win.over_list = win_over.as<int32_t>(); win.obs_lay = obs_lay.as<int32_t>();
     // camera-pair lists of the Schur complement, built on the device
     PairListsDev PL;
-    OSFM_RETURN_IF(pair_lists_build(d, pdim != 0, std::max<int64_t>(pair_bound, 1), &PL, s));
+    const int dense_policy = getenv("OSFM_BA_DENSE_SCHUR") ? atoi(getenv("OSFM_BA_DENSE_SCHUR")) : -1;     // (0 / 1: A/B runs and tests)
+    OSFM_RETURN_IF(pair_lists_build(d, pdim != 0, std::max<int64_t>(pair_bound, 1), &PL, s, dense_policy));
     const int num_pairs = PL.num_pairs;
-    sum->num_pair_entries = PL.num_entries;
+    sum->num_pair_entries = PL.dense ? PL.num_entries_all : PL.num_entries;
+    // dense visibility: the point part of the Schur complement is a product of two dense matrices (ba_dense.hip)
+    DevArray dense_z, dense_w, dense_partial;
+    bool dense_first = true;
+    if (PL.dense) {
+        const size_t zw = (size_t)schur_dense_rows(nc) * schur_dense_cols(M) * 8;
+        OSFM_RETURN_IF(dense_z.alloc(zw));
+        OSFM_RETURN_IF(dense_w.alloc(zw));
+        OSFM_RETURN_IF(dense_partial.alloc(schur_dense_partial_bytes(nc, M)));
+    }
     OSFM_HIP_CHECK(hipStreamSynchronize(s));     // (pair_lists_build has synchronised: this returns at once)
     win.num_over = *h_over;
     lap("pair lists (device)");
@@ -242,6 +252,7 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
     memset(&qa, 0, sizeof(qa));
     qa.min_diag = o.min_lm_diagonal; qa.max_diag = o.max_lm_diagonal;
     qa.num_pairs = num_pairs;
+    qa.dense = PL.dense ? 1 : 0;
     qa.pair_key = PL.unique.as<uint32_t>(); qa.pair_start = PL.starts.as<int32_t>();
     qa.entries = PL.entries.as<uint64_t>();
     qa.chunk_start = PL.chunk_start.as<int32_t>(); qa.max_chunks = PL.max_chunks; qa.chunk = PL.chunk;
@@ -323,6 +334,11 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
         launch_point_pass(d, pa, win, s);
         OSFM_RETURN_IF(toc());
         if (reset) launch_reset_system(S.as<double>(), s_elems, N, nc, N, s);
+        if (PL.dense) {
+            launch_schur_dense(d, obsrec.as<double>(), win.obs_lay, dense_z.as<double>(), dense_w.as<double>(), dense_partial.as<double>(),
+                S.as<double>(), N, dense_first, s);
+            dense_first = false;
+        }
         memset(&qa.post, 0, sizeof(qa.post));
         if (post != kPostNone && post_fused) {
             qa.post.lm = lm; qa.post.prm = prm; qa.post.sc = sc; qa.post.host_out = host_out;

@@ -31,6 +31,14 @@ struct ObsWindows {
     const int32_t *obs_lay;       // [O] cam_off | cam_ldim << 24 of the observation's camera
     int32_t num, num_over;
 };
+// ---- ba_dense.hip: the Schur complement's point part as a dense product (dense visibility) ----
+int schur_dense_rows(int nc);            // rows of Zm / Wm (nc rounded up to the tile)
+int schur_dense_cols(int M);             // their leading dimension (3 M rounded up to the K step)
+bool schur_dense_wins(int nc, int M, int64_t entries);      // cost model: the product against `entries` list entries
+size_t schur_dense_partial_bytes(int nc, int M);            // split-K partials (16 when the product is not split)
+void launch_schur_dense(const BaDev &d, const double *obsrec, const int32_t *obs_lay, double *Zm, double *Wm, double *partial,
+    double *S, int ldS, bool first, hipStream_t s);
+
 int obs_windows_count(int O);
 // desc / over_list: [num], *over_count zeroed by the caller, obs_lay: [O]
 void launch_obs_windows(const BaDev &d, int num, WinDesc *desc, int32_t *over_list, int32_t *over_count, int32_t *obs_lay,
@@ -117,6 +125,7 @@ struct PairPassArgs {
     int ldS;
     double *rhs;              // [nc]
     LmTail post;              // enabled: the last workgroup runs ba_lm_post
+    int dense;                // the lists hold the diagonal pairs only and -Z W^T is in S already (launch_schur_dense): blocks are ADDED
 };
 
 struct BackPassArgs {
@@ -163,6 +172,8 @@ struct PairListsDev {
     PooledBuffer counts, offsets, keys_in, keys, vals_in, entries, unique, runs, starts, scalars, temp;
     PooledBuffer chunk_start, chunk_pair, chunk_partials, chunk_desc, pair_ticket;
     int num_pairs = 0;
+    bool dense = false;          // the lists hold the diagonal pairs only: the rest is ba_dense.hip's product
+    int num_entries_all = 0;     // entries of the complete lists (what was counted before the choice)
     int num_entries = 0;
     int max_chunks = 0;
     int chunk = kPairChunk;
@@ -173,7 +184,8 @@ struct PairListsDev {
         for (auto *x : b) x->release();
     }
 };
-int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, PairListsDev *out, hipStream_t s);
+// dense_policy: -1 the cost model decides (schur_dense_wins), 0 never, 1 always (with points)
+int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, PairListsDev *out, hipStream_t s, int dense_policy = -1);
 
 // dense Cholesky solve of the reduced camera system (ba_cholesky.hip)
 int cholesky_padded_dim(int n);

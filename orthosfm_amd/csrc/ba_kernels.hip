@@ -531,7 +531,8 @@ ba_point_win_kernel(BaDev d, PointPassArgs a, ObsWindows w)
     block_partial<true>((double)bad, a.partials, 2, sh, b, w.num);
 }
 
-// the windows of more than 256 observations: four neighbouring lanes per track, 64 tracks at a time
+// the windows of more than 256 observations (a long track at their end, or nothing but long tracks): a WAVE per
+// track, its lanes striding over the track's observations, the track's sums by a fixed-order butterfly
 __global__ __launch_bounds__(256) void
 ba_point_over_kernel(BaDev d, PointPassArgs a, ObsWindows w)
 {
@@ -542,18 +543,16 @@ ba_point_over_kernel(BaDev d, PointPassArgs a, ObsWindows w)
     }
     const int b = w.over_list[blockIdx.x];
     const WinDesc wd = w.desc[b];
-    const int sub = threadIdx.x % kPointLanes;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double cost = 0.0, gmax = 0.0;
     int bad = 0;
-    for (int jb = wd.jf; jb < wd.jn; jb += 256 / kPointLanes) {
-        const int j = jb + (int)threadIdx.x / kPointLanes;          // a quad never straddles j < jn
-        if (j >= wd.jn) continue;
+    for (int j = wd.jf + wave; j < wd.jn; j += 4) {
         const int k0 = d.pt_start[j], k1 = d.pt_start[j + 1];
         double V[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } }, g[3] = { 0, 0, 0 };
         PointDer pd;
         point_der(d, j, d.points + 4 * j, true, pd);
         const double zero6[6] = { 0, 0, 0, 0, 0, 0 };
-        for (int k = k0 + sub; k < k1; k += kPointLanes) {
+        for (int k = k0 + lane; k < k1; k += 64) {
             ObsLin o;
             linearize_obs(d, k, d.obs_cam[k], w.obs_lay[k], d.camder, pd, o);
             cost += 0.5 * o.rho0;
@@ -566,17 +565,17 @@ ba_point_over_kernel(BaDev d, PointPassArgs a, ObsWindows w)
             }
         }
         if (!d.pdim) continue;
-        // the track's sums, identical in its four lanes from here on
+        // the track's sums, identical in all lanes from here on
         for (int x = 0; x < 3; ++x) {
-            g[x] = quad_sum(g[x]);
-            for (int y = 0; y <= x; ++y) V[x][y] = quad_sum(V[x][y]);
+            g[x] = wave_sum(g[x]);
+            for (int y = 0; y <= x; ++y) V[x][y] = wave_sum(V[x][y]);
         }
         double Vi[3][3];
-        const bool ok = point_track_finish(d, a, j, sub == 0, k1 == k0, V, g, Vi, gmax);
+        const bool ok = point_track_finish(d, a, j, lane == 0, k1 == k0, V, g, Vi, gmax);
         if (!ok) bad = 1;
         if (a.mode == kPassScaleInit) continue;
         // Q = Jp V^-1 for every observation of the track (each lane its own records)
-        for (int k = k0 + sub; k < k1; k += kPointLanes) {
+        for (int k = k0 + lane; k < k1; k += 64) {
             double2 *rec2 = reinterpret_cast<double2 *>(a.obsrec + (size_t)k * kObsRec);
             double jp[6], qv[6];
 #pragma unroll
@@ -661,7 +660,10 @@ pair_finish(const BaDev &d, const PairPassArgs &a, int c1, int c2, int n1, int n
     for (int x = 0; x < 6; ++x)
 #pragma unroll
         for (int y = 0; y < 6; ++y)
-            if (x < n1 && y < n2) a.S[(size_t)(o1 + x) * a.ldS + (o2 + y)] = acc[x][y];
+            if (x < n1 && y < n2) {
+                double *dst = a.S + (size_t)(o1 + x) * a.ldS + (o2 + y);
+                *dst = a.dense ? *dst + acc[x][y] : acc[x][y];
+            }
     if (diag_pair && a.gmax_out && a.want_gradient) {
         double dl[6];
 #pragma unroll
@@ -736,7 +738,7 @@ pair_pass_wave(const BaDev &d, const PairPassArgs &a, int2 (*ent_lds)[64], doubl
         const uint64_t ent = ent_next;
         if (eb + 64 < e1) ent_next = a.entries[min(e + 64, e1 - 1)];
         const int ka = (int)(ent >> 32), kb = (int)(ent & 0xffffffffu);
-        const bool with_b = d.pdim && a.mode != kPassScaleInit;
+        const bool with_b = d.pdim && a.mode != kPassScaleInit && !a.dense;
         ent_lds[wv][lane] = make_int2(ka, kb);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // of record a only Jc and Q (18 doubles at [kRecJc, kRecR)) -- the residual is read by the diagonal
@@ -785,7 +787,7 @@ pair_pass_wave(const BaDev &d, const PairPassArgs &a, int2 (*ent_lds)[64], doubl
                 for (int y = 0; y < 6; ++y) acc[x][y] += Ja[0][x] * Ja[0][y] + Ja[1][x] * Ja[1][y];
             }
         }
-        if (d.pdim && a.mode != kPassScaleInit) {
+        if (with_b) {
             // Z_a W_b^T = Jc_a^T (Q_a Jp_b^T) Jc_b; of record b only Jc and Jp (18 doubles)
             double M[2][2];
 #pragma unroll
@@ -1066,16 +1068,15 @@ ba_back_over_kernel(BaDev d, BackPassArgs a, ObsWindows w)
     const bool fused = a.fused != 0;
     const int b = w.over_list[blockIdx.x];
     const WinDesc wd = w.desc[b];
-    const int sub = threadIdx.x % kPointLanes;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double mcc = 0.0, sn = 0.0, xn = 0.0, ccost = 0.0;
-    for (int jb = wd.jf; jb < wd.jn; jb += 256 / kPointLanes) {
-        const int j = jb + (int)threadIdx.x / kPointLanes;
-        if (j >= wd.jn) continue;
+    // a wave per track (ba_point_over_kernel)
+    for (int j = wd.jf + wave; j < wd.jn; j += 4) {
         const int k0 = d.pt_start[j], k1 = d.pt_start[j + 1];
         double step_p[3] = { 0, 0, 0 };
         if (d.pdim) {
             double t3[3] = { 0, 0, 0 };
-            for (int k = k0 + sub; k < k1; k += kPointLanes) {
+            for (int k = k0 + lane; k < k1; k += 64) {
                 double r[kRecQ];
                 {
                     const double2 *src = reinterpret_cast<const double2 *>(a.obsrec + (size_t)k * kObsRec);
@@ -1087,11 +1088,11 @@ ba_back_over_kernel(BaDev d, BackPassArgs a, ObsWindows w)
 #pragma unroll
                 for (int t = 0; t < 3; ++t) t3[t] -= r[kRecJp + t] * u0 + r[kRecJp + 3 + t] * u1;
             }
-            for (int t = 0; t < 3; ++t) t3[t] = a.ge[3 * j + t] + quad_sum(t3[t]);
+            for (int t = 0; t < 3; ++t) t3[t] = a.ge[3 * j + t] + wave_sum(t3[t]);
             const double *Vi = a.vinv + 9 * j;
             for (int x = 0; x < 3; ++x) step_p[x] = -(Vi[3 * x] * t3[0] + Vi[3 * x + 1] * t3[1] + Vi[3 * x + 2] * t3[2]);
         }
-        for (int k = k0 + sub; k < k1; k += kPointLanes) {
+        for (int k = k0 + lane; k < k1; k += 64) {
             double r[kObsRec];
             {
                 const double2 *src = reinterpret_cast<const double2 *>(a.obsrec + (size_t)k * kObsRec);
@@ -1112,14 +1113,14 @@ ba_back_over_kernel(BaDev d, BackPassArgs a, ObsWindows w)
             double dl[3];
             for (int x = 0; x < 3; ++x) dl[x] = step_p[x] * d.scale_p[3 * j + x];
             homog_plus(P, dl, out);
-            if (sub == 0)
+            if (lane == 0)
                 for (int x = 0; x < 4; ++x) { sn += (P[x] - out[x]) * (P[x] - out[x]); xn += P[x] * P[x]; }
         }
-        if (sub == 0)
+        if (lane == 0)
             for (int x = 0; x < 4; ++x) a.points_out[4 * j + x] = out[x];
         if (fused) {
             const double pc[3] = { out[0] / out[3], out[1] / out[3], out[2] / out[3] };
-            for (int k = k0 + sub; k < k1; k += kPointLanes) ccost += 0.5 * obs_cost_at(d, k, cand, kCamDer, pc);
+            for (int k = k0 + lane; k < k1; k += 64) ccost += 0.5 * obs_cost_at(d, k, cand, kCamDer, pc);
         }
     }
     back_pass_end(a, mcc, sn, xn, ccost, b, w.num, sh, &lds_last);

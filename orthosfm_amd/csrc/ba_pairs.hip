@@ -30,7 +30,7 @@ pair_count_kernel(BaDev d, int with_points, int32_t *counts)
     const int ca = d.obs_cam[a];
     int n = 0;
     if (d.cam_ldim[ca] != 0) {
-        if (!with_points) n = 1;
+        if (with_points != 1) n = 1;             // 0: no points (no Schur term); 2: the diagonal pairs only
         else {
             const int j = d.obs_pt[a];
             const int k0 = d.pt_start[j], k1 = d.pt_start[j + 1];
@@ -62,7 +62,7 @@ pair_fill_kernel(BaDev d, int with_points, int group, const int32_t *offsets, ui
     if (d.cam_ldim[ca] == 0) return;
     int pos = offsets[a];
     int k0 = a, k1 = a + 1;
-    if (with_points) { const int j = d.obs_pt[a]; k0 = d.pt_start[j]; k1 = d.pt_start[j + 1]; }
+    if (with_points == 1) { const int j = d.obs_pt[a]; k0 = d.pt_start[j]; k1 = d.pt_start[j + 1]; }
     for (int b = k0; b < k1; ++b) {
         const int cb = d.obs_cam[b];
         if (d.cam_ldim[cb] == 0 || ca < cb) continue;
@@ -102,10 +102,10 @@ pair_chunk_fill_kernel(const int32_t *chunk_start, int num_pairs, int32_t *chunk
     }
 }
 
-int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, PairListsDev *out, hipStream_t s)
+int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, PairListsDev *out, hipStream_t s, int dense_policy)
 {
     const int M = d.O;          // the lists are generated per observation
-    out->num_pairs = 0; out->num_entries = 0;
+    out->num_pairs = 0; out->num_entries = 0; out->dense = false; out->num_entries_all = 0;
     if (M == 0 || d.M == 0) return OSFM_OK;
     // per-observation counts, offsets and the hipCUB item counts are 32-bit, and the lists take
     // about 36 bytes per entry up front: long tracks (sum of squared track lengths) are
@@ -129,7 +129,8 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
     OSFM_RETURN_IF(out->scalars.reserve(64));
 
     const int blocks = (M + 255) / 256;
-    hipLaunchKernelGGL(pair_count_kernel, dim3(blocks), dim3(256), 0, s, d, with_points ? 1 : 0,
+    int list_mode = with_points ? 1 : 0;
+    hipLaunchKernelGGL(pair_count_kernel, dim3(blocks), dim3(256), 0, s, d, list_mode,
         out->counts.as<int32_t>());
     size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     int32_t *counts = out->counts.as<int32_t>(), *offsets = out->offsets.as<int32_t>();
@@ -146,8 +147,22 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
     OSFM_HIP_CHECK(hipMemcpyAsync(&h_last[0], offsets + (M - 1), 4, hipMemcpyDeviceToHost, s));
     OSFM_HIP_CHECK(hipMemcpyAsync(&h_last[1], counts + (M - 1), 4, hipMemcpyDeviceToHost, s));
     OSFM_HIP_CHECK(hipStreamSynchronize(s));
-    const int E = h_last[0] + h_last[1];
+    int E = h_last[0] + h_last[1];
     if (E > max_entries) { set_error("pair lists: %d entries exceed the bound %lld", E, (long long)max_entries); return OSFM_E_ARG; }
+    out->num_entries_all = E;
+    // Dense visibility: the point part of the Schur complement as a product of two dense matrices (ba_dense.hip), and
+    // lists of the diagonal pairs only -- counted again, nothing of the full lists has been built yet
+    if (with_points && E > 0 && (dense_policy == 1 || (dense_policy < 0 && schur_dense_wins(d.nc, d.M, E)))) {
+        out->dense = true;
+        list_mode = 2;
+        hipLaunchKernelGGL(pair_count_kernel, dim3(blocks), dim3(256), 0, s, d, list_mode, out->counts.as<int32_t>());
+        tb = out->temp.bytes;
+        OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(out->temp.ptr, tb, counts, offsets, M, s));
+        OSFM_HIP_CHECK(hipMemcpyAsync(&h_last[0], offsets + (M - 1), 4, hipMemcpyDeviceToHost, s));
+        OSFM_HIP_CHECK(hipMemcpyAsync(&h_last[1], counts + (M - 1), 4, hipMemcpyDeviceToHost, s));
+        OSFM_HIP_CHECK(hipStreamSynchronize(s));
+        E = h_last[0] + h_last[1];
+    }
     out->num_entries = E;
     if (E == 0) return OSFM_OK;
     OSFM_RETURN_IF(out->keys_in.reserve((size_t)E * 4));
@@ -162,7 +177,7 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
     OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, t4, out->runs.as<int32_t>(), out->starts.as<int32_t>(),
         (int)max_runs, s));
     OSFM_RETURN_IF(out->temp.reserve(std::max(std::max(t1, t2), std::max(t3, t4)) + 256));
-    hipLaunchKernelGGL(pair_fill_kernel, dim3(blocks), dim3(256), 0, s, d, with_points ? 1 : 0, group, offsets, kin, vin);
+    hipLaunchKernelGGL(pair_fill_kernel, dim3(blocks), dim3(256), 0, s, d, list_mode, group, offsets, kin, vin);
     tb = out->temp.bytes;
     OSFM_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(out->temp.ptr, tb, kin, kout, vin, vout, E, 0, bits, s));
     tb = out->temp.bytes;

@@ -394,6 +394,28 @@ def test_one_launch_cholesky_equals_launch_per_column(ba, model, cams, pts):
     assert np.abs(fp1.points - fp2.points).max() <= 1e-9
 
 
+@pytest.mark.parametrize("model,cams,pts,lo,hi", [(0, 40, 900, 12, 24), (1, 150, 1200, 50, 90), (1, 30, 5000, 3, 8)])
+def test_dense_schur_product_equals_the_entry_lists(ba, model, cams, pts, lo, hi):
+    """Tracks seen by a large share of the cameras: the point part of the Schur complement as a product of two dense
+    matrices on the f64 matrix cores (ba_dense.hip: one 128 x 128 tile split over K; a 745-unknown system; a sparse
+    problem forced through it) against the camera-pair entry lists: same LM trajectory, the final cost to 1e-12."""
+    sc = synth.make_ba_scene(model, cams, pts, config_id=71, min_len=lo, max_len=hi)
+    s1, fp1 = _solve_with_env(ba, sc, {"OSFM_BA_DENSE_SCHUR": "1"})
+    s2, fp2 = _solve_with_env(ba, sc, {"OSFM_BA_DENSE_SCHUR": "0"})
+    assert (s1.num_iterations, s1.num_successful_steps, s1.num_unsuccessful_steps, s1.termination) == \
+        (s2.num_iterations, s2.num_successful_steps, s2.num_unsuccessful_steps, s2.termination)
+    assert s1.num_iterations >= 3
+    assert s1.num_pair_entries == s2.num_pair_entries
+    assert abs(s1.final_cost - s2.final_cost) <= 1e-12 * s2.final_cost
+    assert np.abs(fp1.cam_params - fp2.cam_params).max() <= 1e-10
+    assert np.abs(fp1.points - fp2.points).max() <= 1e-9
+    if cams == 150:
+        # whichever of the two the cost model takes here: the oracle's solve
+        s3, fp3 = _solve_with_env(ba, sc)
+        assert np.array_equal(fp3.cam_params, fp1.cam_params) or np.array_equal(fp3.cam_params, fp2.cam_params)
+        _compare_solve(ba, sc)
+
+
 @pytest.mark.parametrize("cams,pts", [(12, 1500), (61, 6000)])
 def test_a_cholesky_launch_given_up_is_repeated_launch_by_launch(ba, cams, pts):
     """A wait of the one-launch Cholesky that outlasts its spin limit (its workgroups were not all resident:
