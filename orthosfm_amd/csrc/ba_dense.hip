@@ -36,6 +36,7 @@ bool schur_dense_wins(int nc, int M, int64_t entries)
 {
     if (nc < 64 || M <= 0) return false;
     const double rows = schur_dense_rows(nc), cols = schur_dense_cols(M);
+    if (2.0 * rows * cols * 8.0 > 16e9) return false;          // the two matrices: at most 16 GB of the card
     const double t_sparse = 60e-12 * (double)entries;
     const double t_dense = rows * rows * cols / 30e12 + 2.0 * rows * cols * 8.0 / 3e12 + 60e-6;
     return t_dense < 0.8 * t_sparse;
