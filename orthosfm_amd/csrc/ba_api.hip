@@ -176,16 +176,19 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
     LmDev *h_state = static_cast<LmDev *>(sg.set->pinned);
     ObsWindows win;
     win.num = obs_windows_count(d.O);
-    DevArray win_desc, win_over, win_count, obs_lay;
+    DevArray win_desc, win_over, win_ok, win_count, obs_lay;
     OSFM_RETURN_IF(win_desc.alloc((size_t)win.num * sizeof(WinDesc)));
     OSFM_RETURN_IF(win_over.alloc((size_t)win.num * 4));
+    OSFM_RETURN_IF(win_ok.alloc((size_t)win.num * 4));
     OSFM_RETURN_IF(win_count.alloc(16));
     OSFM_RETURN_IF(obs_lay.alloc((size_t)std::max(d.O, 1) * 4));
     OSFM_HIP_CHECK(hipMemsetAsync(win_count.ptr, 0, 16, s));
-    launch_obs_windows(d, win.num, win_desc.as<WinDesc>(), win_over.as<int32_t>(), win_count.as<int32_t>(), obs_lay.as<int32_t>(), s);
+    launch_obs_windows(d, win.num, win_desc.as<WinDesc>(), win_over.as<int32_t>(), win_ok.as<int32_t>(), win_count.as<int32_t>(),
+        obs_lay.as<int32_t>(), s);
     int32_t *h_over = reinterpret_cast<int32_t *>(&h_state[max_slots - 1]);
     OSFM_HIP_CHECK(hipMemcpyAsync(h_over, win_count.ptr, 4, hipMemcpyDeviceToHost, s));
-    win.desc = win_desc.as<WinDesc>(); win.over_list = win_over.as<int32_t>(); win.obs_lay = obs_lay.as<int32_t>();
+    win.desc = win_desc.as<WinDesc>(); win.over_list = win_over.as<int32_t>(); win.ok_list = win_ok.as<int32_t>();
+    win.obs_lay = obs_lay.as<int32_t>();
     // camera-pair lists of the Schur complement, built on the device
     PairListsDev PL;
     const int dense_policy = getenv("OSFM_BA_DENSE_SCHUR") ? atoi(getenv("OSFM_BA_DENSE_SCHUR")) : -1;     // (0 / 1: A/B runs and tests)

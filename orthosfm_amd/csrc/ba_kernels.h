@@ -28,6 +28,8 @@ struct WinDesc { int32_t jf, jn, ka, kb; };     // tracks [jf, jn), observations
 struct ObsWindows {
     const WinDesc *desc;          // [num]
     const int32_t *over_list;     // [num_over] windows of more than 256 observations
+    const int32_t *ok_list;       // [num - num_over] the others (launching a workgroup per window that returns at once
+                                  // took 80 us where every window is of the first kind)
     const int32_t *obs_lay;       // [O] cam_off | cam_ldim << 24 of the observation's camera
     int32_t num, num_over;
 };
@@ -40,8 +42,8 @@ void launch_schur_dense(const BaDev &d, const double *obsrec, const int32_t *obs
     double *S, int ldS, bool first, hipStream_t s);
 
 int obs_windows_count(int O);
-// desc / over_list: [num], *over_count zeroed by the caller, obs_lay: [O]
-void launch_obs_windows(const BaDev &d, int num, WinDesc *desc, int32_t *over_list, int32_t *over_count, int32_t *obs_lay,
+// desc / over_list / ok_list: [num], counts[0] (over) and counts[1] (ok) zeroed by the caller, obs_lay: [O]
+void launch_obs_windows(const BaDev &d, int num, WinDesc *desc, int32_t *over_list, int32_t *ok_list, int32_t *counts, int32_t *obs_lay,
     hipStream_t s);
 
 struct PointPassArgs {

@@ -334,7 +334,7 @@ void launch_lm_post(LmDev *lm, const LmParams &prm, const LmScratch &sc, int ini
 // the four-lanes-per-track form, any length.  The window layout is the same in every iteration of a solve.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void
-ba_windows_kernel(BaDev d, int num, WinDesc *desc, int32_t *over_list, int32_t *over_count)
+ba_windows_kernel(BaDev d, int num, WinDesc *desc, int32_t *over_list, int32_t *ok_list, int32_t *counts)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= num) return;
@@ -346,7 +346,9 @@ ba_windows_kernel(BaDev d, int num, WinDesc *desc, int32_t *over_list, int32_t *
     w.ka = d.pt_start[w.jf];
     w.kb = d.pt_start[w.jn];
     desc[b] = w;
-    if (w.kb - w.ka > 256) over_list[atomicAdd(over_count, 1)] = b;
+    // (the order inside the two lists is whatever the atomics make it: a window's partials have the window's slot)
+    if (w.kb - w.ka > 256) over_list[atomicAdd(counts, 1)] = b;
+    else ok_list[atomicAdd(counts + 1, 1)] = b;
 }
 
 // obs_lay[k] = cam_off | cam_ldim << 24 of the observation's camera: one coalesced load instead of two gathers
@@ -362,10 +364,10 @@ ba_obs_lay_kernel(BaDev d, int32_t *obs_lay)
 
 int obs_windows_count(int O) { return std::max(1, (O + kWinObs - 1) / kWinObs); }
 
-void launch_obs_windows(const BaDev &d, int num, WinDesc *desc, int32_t *over_list, int32_t *over_count, int32_t *obs_lay,
+void launch_obs_windows(const BaDev &d, int num, WinDesc *desc, int32_t *over_list, int32_t *ok_list, int32_t *counts, int32_t *obs_lay,
     hipStream_t s)
 {
-    hipLaunchKernelGGL(ba_windows_kernel, dim3((num + 255) / 256), dim3(256), 0, s, d, num, desc, over_list, over_count);
+    hipLaunchKernelGGL(ba_windows_kernel, dim3((num + 255) / 256), dim3(256), 0, s, d, num, desc, over_list, ok_list, counts);
     if (d.O > 0) hipLaunchKernelGGL(ba_obs_lay_kernel, dim3((d.O + 255) / 256), dim3(256), 0, s, d, obs_lay);
 }
 
@@ -454,9 +456,8 @@ ba_point_win_kernel(BaDev d, PointPassArgs a, ObsWindows w)
         // the LM state decides what this linearisation is for
         a.radius = d.lm->radius; a.update_diag = d.lm->update_diag; a.want_gradient = d.lm->want_gradient;
     }
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = w.ok_list[blockIdx.x], tid = threadIdx.x;          // (the other windows: ba_point_over_kernel)
     const WinDesc wd = w.desc[b];
-    if (wd.kb - wd.ka > 256) return;              // ba_point_over_kernel's
     const int k = wd.ka + tid;
     const bool live = k < wd.kb;
     double cost = 0.0, gmax = 0.0;
@@ -596,7 +597,7 @@ ba_point_over_kernel(BaDev d, PointPassArgs a, ObsWindows w)
 
 void launch_point_pass(const BaDev &d, const PointPassArgs &a, const ObsWindows &w, hipStream_t s)
 {
-    hipLaunchKernelGGL(ba_point_win_kernel, dim3(w.num), dim3(256), 0, s, d, a, w);
+    if (w.num > w.num_over) hipLaunchKernelGGL(ba_point_win_kernel, dim3(w.num - w.num_over), dim3(256), 0, s, d, a, w);
     if (w.num_over > 0) hipLaunchKernelGGL(ba_point_over_kernel, dim3(w.num_over), dim3(256), 0, s, d, a, w);
 }
 
@@ -987,11 +988,10 @@ ba_back_win_kernel(BaDev d, BackPassArgs a, ObsWindows w)
     const double *cand;
     if (!back_pass_begin(d, a, cand, sh)) return;
     const bool fused = a.fused != 0;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = w.ok_list[blockIdx.x], tid = threadIdx.x;          // (the other windows: ba_back_over_kernel)
     const WinDesc wd = w.desc[b];
-    const int nobs = wd.kb - wd.ka;
     const int k = wd.ka + tid;
-    const bool live = nobs <= 256 && k < wd.kb;              // windows of more: ba_back_over_kernel's
+    const bool live = k < wd.kb;
     double mcc = 0.0, sn = 0.0, xn = 0.0, ccost = 0.0;
     int j = 0, ks = 0, ke = 0;
     double r[kObsRec], u0 = 0.0, u1 = 0.0, cd[kCamCost];
@@ -1048,13 +1048,11 @@ ba_back_win_kernel(BaDev d, BackPassArgs a, ObsWindows w)
             ccost = 0.5 * row_cost(cd, pc, xy.x, xy.y, d.huber);
         }
     }
-    if (nobs <= 256)
-        for_empty_tracks(d, wd, [&](int je) {
+    for_empty_tracks(d, wd, [&](int je) {
             // no observations: no step (ge = 0)
             const double *P = d.points + 4 * je;
             for (int x = 0; x < 4; ++x) { a.points_out[4 * je + x] = P[x]; if (d.pdim) xn += P[x] * P[x]; }
         });
-    if (nobs > 256) return;        // (then the over kernel's launch carries the decision: launch_back_pass)
     back_pass_end(a, mcc, sn, xn, ccost, b, w.num, sh, &lds_last);
 }
 
@@ -1131,7 +1129,7 @@ void launch_back_pass(const BaDev &d, const BackPassArgs &a, const ObsWindows &w
     // the decision rides in the tail of the launch that comes last
     BackPassArgs first = a;
     if (w.num_over > 0) first.decide.enabled = 0;
-    hipLaunchKernelGGL(ba_back_win_kernel, dim3(w.num), dim3(256), 0, s, d, first, w);
+    if (w.num > w.num_over) hipLaunchKernelGGL(ba_back_win_kernel, dim3(w.num - w.num_over), dim3(256), 0, s, d, first, w);
     if (w.num_over > 0) hipLaunchKernelGGL(ba_back_over_kernel, dim3(w.num_over), dim3(256), 0, s, d, a, w);
 }
 
