@@ -20,10 +20,8 @@ constexpr int kRecJp = 0, kRecJc = 6, kRecQ = 18, kRecR = 24;
 // The per-point kernels (point / back / cost pass) give every observation a lane: a workgroup of 256 threads takes
 // the tracks whose first observation lies in a window of kWinObs consecutive observations -- at most 256
 // observations unless a track runs more than 256 - kWinObs past the window's end; those windows (listed once per
-// solve) go to kernels that give every track kPointLanes lanes instead.  Their grids and their partials: one
-// workgroup / one slot per window.
+// solve) go to kernels that give every track a wave instead.  Their partials: one slot per window.
 constexpr int kWinObs = 224;
-constexpr int kPointLanes = 4;
 struct WinDesc { int32_t jf, jn, ka, kb; };     // tracks [jf, jn), observations [ka, kb)
 struct ObsWindows {
     const WinDesc *desc;          // [num]

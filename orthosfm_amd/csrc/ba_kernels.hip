@@ -81,19 +81,6 @@ __device__ __forceinline__ double wave_reduce_54(const double (&s)[54], int lane
     return (b0 ? q[1] : q[0]) + __shfl_xor(b0 ? q[0] : q[1], 1);
 }
 
-// The per-point kernels give every track kPointLanes neighbouring lanes (observation
-// k0 + lane, k0 + lane + 4, ...): one thread per track left 1.5 waves per SIMD to
-// hide a chain of dependent loads per observation.  Sums over a track are folded
-// with two xor-shuffles in a fixed order -- ((l0 + l1) + (l2 + l3)) in every lane --
-// so results stay bit-reproducible.
-static_assert(kPointLanes == 4, "quad_sum folds four lanes");
-__device__ __forceinline__ double quad_sum(double v)
-{
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    return v;
-}
-
 // per-block partial -> partials[slot * count + index] (index: the workgroup's window)
 template <bool IS_MAX, bool SC1 = false>
 __device__ __forceinline__ void block_partial(double v, double *partials, int slot, double *sh, int index, int count)

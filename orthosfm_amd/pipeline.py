@@ -433,11 +433,12 @@ def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, ti
     builder = T.TracksBuilder(sizes)
     n_batches = max(1, min(32, pf.shape[0] // 512))
     bounds = np.linspace(0, pf.shape[0], n_batches + 1).astype(np.int64)
-    if n_batches > 1 and matcher == "exhaustive":
+    if n_batches > 1 and matcher == "exhaustive" and os.environ.get("OSFM_PIPELINE_EARLY_BATCHES", "1") != "0":
         # The first batch of 32 equal ones names views up to sqrt(2 pairs / 32) -- 35 of 200 -- and the device idles
         # until they are all up (2 - 3 ms each: 0.1 s of a 2 s job).  In the reference's pair order the first
-        # v (v - 1) / 2 pairs name v views: three short batches (6, 12 and 20 views) let the matching start 15 ms in.
-        early = [v * (v - 1) // 2 for v in (6, 12, 20) if v * (v - 1) // 2 < int(bounds[1])]
+        # v (v - 1) / 2 pairs name v views: short batches (6, 12, 20, 32, 48 and 64 views, as far as they stay below
+        # the first regular one) let the matching start 15 ms in and keep it fed while the rest goes up.
+        early = [v * (v - 1) // 2 for v in (6, 12, 20, 32, 48, 64) if v * (v - 1) // 2 < int(bounds[1]) * 3 // 4]
         bounds = np.array(sorted(set([0] + early + [int(b) for b in bounds[1:]])), dtype=np.int64)
         n_batches = bounds.shape[0] - 1
     pair_cap = np.minimum(sizes[pf[:, 0]], sizes[pf[:, 1]]).astype(np.int64) if pf.shape[0] else np.zeros(0, np.int64)

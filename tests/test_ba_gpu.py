@@ -394,11 +394,13 @@ def test_one_launch_cholesky_equals_launch_per_column(ba, model, cams, pts):
     assert np.abs(fp1.points - fp2.points).max() <= 1e-9
 
 
-@pytest.mark.parametrize("model,cams,pts,lo,hi", [(0, 40, 900, 12, 24), (1, 150, 1200, 50, 90), (1, 30, 5000, 3, 8)])
+@pytest.mark.parametrize("model,cams,pts,lo,hi", [(0, 40, 900, 12, 24), (1, 150, 1200, 50, 90), (1, 30, 5000, 3, 8),
+                                                  (1, 500, 2500, 150, 250)])
 def test_dense_schur_product_equals_the_entry_lists(ba, model, cams, pts, lo, hi):
     """Tracks seen by a large share of the cameras: the point part of the Schur complement as a product of two dense
-    matrices on the f64 matrix cores (ba_dense.hip: one 128 x 128 tile split over K; a 745-unknown system; a sparse
-    problem forced through it) against the camera-pair entry lists: same LM trajectory, the final cost to 1e-12."""
+    matrices on the f64 matrix cores (ba_dense.hip: three tiles split over K; a 745-unknown system; a sparse problem
+    forced through it; the 500-view job's last global adjustments -- 2495 unknowns, 210 tiles, no split) against the
+    camera-pair entry lists: same LM trajectory, the final cost to 1e-12."""
     sc = synth.make_ba_scene(model, cams, pts, config_id=71, min_len=lo, max_len=hi)
     s1, fp1 = _solve_with_env(ba, sc, {"OSFM_BA_DENSE_SCHUR": "1"})
     s2, fp2 = _solve_with_env(ba, sc, {"OSFM_BA_DENSE_SCHUR": "0"})
