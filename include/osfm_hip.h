@@ -197,6 +197,12 @@ OSFM_API int osfm_match_set_view(osfm_matcher *m, int view,
     const uint16_t *sift, int n_sift, const int16_t *surf, int n_surf);
 OSFM_API int osfm_match_set_view_float(osfm_matcher *m, int view,
     const float *sift, int n_sift, const float *surf, int n_surf);
+/* A caller that feeds osfm_match_all in batches of growing size (a pipeline whose first batches name the few views
+ * that are up already) says how many pairs its largest call will hold: the work arrays -- 13 MB of column partials
+ * per 20 000-feature pair -- are then sized for that call by the first one, instead of being freed and allocated
+ * again at every size on the way (0.7 s of a 200-view job).  A hint: calls of any size stay valid.  0 clears it.
+ * (No reference counterpart: bundler::Matching::compute allocates per pair, bundler_matching.cc:86-160.) */
+OSFM_API int osfm_match_expect_pairs(osfm_matcher *m, int32_t pairs_per_call);
 OSFM_API int osfm_match_view_size(const osfm_matcher *m, int view,
     int *n_sift, int *n_surf);
 

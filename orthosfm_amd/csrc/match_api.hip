@@ -125,6 +125,7 @@ struct osfm_matcher {
     DeviceBuffer sp_parts, sp_col, d_spjobs;      // match_special_kernel: row results, column results, job list
     DeviceBuffer clock_probe;
     int special_max = 512;                // views with more special descriptors take the per-view operand forms
+    int expect_pairs = 0;                 // osfm_match_expect_pairs: the largest call to come (work arrays sized for it)
     DeviceBuffer d_m12_off, d_len12, d_corr_off, d_keep_pair, d_corr;
     // osfm_match_all without verification: the lists of chunk k leave the device on a copy stream while
     // chunk k + 1 is matched (two list buffers alternate)
@@ -222,6 +223,7 @@ struct BatchMode {
     bool lowres = false;      // pairwise_match_lowres: SIFT if view_1 has SIFT, else SURF
     bool apply = true;        // remove_inconsistent_matches + combine offsets
     int type_mask = 3;        // bit 0: SIFT, bit 1: SURF
+    int expect = 0;           // pairs of the largest batch to come (osfm_match_expect_pairs): the work arrays are sized for it
 };
 
 int ensure_cashash(osfm_matcher *m);
@@ -385,11 +387,16 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
     res->out_ints = out_ints;
 
     // --- scratch ---------------------------------------------------------
-    OSFM_RETURN_IF(m->out.reserve((size_t)std::max<int64_t>(out_ints, 4) * 4));
-    OSFM_RETURN_IF(m->rowparts.reserve((size_t)std::max<int64_t>(rowpart_recs, 1) * sizeof(RowPart)));
-    OSFM_RETURN_IF(m->colparts.reserve((size_t)std::max<int64_t>(colpart_recs, 1) * sizeof(ColPart)));
-    OSFM_RETURN_IF(m->keep.reserve((size_t)std::max<int64_t>(keep_bytes, 16)));
-    OSFM_RETURN_IF(m->exact_items.reserve((size_t)std::max<int64_t>(total_queries, 1) * sizeof(ExactItem)));
+    // (a smaller call than the largest the caller has announced: the arrays in proportion, once -- the parts of a
+    //  large call are bounded by batch_size_for, and so is the proportion)
+    double grow = 1.0;
+    if (mode.expect > num_pairs && num_pairs > 0) grow = 1.02 * (double)mode.expect / num_pairs;
+    auto grown = [&](int64_t n) { return (size_t)((double)std::max<int64_t>(n, 1) * std::max(grow, 1.0)); };
+    OSFM_RETURN_IF(m->out.reserve(grown(std::max<int64_t>(out_ints, 4)) * 4));
+    OSFM_RETURN_IF(m->rowparts.reserve(grown(rowpart_recs) * sizeof(RowPart)));
+    OSFM_RETURN_IF(m->colparts.reserve(grown(colpart_recs) * sizeof(ColPart)));
+    OSFM_RETURN_IF(m->keep.reserve(grown(std::max<int64_t>(keep_bytes, 16))));
+    OSFM_RETURN_IF(m->exact_items.reserve(grown(total_queries) * sizeof(ExactItem)));
     OSFM_RETURN_IF(m->exact_count.reserve(16));
     OSFM_RETURN_IF(m->sp_parts.reserve((size_t)std::max<int64_t>(sp_recs, 1) * sizeof(RowPart)));
     hipStream_t s = m->stream;
@@ -1245,6 +1252,18 @@ int osfm_match_set_view_float(osfm_matcher *m, int view, const float *sift, int 
     return osfm_match_set_view(m, view, qs.data(), n_sift, qu.data(), n_surf);
 }
 
+int osfm_match_expect_pairs(osfm_matcher *m, int32_t pairs_per_call)
+{
+    if (!m || pairs_per_call < 0) { set_error("match_expect_pairs: bad arguments"); return OSFM_E_ARG; }
+    if (!m->shards.empty()) {
+        for (auto *sh : m->shards) sh->expect_pairs = (pairs_per_call + (int)m->shards.size() - 1) / (int)m->shards.size();
+        return OSFM_OK;
+    }
+    std::lock_guard<std::mutex> lock(m->mu);
+    m->expect_pairs = pairs_per_call;
+    return OSFM_OK;
+}
+
 int osfm_match_view_size(const osfm_matcher *m, int view, int *n_sift, int *n_surf)
 {
     if (!m) { set_error("view_size: null matcher"); return OSFM_E_ARG; }
@@ -1634,7 +1653,10 @@ int match_all_single(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osf
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_chunk).count());
             };
             BatchResult res;
-            OSFM_RETURN_IF(run_batch(m, chunk.data(), n, BatchMode(), &res));
+            BatchMode full_mode;
+            // (the largest part of the largest call announced: what the work arrays are sized for from the first call on)
+            if (m->expect_pairs > 0) full_mode.expect = std::min<int>(full_batch_size((size_t)m->expect_pairs), m->expect_pairs);
+            OSFM_RETURN_IF(run_batch(m, chunk.data(), n, full_mode, &res));
             lap("matched");
             h_m12_off.assign(n, 0); h_corr_off.assign(n, 0); h_len12.assign(n, 0); h_keep.assign(n, 0);
             int64_t chunk_corr = 0;

@@ -91,6 +91,10 @@ class HipExhaustiveMatching:
             self._h, view, capi._ptr(sift, C.c_uint16), sift.shape[0],
             capi._ptr(surf, C.c_int16), surf.shape[0]))
 
+    def expect_pairs(self, pairs_per_call: int):
+        """The largest compute() call to come: the work arrays are sized for it at once (osfm_match_expect_pairs)."""
+        capi.check(capi.lib.osfm_match_expect_pairs(self._h, C.c_int32(int(pairs_per_call))))
+
     def set_positions(self, view, xy):
         """FeatureSet::positions (normalised x, y per feature) for RANSAC-F."""
         xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)

@@ -441,6 +441,7 @@ def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, ti
         early = [v * (v - 1) // 2 for v in (6, 12, 20, 32, 48, 64) if v * (v - 1) // 2 < int(bounds[1]) * 3 // 4]
         bounds = np.array(sorted(set([0] + early + [int(b) for b in bounds[1:]])), dtype=np.int64)
         n_batches = bounds.shape[0] - 1
+    m.expect_pairs(int(np.diff(bounds).max()) if n_batches > 0 else 0)      # the short first batches do not size the work arrays
     pair_cap = np.minimum(sizes[pf[:, 0]], sizes[pf[:, 1]]).astype(np.int64) if pf.shape[0] else np.zeros(0, np.int64)
     max_cap = max(int(max((pair_cap[bounds[k]:bounds[k + 1]].sum() for k in range(n_batches)), default=1)), 1)
     # The two list buffers are page-locked on a thread of their own: the first is there when the first views
