@@ -10,8 +10,10 @@
 // of kernels that select its observations from the flags (a scan over the features and a scatter), run the same
 // triangulation / reprojection / LM kernels on the compacted arrays and write flags, points and cameras back.
 // Nothing but a few counters, the cameras of a step and the LM summary crosses PCIe.  What a filter of the
-// reference removes from its list is a cleared flag here; the table is never compacted (a scan over 3.2 M feature
-// flags is ten microseconds on this device).
+// reference removes from its list is a cleared flag here.  The table is compacted when a filter has left fewer than
+// half of its tracks alive (scene_compact): every step passes over ALL features a dozen times, and after the first
+// global round ~5 % of a large job's table is alive (200 views: 3.2 M features, 500 views: 8 M).  Maps back to the
+// caller's numbering serve osfm_scene_download / osfm_scene_set_flags.
 //
 // Semantics are those of orthosfm_amd/pipeline.py's per-call form (which stays, behind use_scene = False, and is
 // what tests/test_e2e_gpu.py compares this against bit for bit): see the entry points below.
@@ -40,6 +42,11 @@ struct osfm_scene {
     std::vector<uint8_t> h_const;                         // [V][7] by camera index
     // scratch, grow-only
     DeviceBuffer cam_map, sel, scan, cnt, tflag, tslot, aux_f, aux_t, aux_t2, cub_temp, counters, tmp_hp, tmp_point;
+    // after a compaction: the caller's numbering (T0 tracks, F0 features) and where every kept track / feature was
+    int T0 = 0;
+    int64_t F0 = 0;
+    bool compacted = false;
+    DeviceBuffer orig_t, orig_f;                          // int32 [T], int32 [F] (valid when compacted)
     std::mutex mu;
 };
 
@@ -467,6 +474,91 @@ int reprojection_filter(osfm_scene *sc, int n, const int32_t *views, const doubl
     return OSFM_OK;
 }
 
+// ---- compaction: the alive features of the alive tracks, in order ----
+__global__ void scene_compact_features_kernel(int64_t F, const int32_t *__restrict__ sel, const int32_t *__restrict__ scan,
+    const int32_t *__restrict__ tslot, const int32_t *__restrict__ view, const double2 *__restrict__ xy,
+    const int32_t *__restrict__ track_of, const int32_t *__restrict__ orig_f, int32_t *__restrict__ view2,
+    double2 *__restrict__ xy2, int32_t *__restrict__ track_of2, int32_t *__restrict__ orig_f2)
+{
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F || !sel[f]) return;
+    const int nf = scan[f];
+    view2[nf] = view[f];
+    xy2[nf] = xy[f];
+    track_of2[nf] = tslot[track_of[f]];
+    orig_f2[nf] = orig_f ? orig_f[f] : (int32_t)f;
+}
+
+__global__ void scene_compact_tracks_kernel(int T, int T2, int F2, const int32_t *__restrict__ tflag, const int32_t *__restrict__ tslot,
+    const int32_t *__restrict__ offsets, const int32_t *__restrict__ scan, const uint8_t *__restrict__ has_point,
+    const double *__restrict__ point, const int32_t *__restrict__ orig_t, int32_t *__restrict__ offsets2,
+    uint8_t *__restrict__ has_point2, double *__restrict__ point2, int32_t *__restrict__ orig_t2)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) offsets2[T2] = F2;
+    if (t >= T || !tflag[t]) return;
+    const int nt = tslot[t];
+    offsets2[nt] = scan[offsets[t]];
+    has_point2[nt] = has_point[t];
+    for (int i = 0; i < 4; ++i) point2[4 * (size_t)nt + i] = point[4 * (size_t)t + i];
+    orig_t2[nt] = orig_t ? orig_t[t] : t;
+}
+
+// out[map[i]] = in[i] (bytes / 32-byte points): the compact table back into the caller's numbering
+__global__ void scene_scatter_u8_kernel(int64_t n, const int32_t *__restrict__ map, const uint8_t *__restrict__ in, uint8_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[map[i]] = in[i];
+}
+__global__ void scene_scatter_pt_kernel(int n, const int32_t *__restrict__ map, const double *__restrict__ in, double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < 4; ++k) out[4 * (size_t)map[i] + k] = in[4 * (size_t)i + k];
+}
+__global__ void scene_gather_u8_kernel(int64_t n, const int32_t *__restrict__ map, const uint8_t *__restrict__ in, uint8_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[map[i]];
+}
+
+// Drops the dead tracks and the dead features of the others (the caller has decided that it pays).
+int scene_compact(osfm_scene *sc, hipStream_t s)
+{
+    const int64_t F = sc->F;
+    const int T = sc->T;
+    int32_t *sel = sc->sel.as<int32_t>(), *scan = sc->scan.as<int32_t>(), *tflag = sc->tflag.as<int32_t>(), *tslot = sc->tslot.as<int32_t>();
+    hipLaunchKernelGGL(scene_track_flag_kernel, dim3(blocks_for(T + 1)), dim3(kThreads), 0, s, T, (int)kFlagAlive, 0, nullptr,
+        sc->alive_t.as<uint8_t>(), nullptr, tflag);
+    OSFM_RETURN_IF(exclusive_scan(sc, tflag, tslot, (int64_t)T + 1, s));
+    hipLaunchKernelGGL(scene_select_kernel, dim3(blocks_for(F + 1)), dim3(kThreads), 0, s, F, sc->feat_view.as<int32_t>(),
+        sc->track_of.as<int32_t>(), sc->alive_f.as<uint8_t>(), sc->alive_t.as<uint8_t>(), nullptr, nullptr, sel);
+    OSFM_RETURN_IF(exclusive_scan(sc, sel, scan, F + 1, s));
+    int F2 = 0, T2 = 0;
+    OSFM_RETURN_IF(read_totals2(scan, F, tslot, T, s, &F2, &T2));
+    if (T2 == T && F2 == F) return OSFM_OK;
+    if (!sc->compacted) { sc->T0 = T; sc->F0 = F; }
+    DeviceBuffer view2, xy2, tof2, off2, af2, at2, hp2, pt2, ot2, of2;
+    const size_t Fz = (size_t)std::max(F2, 1), Tz = (size_t)std::max(T2, 1);
+    OSFM_RETURN_IF(view2.reserve(Fz * 4)); OSFM_RETURN_IF(xy2.reserve(Fz * 16)); OSFM_RETURN_IF(tof2.reserve(Fz * 4));
+    OSFM_RETURN_IF(off2.reserve((Tz + 1) * 4)); OSFM_RETURN_IF(af2.reserve(Fz)); OSFM_RETURN_IF(at2.reserve(Tz));
+    OSFM_RETURN_IF(hp2.reserve(Tz)); OSFM_RETURN_IF(pt2.reserve(Tz * 32)); OSFM_RETURN_IF(ot2.reserve(Tz * 4)); OSFM_RETURN_IF(of2.reserve(Fz * 4));
+    const int32_t *orig_t = sc->compacted ? sc->orig_t.as<int32_t>() : nullptr, *orig_f = sc->compacted ? sc->orig_f.as<int32_t>() : nullptr;
+    hipLaunchKernelGGL(scene_compact_features_kernel, dim3(blocks_for(F)), dim3(kThreads), 0, s, F, sel, scan, tslot, sc->feat_view.as<int32_t>(),
+        sc->feat_xy.as<double2>(), sc->track_of.as<int32_t>(), orig_f, view2.as<int32_t>(), xy2.as<double2>(), tof2.as<int32_t>(), of2.as<int32_t>());
+    hipLaunchKernelGGL(scene_compact_tracks_kernel, dim3(blocks_for(T)), dim3(kThreads), 0, s, T, T2, F2, tflag, tslot, sc->offsets.as<int32_t>(),
+        scan, sc->has_point.as<uint8_t>(), sc->point.as<double>(), orig_t, off2.as<int32_t>(), hp2.as<uint8_t>(), pt2.as<double>(), ot2.as<int32_t>());
+    OSFM_HIP_CHECK(hipMemsetAsync(af2.ptr, 1, Fz, s));
+    OSFM_HIP_CHECK(hipMemsetAsync(at2.ptr, 1, Tz, s));
+    OSFM_HIP_CHECK(hipGetLastError());
+    OSFM_HIP_CHECK(hipStreamSynchronize(s));            // the old arrays are released below
+    sc->feat_view = std::move(view2); sc->feat_xy = std::move(xy2); sc->track_of = std::move(tof2); sc->offsets = std::move(off2);
+    sc->alive_f = std::move(af2); sc->alive_t = std::move(at2); sc->has_point = std::move(hp2); sc->point = std::move(pt2);
+    sc->orig_t = std::move(ot2); sc->orig_f = std::move(of2);
+    sc->T = T2; sc->F = F2; sc->compacted = true;
+    return OSFM_OK;
+}
+
 // the pair-list bound of a finished problem
 int pair_bound_of(osfm_scene *sc, const Compact &P, hipStream_t s, int64_t *bound)
 {
@@ -566,8 +658,29 @@ int osfm_scene_set_flags(osfm_scene *sc, const uint8_t *alive_track, const uint8
     if (!sc) { set_error("scene_set_flags: null scene"); return OSFM_E_ARG; }
     std::lock_guard<std::mutex> lock(sc->mu);
     OSFM_RETURN_IF(select_device(sc->device));
-    if (alive_track && sc->T) OSFM_HIP_CHECK(hipMemcpy(sc->alive_t.ptr, alive_track, (size_t)sc->T, hipMemcpyHostToDevice));
-    if (alive_feature && sc->F) OSFM_HIP_CHECK(hipMemcpy(sc->alive_f.ptr, alive_feature, (size_t)sc->F, hipMemcpyHostToDevice));
+    if (!sc->compacted) {
+        if (alive_track && sc->T) OSFM_HIP_CHECK(hipMemcpy(sc->alive_t.ptr, alive_track, (size_t)sc->T, hipMemcpyHostToDevice));
+        if (alive_feature && sc->F) OSFM_HIP_CHECK(hipMemcpy(sc->alive_f.ptr, alive_feature, (size_t)sc->F, hipMemcpyHostToDevice));
+        return OSFM_OK;
+    }
+    // a compacted table: the flags of what is still in it (what was dropped stays dropped)
+    StreamLease sg;
+    OSFM_RETURN_IF(sg.acquire());
+    hipStream_t s = sg.s;
+    DevArray tmp;
+    OSFM_RETURN_IF(tmp.alloc(std::max<size_t>(std::max((size_t)sc->F0, (size_t)sc->T0), 16)));
+    if (alive_track && sc->T) {
+        OSFM_HIP_CHECK(hipMemcpyAsync(tmp.ptr, alive_track, (size_t)sc->T0, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(scene_gather_u8_kernel, dim3(blocks_for(sc->T)), dim3(kThreads), 0, s, (int64_t)sc->T, sc->orig_t.as<int32_t>(),
+            tmp.as<uint8_t>(), sc->alive_t.as<uint8_t>());
+        OSFM_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    if (alive_feature && sc->F) {
+        OSFM_HIP_CHECK(hipMemcpyAsync(tmp.ptr, alive_feature, (size_t)sc->F0, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(scene_gather_u8_kernel, dim3(blocks_for(sc->F)), dim3(kThreads), 0, s, sc->F, sc->orig_f.as<int32_t>(),
+            tmp.as<uint8_t>(), sc->alive_f.as<uint8_t>());
+        OSFM_HIP_CHECK(hipStreamSynchronize(s));
+    }
     return OSFM_OK;
 }
 
@@ -798,6 +911,16 @@ int osfm_scene_filter_outliers(osfm_scene *sc, osfm_outlier_stats *stats, int32_
     for (int i = 0; i < n; ++i) if (!keep[i]) { alive[at[i]] = 0; ++killed; }
     if (killed) OSFM_HIP_CHECK(hipMemcpy(sc->alive_t.ptr, alive.data(), (size_t)T, hipMemcpyHostToDevice));
     if (num_killed) *num_killed = killed;
+    // fewer than half of a large table's tracks are left (the reprojection filter in front of this one clears flags
+    // too): drop the rest, every step passes over all features.  OSFM_SCENE_COMPACT = 0: never; 2: whenever anything is
+    // dead (tests: small sets whose tracks mostly survive)
+    const int policy = getenv("OSFM_SCENE_COMPACT") ? atoi(getenv("OSFM_SCENE_COMPACT")) : 1;
+    const bool pays = T >= 4096 && 2 * (int64_t)(n - killed) <= T;
+    if (policy == 2 || (policy == 1 && pays)) {
+        StreamLease sg;
+        OSFM_RETURN_IF(sg.acquire());
+        OSFM_RETURN_IF(scene_compact(sc, sg.s));
+    }
     return OSFM_OK;
 }
 
@@ -806,10 +929,37 @@ int osfm_scene_download(osfm_scene *sc, uint8_t *alive_track, uint8_t *alive_fea
     if (!sc) { set_error("scene_download: null scene"); return OSFM_E_ARG; }
     std::lock_guard<std::mutex> lock(sc->mu);
     OSFM_RETURN_IF(select_device(sc->device));
-    if (alive_track && sc->T) OSFM_HIP_CHECK(hipMemcpy(alive_track, sc->alive_t.ptr, (size_t)sc->T, hipMemcpyDeviceToHost));
-    if (alive_feature && sc->F) OSFM_HIP_CHECK(hipMemcpy(alive_feature, sc->alive_f.ptr, (size_t)sc->F, hipMemcpyDeviceToHost));
-    if (has_point && sc->T) OSFM_HIP_CHECK(hipMemcpy(has_point, sc->has_point.ptr, (size_t)sc->T, hipMemcpyDeviceToHost));
-    if (points && sc->T) OSFM_HIP_CHECK(hipMemcpy(points, sc->point.ptr, (size_t)sc->T * 32, hipMemcpyDeviceToHost));
+    if (!sc->compacted) {
+        if (alive_track && sc->T) OSFM_HIP_CHECK(hipMemcpy(alive_track, sc->alive_t.ptr, (size_t)sc->T, hipMemcpyDeviceToHost));
+        if (alive_feature && sc->F) OSFM_HIP_CHECK(hipMemcpy(alive_feature, sc->alive_f.ptr, (size_t)sc->F, hipMemcpyDeviceToHost));
+        if (has_point && sc->T) OSFM_HIP_CHECK(hipMemcpy(has_point, sc->has_point.ptr, (size_t)sc->T, hipMemcpyDeviceToHost));
+        if (points && sc->T) OSFM_HIP_CHECK(hipMemcpy(points, sc->point.ptr, (size_t)sc->T * 32, hipMemcpyDeviceToHost));
+        return OSFM_OK;
+    }
+    // the compacted table back into the caller's numbering: what was dropped is dead, without a point, at (0, 0, 0, 0)
+    StreamLease sg;
+    OSFM_RETURN_IF(sg.acquire());
+    hipStream_t s = sg.s;
+    DevArray tmp;
+    const size_t T0 = (size_t)sc->T0, F0 = (size_t)sc->F0;
+    OSFM_RETURN_IF(tmp.alloc(std::max<size_t>(std::max(F0, T0 * 32), 16)));
+    const int32_t *ot = sc->orig_t.as<int32_t>(), *of = sc->orig_f.as<int32_t>();
+    auto bytes_out = [&](const uint8_t *in, int64_t n, const int32_t *map, size_t n0, uint8_t *host) -> int {
+        OSFM_HIP_CHECK(hipMemsetAsync(tmp.ptr, 0, std::max<size_t>(n0, 1), s));
+        if (n) hipLaunchKernelGGL(scene_scatter_u8_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, s, n, map, in, tmp.as<uint8_t>());
+        OSFM_HIP_CHECK(hipMemcpyAsync(host, tmp.ptr, n0, hipMemcpyDeviceToHost, s));
+        OSFM_HIP_CHECK(hipStreamSynchronize(s));
+        return OSFM_OK;
+    };
+    if (alive_track && T0) OSFM_RETURN_IF(bytes_out(sc->alive_t.as<uint8_t>(), sc->T, ot, T0, alive_track));
+    if (alive_feature && F0) OSFM_RETURN_IF(bytes_out(sc->alive_f.as<uint8_t>(), sc->F, of, F0, alive_feature));
+    if (has_point && T0) OSFM_RETURN_IF(bytes_out(sc->has_point.as<uint8_t>(), sc->T, ot, T0, has_point));
+    if (points && T0) {
+        OSFM_HIP_CHECK(hipMemsetAsync(tmp.ptr, 0, T0 * 32, s));
+        if (sc->T) hipLaunchKernelGGL(scene_scatter_pt_kernel, dim3(blocks_for(sc->T)), dim3(kThreads), 0, s, sc->T, ot, sc->point.as<double>(), tmp.as<double>());
+        OSFM_HIP_CHECK(hipMemcpyAsync(points, tmp.ptr, T0 * 32, hipMemcpyDeviceToHost, s));
+        OSFM_HIP_CHECK(hipStreamSynchronize(s));
+    }
     return OSFM_OK;
 }
 

@@ -288,10 +288,16 @@ def test_scene_on_the_device_equals_the_per_call_form(iset, solver):
     from orthosfm_amd import pipeline as P
     a = P.reconstruct(iset, solver=solver, seed=11, use_scene=True, check_incremental=True)
     b = P.reconstruct(iset, solver=solver, seed=11, use_scene=False)
+    _same_reconstruction(a, b, raw_feature_flags=True)
+
+
+def _same_reconstruction(a, b, raw_feature_flags):
     assert a.aligned_views == b.aligned_views
     assert np.array_equal(a.cam_params, b.cam_params)
     ta, tb = a.tracks, b.tracks
-    assert np.array_equal(ta.alive_t, tb.alive_t) and np.array_equal(ta.alive_f, tb.alive_f)
+    assert np.array_equal(ta.alive_t, tb.alive_t)
+    if raw_feature_flags:
+        assert np.array_equal(ta.alive_f, tb.alive_f)
     assert np.array_equal(ta.live_f, tb.live_f) and np.array_equal(ta.alive_lengths(), tb.alive_lengths())
     assert np.array_equal(ta.has_point & ta.alive_t, tb.has_point & tb.alive_t)
     sel = ta.has_point & ta.alive_t
@@ -299,6 +305,23 @@ def test_scene_on_the_device_equals_the_per_call_form(iset, solver):
     ca = [(c.kind, c.cameras, c.points, c.observations, c.iterations) for c in a.ba_calls]
     cb = [(c.kind, c.cameras, c.points, c.observations, c.iterations) for c in b.ba_calls]
     assert ca == cb
+
+
+def test_compacted_scene_equals_the_per_call_form(iset, monkeypatch):
+    """When a filter has left fewer than half of a large table's tracks alive the scene drops the dead ones (every
+    step passes over all features; a 200-view job keeps ~5 % of its 3.2 M features after the first global round) and
+    answers osfm_scene_download through maps back to the caller's numbering.  Forced on this small set, whose tracks
+    mostly survive, at every outlier filter (OSFM_SCENE_COMPACT=2: repeated compactions, maps composed): cameras, live
+    flags, hasPoint() and points as in the per-call form; what was dropped comes back dead, without a point."""
+    from orthosfm_amd import pipeline as P
+    monkeypatch.setenv("OSFM_SCENE_COMPACT", "2")
+    a = P.reconstruct(iset, solver=0, seed=11, use_scene=True)
+    monkeypatch.delenv("OSFM_SCENE_COMPACT")
+    b = P.reconstruct(iset, solver=0, seed=11, use_scene=False)
+    dead = ~a.tracks.alive_t
+    assert dead.sum() > 0, "the set does not exercise the compaction"
+    _same_reconstruction(a, b, raw_feature_flags=False)
+    assert not a.tracks.has_point[dead].any() and not a.tracks.point[dead].any()
 
 
 def test_cpp_caller_of_the_scene(iset, tmp_path):
