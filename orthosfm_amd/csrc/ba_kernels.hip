@@ -1376,12 +1376,15 @@ __device__ void eig3_jacobi(double A[3][3], double V[3][3], double w[3])
 __global__ void
 ba_triangulate_kernel(BaDev d, double *points_out, uint8_t *valid)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= d.M) return;
+    // eight neighbouring lanes per track: a thread per track walked up to C observations (200 - 250 in the global
+    // adjustments of the end-to-end jobs) on 2500 threads; the eight partial sums are folded in a fixed order
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = gt >> 3, sub = gt & 7;
+    if (j >= d.M) return;                       // (an octet never straddles j < M)
     const int k0 = d.pt_start[j], k1 = d.pt_start[j + 1];
-    if (k1 - k0 < 2) { if (valid) valid[j] = 0; return; }
+    if (k1 - k0 < 2) { if (valid && sub == 0) valid[j] = 0; return; }
     double R[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } }, q[3] = { 0, 0, 0 };
-    for (int k = k0; k < k1; ++k) {
+    for (int k = k0 + sub; k < k1; k += 8) {
         double o3[3], dir[3];
         camera_ray(d, d.obs_cam[k], d.obs_xy[2 * k], d.obs_xy[2 * k + 1], o3, dir);
         const double n = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
@@ -1391,6 +1394,11 @@ ba_triangulate_kernel(BaDev d, double *points_out, uint8_t *valid)
             for (int b = 0; b < 3; ++b) { row[b] = (a == b ? 1.0 : 0.0) - dir[a] * dir[b]; R[a][b] += row[b]; }
             q[a] += row[0] * o3[0] + row[1] * o3[1] + row[2] * o3[2];
         }
+    }
+    for (int a = 0; a < 3; ++a) {
+        for (int m = 1; m < 8; m <<= 1) q[a] += __shfl_xor(q[a], m);
+        for (int b = 0; b < 3; ++b)
+            for (int m = 1; m < 8; m <<= 1) R[a][b] += __shfl_xor(R[a][b], m);
     }
     double A[3][3], V[3][3], w[3];
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) A[a][b] = R[a][b];
@@ -1403,6 +1411,7 @@ ba_triangulate_kernel(BaDev d, double *points_out, uint8_t *valid)
         const double c = (V[0][i] * q[0] + V[1][i] * q[1] + V[2][i] * q[2]) / w[i];
         x[0] += c * V[0][i]; x[1] += c * V[1][i]; x[2] += c * V[2][i];
     }
+    if (sub != 0) return;
     points_out[4 * j] = x[0]; points_out[4 * j + 1] = x[1]; points_out[4 * j + 2] = x[2]; points_out[4 * j + 3] = 1.0;
     if (valid) valid[j] = 1;
 }
@@ -1410,7 +1419,7 @@ ba_triangulate_kernel(BaDev d, double *points_out, uint8_t *valid)
 void launch_triangulate(const BaDev &d, double *points_out, uint8_t *valid, hipStream_t s)
 {
     if (d.M <= 0) return;
-    hipLaunchKernelGGL(ba_triangulate_kernel, dim3((d.M + 127) / 128), dim3(128), 0, s, d, points_out, valid);
+    hipLaunchKernelGGL(ba_triangulate_kernel, dim3((unsigned)(((int64_t)d.M * 8 + 127) / 128)), dim3(128), 0, s, d, points_out, valid);
 }
 
 }  // namespace osfm
