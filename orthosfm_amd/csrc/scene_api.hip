@@ -312,7 +312,8 @@ struct Compact {
     DeviceProblem D;
     DevArray point_track;
     int O = 0, M = 0, C = 0;
-    std::vector<int32_t> w, h;       // image sizes of the cameras: the source of copies that may still be queued
+    DevArray cam_block;              // image sizes and tangent layout of the cameras: one block, one copy
+    std::vector<int32_t> w;          // ... and its host image: the source of a copy that may still be queued
 };
 
 // sel / scan: per-feature flags and their scan; tflag: per-track point flags (T + 1 entries); point_in: start
@@ -345,14 +346,24 @@ int build_problem(osfm_scene *sc, const int32_t *sel, const int32_t *scan, int O
         scan, tflag, tslot, point_in, D.pt_start.as<int32_t>(), out->point_track.as<int32_t>(), D.points[0].as<double>());
     if (h_cams) OSFM_HIP_CHECK(hipMemcpyAsync(D.cams[0].ptr, h_cams, (size_t)C * 56, hipMemcpyHostToDevice, s));
     else if (C) OSFM_HIP_CHECK(hipMemcpyAsync(D.cams[0].ptr, d_cams, (size_t)C * 56, hipMemcpyDeviceToDevice, s));
-    std::vector<int32_t> &w = out->w, &h = out->h;
-    w.resize(C); h.resize(C);
-    for (int c = 0; c < C; ++c) { w[c] = sc->img_w[cam_views[c]]; h[c] = sc->img_h[cam_views[c]]; }
-    OSFM_RETURN_IF(upload(D.img_w, w.data(), (size_t)C, s));
-    OSFM_RETURN_IF(upload(D.img_h, h.data(), (size_t)C, s));
+    // the cameras' small tables -- image sizes, tangent layout -- in ONE block and one copy (five uploads of a few
+    // dozen bytes each were 50 us of host time per problem, two problems per local adjustment)
     build_camera_layout(sc->model, C, h_const, L);
-    OSFM_RETURN_IF(upload_camera_layout(*L, C, s, &D));
+    std::vector<int32_t> &pack = out->w;
+    const size_t Cz = (size_t)std::max(C, 1);
+    pack.assign(4 * Cz + (6 * Cz + 3) / 4, 0);
+    for (int c = 0; c < C; ++c) {
+        pack[c] = sc->img_w[cam_views[c]]; pack[Cz + c] = sc->img_h[cam_views[c]];
+        pack[2 * Cz + c] = L->cam_ldim[c]; pack[3 * Cz + c] = L->cam_off[c];
+    }
+    memcpy(reinterpret_cast<int8_t *>(pack.data() + 4 * Cz), L->colmap.data(), (size_t)6 * C);
+    OSFM_RETURN_IF(upload(out->cam_block, pack.data(), pack.size(), s));
+    OSFM_RETURN_IF(D.scale_c.alloc((size_t)L->nc * 8));
+    launch_fill(D.scale_c.as<double>(), (size_t)L->nc, 1.0, s);
     OSFM_RETURN_IF(finish_device_problem(sc->model, C, M, O, L->nc, huber, pdim, s, &D));
+    const int32_t *blk = out->cam_block.as<int32_t>();
+    D.dev.img_w = blk; D.dev.img_h = blk + Cz; D.dev.cam_ldim = blk + 2 * Cz; D.dev.cam_off = blk + 3 * Cz;
+    D.dev.cam_colmap = reinterpret_cast<const int8_t *>(blk + 4 * Cz);
     return OSFM_OK;
 }
 
