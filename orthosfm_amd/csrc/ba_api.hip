@@ -156,6 +156,8 @@ int finish_device_problem(int model, int C, int M, int O, int nc, double huber, 
     return OSFM_OK;
 }
 
+namespace { struct SubArray { void *ptr; template <typename T> T *as() const { return static_cast<T *>(ptr); } }; }    // a piece of a DevArray
+
 int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, int64_t pair_bound, osfm_ba_summary *sum, int *cur_out)
 {
     const auto t_begin = std::chrono::steady_clock::now();
@@ -211,7 +213,7 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
     const int blocksM = win.num;
     const int N = cholesky_padded_dim(std::max(nc, 1));
     DevArray Lmat;
-    DevArray obsrec, diag_c, diag_p, vinv, ge, S, Ldiag, y_c, partA, partB, partC, part_cam, gmax_cam, scalars, info;
+    DevArray obsrec, diag_c, diag_p, vinv, ge, S, Ldiag, y_c, partA, partB, partC, scalars;
     OSFM_RETURN_IF(obsrec.alloc((size_t)std::max(d.O, 1) * kObsRec * 8));
     OSFM_RETURN_IF(diag_c.alloc((size_t)nc * 8));
     OSFM_RETURN_IF(diag_p.alloc((size_t)3 * M * 8));
@@ -225,19 +227,26 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
     OSFM_RETURN_IF(partA.alloc((size_t)3 * blocksM * 8));
     OSFM_RETURN_IF(partB.alloc((size_t)3 * blocksM * 8));
     OSFM_RETURN_IF(partC.alloc((size_t)blocksM * 8));
-    OSFM_RETURN_IF(part_cam.alloc((size_t)2 * std::max(C, 1) * 8));
-    OSFM_RETURN_IF(gmax_cam.alloc((size_t)std::max(C, 1) * 8));
     OSFM_RETURN_IF(scalars.alloc(16 * 8));
-    OSFM_RETURN_IF(info.alloc(16));
+    // what has to start at zero -- the cameras' partials and gradient norms, the Cholesky's info word, the tickets of
+    // the fused tails -- is one block and one memset (four of them were 30 us of a 3-camera adjustment's set-up)
+    auto r256 = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t z_part = 0, z_gmax = z_part + r256((size_t)2 * std::max(C, 1) * 8), z_info = z_gmax + r256((size_t)std::max(C, 1) * 8),
+                 z_tick = z_info + 256, z_end = z_tick + r256(2 * lm_ticket_bytes());
+    DevArray zeros;
+    OSFM_RETURN_IF(zeros.alloc(z_end));
+    OSFM_HIP_CHECK(hipMemsetAsync(zeros.ptr, 0, z_end, s));
+    const SubArray part_cam{zeros.as<char>() + z_part}, gmax_cam{zeros.as<char>() + z_gmax}, info{zeros.as<char>() + z_info},
+              tickets{zeros.as<char>() + z_tick};
     DevArray flow_flags, flow_mailbox;        // hand-off flags of the one-launch Cholesky, zeroed once per solve
-    const bool use_flow = getenv("OSFM_BA_CHOLESKY_STEPS") == nullptr;
+    // (a system of one block never takes the one-launch form: chol_small_kernel)
+    const bool use_flow = getenv("OSFM_BA_CHOLESKY_STEPS") == nullptr && N > 32;
     if (use_flow) {
         OSFM_RETURN_IF(flow_flags.alloc((size_t)chol_flow_flag_count(std::max(nc, 1)) * 4));
         OSFM_HIP_CHECK(hipMemsetAsync(flow_flags.ptr, 0, (size_t)chol_flow_flag_count(std::max(nc, 1)) * 4, s));
         OSFM_RETURN_IF(flow_mailbox.alloc(chol_flow_mailbox_bytes(std::max(nc, 1))));
     }
     int flow_epoch = 0;
-    OSFM_HIP_CHECK(hipMemsetAsync(gmax_cam.ptr, 0, (size_t)std::max(C, 1) * 8, s));
     // the cameras' derived tables, one per iterate buffer: whoever writes cameras writes their rows
     OSFM_RETURN_IF(D.camder[0].alloc((size_t)std::max(C, 1) * kCamDer * 8));
     OSFM_RETURN_IF(D.camder[1].alloc((size_t)std::max(C, 1) * kCamDer * 8));
@@ -301,8 +310,6 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
     // decide kernel clears the system for the next linearisation
     const bool small = nc > 0 && N == 32;
     sc.reset_S = small ? S.as<double>() : nullptr; sc.reset_n = nc; sc.reset_N = N;
-    OSFM_HIP_CHECK(hipMemsetAsync(info.ptr, 0, 16, s));
-    OSFM_HIP_CHECK(hipMemsetAsync(part_cam.ptr, 0, (size_t)2 * std::max(C, 1) * 8, s));
 
     // kernel-family timing (o.verbose): event pairs per iteration, read after the loop
     std::vector<hipEvent_t> &evs = sg.set->events;
@@ -325,9 +332,6 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
     // the pair pass finalises the iteration): two launches of one workgroup less per iteration; and while the camera
     // tables with the candidates fit LDS the back pass also makes the candidate cameras and evaluates the
     // candidate's cost -- two more launches and a pass over the observations less.
-    DevArray tickets;
-    OSFM_RETURN_IF(tickets.alloc(2 * lm_ticket_bytes()));
-    OSFM_HIP_CHECK(hipMemsetAsync(tickets.ptr, 0, 2 * lm_ticket_bytes(), s));
     const bool post_fused = num_pairs > 0 && getenv("OSFM_BA_SEPARATE_POST") == nullptr;
     enum { kPostNone = 0, kPostInitial = 1, kPostLoop = 2 };
 
