@@ -9,6 +9,7 @@
 // (Host-side construction of the same lists cost ~14 ms for 3.6 M entries;
 // here it is a few launches.)
 #include <cstdlib>
+#include <vector>
 #include <hipcub/hipcub.hpp>
 
 #include "ba_kernels.h"
@@ -102,11 +103,142 @@ pair_chunk_fill_kernel(const int32_t *chunk_start, int num_pairs, int32_t *chunk
     }
 }
 
+// ---------------------------------------------------------------------------
+// A handful of cameras (the 3-camera adjustments of the incremental reconstruction: BASELINE configs[0] and every
+// group of the larger jobs).  The general build sorts the entries by camera pair -- rocPRIM's merge sort for sizes
+// like these: two dozen launches, and with the run-length encoding, its scans and two read-backs 0.19 ms of a call
+// whose LM loop takes 0.4.  With at most kSmallCams cameras there are at most 36 pairs: a thread per track flags, for
+// every pair, whether the track sees both cameras; ONE exclusive sum over the flags laid out pair-major is the
+// position of every entry in the sorted lists (pairs in key order, tracks in order inside a pair: the same lists
+// to the byte); the per-pair totals come back in one copy and the chunk descriptors are made on the host.
+// ---------------------------------------------------------------------------
+constexpr int kSmallCams = 8;
+constexpr int kSmallPairs = kSmallCams * (kSmallCams + 1) / 2;
+
+// the observation of track j in every camera (-1: none), from its at most C observations
+__device__ __forceinline__ void small_track_slots(const BaDev &d, int j, int (&slot)[kSmallCams])
+{
+#pragma unroll
+    for (int c = 0; c < kSmallCams; ++c) slot[c] = -1;
+    for (int k = d.pt_start[j]; k < d.pt_start[j + 1]; ++k) {
+        const int c = d.obs_cam[k];
+#pragma unroll
+        for (int cc = 0; cc < kSmallCams; ++cc) slot[cc] = (cc == c && d.cam_ldim[c] != 0) ? k : slot[cc];
+    }
+}
+
+// pair p of the order (c2 major, c1 >= c2 minor) -- the order of the general build's keys for C <= its group of 8
+__host__ __device__ __forceinline__ void small_pair_cameras(int p, int C, int &c1, int &c2)
+{
+    c2 = 0;
+    while (p >= C - c2) { p -= C - c2; ++c2; }
+    c1 = c2 + p;
+}
+
+__global__ __launch_bounds__(256) void
+pair_small_flags_kernel(BaDev d, int num_pairs_all, int32_t *flags)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) flags[(size_t)num_pairs_all * d.M] = 0;           // the scan's last entry is the total
+    if (j >= d.M) return;
+    int slot[kSmallCams];
+    small_track_slots(d, j, slot);
+    int p = 0;
+    for (int c2 = 0; c2 < d.C; ++c2)
+        for (int c1 = c2; c1 < d.C; ++c1, ++p) {
+            int a = -1, b = -1;
+#pragma unroll
+            for (int cc = 0; cc < kSmallCams; ++cc) { a = cc == c1 ? slot[cc] : a; b = cc == c2 ? slot[cc] : b; }
+            flags[(size_t)p * d.M + j] = (a >= 0 && b >= 0) ? 1 : 0;
+        }
+}
+
+__global__ void pair_small_totals_kernel(const int32_t *scan, int num_pairs_all, int M, int32_t *starts)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p <= num_pairs_all) starts[p] = scan[(size_t)p * M];
+}
+
+__global__ __launch_bounds__(256) void
+pair_small_fill_kernel(BaDev d, int num_pairs_all, const int32_t *flags, const int32_t *scan, uint64_t *entries)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= d.M) return;
+    int slot[kSmallCams];
+    small_track_slots(d, j, slot);
+    int p = 0;
+    for (int c2 = 0; c2 < d.C; ++c2)
+        for (int c1 = c2; c1 < d.C; ++c1, ++p) {
+            if (!flags[(size_t)p * d.M + j]) continue;
+            int a = -1, b = -1;
+#pragma unroll
+            for (int cc = 0; cc < kSmallCams; ++cc) { a = cc == c1 ? slot[cc] : a; b = cc == c2 ? slot[cc] : b; }
+            entries[scan[(size_t)p * d.M + j]] = ((uint64_t)(uint32_t)a << 32) | (uint32_t)b;
+        }
+}
+
+static int pair_lists_build_small(const BaDev &d, int64_t max_entries, PairListsDev *out, hipStream_t s)
+{
+    const int C = d.C, M = d.M, P = C * (C + 1) / 2;
+    const size_t nflag = (size_t)P * M + 1;
+    OSFM_RETURN_IF(out->counts.reserve(nflag * 4));
+    OSFM_RETURN_IF(out->offsets.reserve(nflag * 4));
+    OSFM_RETURN_IF(out->starts.reserve((size_t)(P + 1) * 4 + 16));
+    int32_t *flags = out->counts.as<int32_t>(), *scan = out->offsets.as<int32_t>();
+    hipLaunchKernelGGL(pair_small_flags_kernel, dim3((M + 255) / 256), dim3(256), 0, s, d, P, flags);
+    size_t t1 = 0;
+    OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, t1, flags, scan, (int)nflag, s));
+    OSFM_RETURN_IF(out->temp.reserve(t1 + 256));
+    size_t tb = out->temp.bytes;
+    OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(out->temp.ptr, tb, flags, scan, (int)nflag, s));
+    hipLaunchKernelGGL(pair_small_totals_kernel, dim3(1), dim3(64), 0, s, scan, P, M, out->starts.as<int32_t>());
+    int32_t h_starts[kSmallPairs + 1];
+    OSFM_HIP_CHECK(hipMemcpyAsync(h_starts, out->starts.ptr, (size_t)(P + 1) * 4, hipMemcpyDeviceToHost, s));
+    OSFM_HIP_CHECK(hipStreamSynchronize(s));
+    const int E = h_starts[P];
+    if (E > max_entries) { set_error("pair lists: %d entries exceed the bound %lld", E, (long long)max_entries); return OSFM_E_ARG; }
+    out->num_entries = E; out->num_entries_all = E;
+    if (E == 0) return OSFM_OK;
+    OSFM_RETURN_IF(out->entries.reserve((size_t)E * 8));
+    hipLaunchKernelGGL(pair_small_fill_kernel, dim3((M + 255) / 256), dim3(256), 0, s, d, P, flags, scan, out->entries.as<uint64_t>());
+    // chunk descriptors of the pairs that have entries, on the host
+    out->chunk = E < kPairChunkSmallLimit ? kPairChunkSmall : kPairChunk;
+    std::vector<PairChunkDesc> desc;
+    int np = 0;
+    for (int p = 0; p < P; ++p) {
+        const int p0 = h_starts[p], p1 = h_starts[p + 1];
+        if (p1 == p0) continue;
+        int c1, c2;
+        small_pair_cameras(p, C, c1, c2);
+        const int nch = (p1 - p0 + out->chunk - 1) / out->chunk, first = (int)desc.size();
+        for (int c = 0; c < nch; ++c) {
+            PairChunkDesc dsc;
+            dsc.pi = np; dsc.e0 = p0 + c * out->chunk; dsc.e1 = std::min(p1, dsc.e0 + out->chunk); dsc.nchunks = nch;
+            dsc.c1 = c1; dsc.c2 = c2; dsc.first = first; dsc.pad1 = 0;
+            desc.push_back(dsc);
+        }
+        ++np;
+    }
+    out->num_pairs = np;
+    out->max_chunks = (int)desc.size();
+    OSFM_RETURN_IF(out->chunk_desc.reserve((desc.size() + 4) * sizeof(PairChunkDesc)));
+    OSFM_HIP_CHECK(hipMemcpyAsync(out->chunk_desc.ptr, desc.data(), desc.size() * sizeof(PairChunkDesc), hipMemcpyHostToDevice, s));
+    OSFM_RETURN_IF(out->chunk_partials.reserve((size_t)out->max_chunks * kPairSums * sizeof(double)));
+    OSFM_RETURN_IF(out->pair_ticket.reserve((size_t)(np + 1) * 4));
+    OSFM_HIP_CHECK(hipMemsetAsync(out->pair_ticket.ptr, 0, (size_t)(np + 1) * 4, s));
+    OSFM_HIP_CHECK(hipGetLastError());
+    OSFM_HIP_CHECK(hipStreamSynchronize(s));            // desc leaves scope
+    return OSFM_OK;
+}
+
 int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, PairListsDev *out, hipStream_t s, int dense_policy)
 {
     const int M = d.O;          // the lists are generated per observation
     out->num_pairs = 0; out->num_entries = 0; out->dense = false; out->num_entries_all = 0;
     if (M == 0 || d.M == 0) return OSFM_OK;
+    const bool no_small = getenv("OSFM_BA_PAIR_LISTS_GENERAL") != nullptr;      // (A/B runs and tests)
+    if (with_points && d.C <= kSmallCams && dense_policy != 1 && !no_small && (int64_t)d.C * (d.C + 1) / 2 * d.M < (1ll << 30))
+        return pair_lists_build_small(d, max_entries, out, s);
     // per-observation counts, offsets and the hipCUB item counts are 32-bit, and the lists take
     // about 36 bytes per entry up front: long tracks (sum of squared track lengths) are
     // refused here instead of wrapping the offsets

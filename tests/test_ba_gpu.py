@@ -418,6 +418,20 @@ def test_dense_schur_product_equals_the_entry_lists(ba, model, cams, pts, lo, hi
         _compare_solve(ba, sc)
 
 
+@pytest.mark.parametrize("model,cams,pts,lo,hi", [(0, 3, 2500, 3, 3), (1, 3, 400, 2, 3), (0, 8, 3000, 2, 8), (0, 6, 50, 1, 4)])
+def test_pair_lists_of_a_handful_of_cameras_without_the_sort(ba, model, cams, pts, lo, hi):
+    """Up to eight cameras: the Schur pair lists from one scan over per-pair flags (ba_pairs.hip:
+    pair_lists_build_small) instead of the general build's sort -- the same lists, hence the same solve to the bit
+    (3-camera local adjustments with every track in every camera; tracks of two views; eight cameras; tracks of one
+    view, which have no off-diagonal entries)."""
+    sc = synth.make_ba_scene(model, cams, pts, config_id=81, min_len=lo, max_len=hi)
+    s1, fp1 = _solve_with_env(ba, sc)
+    s2, fp2 = _solve_with_env(ba, sc, {"OSFM_BA_PAIR_LISTS_GENERAL": "1"})
+    assert s1.num_pair_entries == s2.num_pair_entries and s1.num_pair_entries > 0
+    assert (s1.num_iterations, s1.termination, s1.final_cost) == (s2.num_iterations, s2.termination, s2.final_cost)
+    assert np.array_equal(fp1.cam_params, fp2.cam_params) and np.array_equal(fp1.points, fp2.points)
+
+
 @pytest.mark.parametrize("cams,pts", [(12, 1500), (61, 6000)])
 def test_a_cholesky_launch_given_up_is_repeated_launch_by_launch(ba, cams, pts):
     """A wait of the one-launch Cholesky that outlasts its spin limit (its workgroups were not all resident:
