@@ -423,6 +423,41 @@ store_record(double *obsrec, int k, const ObsLin &o, const double (&qv)[6])
     for (int i = 0; i < kObsRec / 2; ++i) dst[i] = make_double2(w[2 * i], w[2 * i + 1]);
 }
 
+// The records of a wave's 64 observations are 13 KB of consecutive memory, but a lane storing its own record makes every
+// store instruction touch 64 different cache lines (13 of them: 32 of the point pass's 83 us; the same bytes stored
+// coalesced cost 10).  So the wave turns them through LDS in two rounds -- pieces 0 .. 6, then 7 .. 12 of every record,
+// a lane writing its own and reading piece (64 i + lane) of the round's stream: consecutive lanes, consecutive 16 bytes,
+// a handful of lines per instruction.  stage: kRecStage double2 of LDS of the wave's own (one wave's LDS operations
+// execute in order: no barrier); nrec: records of the wave that exist (the others' lanes store nothing).
+constexpr int kRecStage = 64 * 7;
+__device__ __forceinline__ void
+store_records_staged(double *obsrec, int k_wave, int nrec, int lane, const ObsLin &o, const double (&qv)[6], double2 *stage)
+{
+    double w[kObsRec];
+#pragma unroll
+    for (int x = 0; x < 6; ++x) { w[kRecJc + x] = o.Jc[0][x]; w[kRecJc + 6 + x] = o.Jc[1][x]; w[kRecQ + x] = qv[x]; }
+#pragma unroll
+    for (int x = 0; x < 3; ++x) { w[kRecJp + x] = o.Jp[0][x]; w[kRecJp + 3 + x] = o.Jp[1][x]; }
+    w[kRecR] = o.r[0]; w[kRecR + 1] = o.r[1];
+    double2 *dst = reinterpret_cast<double2 *>(obsrec + (size_t)k_wave * kObsRec);
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const int np = round == 0 ? 7 : 6, p0 = round == 0 ? 0 : 7;           // pieces of this round
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            if (i < np) stage[lane * np + i] = make_double2(w[2 * (p0 + i)], w[2 * (p0 + i) + 1]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            if (i >= np) continue;
+            const int q = i * 64 + lane, rec = q / np, pc = q - rec * np;
+            const double2 v = stage[q];
+            if (rec < nrec) dst[rec * (kObsRec / 2) + p0 + pc] = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 // the tracks of a window without observations (point or back pass: lane per track)
 template <typename F>
 __device__ __forceinline__ void for_empty_tracks(const BaDev &d, const WinDesc &wd, F f)
@@ -436,7 +471,10 @@ ba_point_win_kernel(BaDev d, PointPassArgs a, ObsWindows w)
 {
     // what an observation adds to its track's sums -- Jp^T Jp (lower triangle: 6) and Jp^T r (3) -- piece i of
     // lane t at [i][t]: the lanes' 16-byte accesses are consecutive
-    __shared__ double2 obs_lds[5][256];
+    // (the same LDS serves the staged store of the records afterwards: 4 waves x kRecStage pieces)
+    __shared__ double2 lds_buf[4 * kRecStage];
+    double2 (*obs_lds)[256] = reinterpret_cast<double2 (*)[256]>(lds_buf);
+    static_assert(4 * kRecStage >= 5 * 256, "the products of 256 observations fit the staging space");
     __shared__ double sh[4];
     if (!lm_resolve(d)) return;
     if (d.lm && a.mode == kPassNormal) {
@@ -472,8 +510,8 @@ ba_point_win_kernel(BaDev d, PointPassArgs a, ObsWindows w)
         for (int i = 0; i < 5; ++i) obs_lds[i][tid] = make_double2(pr[2 * i], pr[2 * i + 1]);
     }
     __syncthreads();
+    double qv[6] = { 0, 0, 0, 0, 0, 0 };
     if (live) {
-        double qv[6] = { 0, 0, 0, 0, 0, 0 };
         if (d.pdim) {
             // the track's sums, in observation order, in every lane of the track
             double sm[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -495,14 +533,18 @@ ba_point_win_kernel(BaDev d, PointPassArgs a, ObsWindows w)
                         qv[3 * rr + t] = bad ? 0.0 : o.Jp[rr][0] * Vi[0][t] + o.Jp[rr][1] * Vi[1][t] + o.Jp[rr][2] * Vi[2][t];
             }
         }
-        store_record(a.obsrec, k, o, qv);
+    }
+    // every wave has its track sums: the LDS is free for the records (and the gradients below are in memory)
+    __syncthreads();
+    {
+        const int wave = tid >> 6, k_wave = wd.ka + wave * 64;
+        if (k_wave < wd.kb) store_records_staged(a.obsrec, k_wave, min(64, wd.kb - k_wave), tid & 63, o, qv, lds_buf + wave * kRecStage);
     }
     if (d.pdim) {
         // a lane per TRACK: the tracks without observations, and every point's share of the gradient norm (sine,
         // cosine and two roots that all four waves went through for their few first lanes) from the gradient its
-        // first lane has just stored
+        // first lane has stored
         const bool with_gmax = a.mode != kPassScaleInit && a.want_gradient;
-        if (with_gmax) __syncthreads();
         for (int je = wd.jf + tid; je < wd.jn; je += 256) {
             if (d.pt_start[je + 1] == d.pt_start[je]) {
                 double V[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } }, Vi[3][3];
@@ -984,7 +1026,8 @@ ba_back_win_kernel(BaDev d, BackPassArgs a, ObsWindows w)
     double r[kObsRec], u0 = 0.0, u1 = 0.0, cd[kCamCost];
     double2 xy = make_double2(0.0, 0.0);
     if (live) {
-        // Jc, Jp and the residual of the record, the loads issued together
+        // Jc, Jp and the residual of the record, the loads issued together (brought in stream order through LDS like
+        // the point pass stores them, the pass took 91 us instead of 87: its scattered loads are not what it waits for)
         const double2 *src = reinterpret_cast<const double2 *>(a.obsrec + (size_t)k * kObsRec);
 #pragma unroll
         for (int i = 0; i < kRecQ / 2; ++i) { const double2 v = src[i]; r[2 * i] = v.x; r[2 * i + 1] = v.y; }
