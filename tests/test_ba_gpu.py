@@ -411,6 +411,11 @@ def test_dense_schur_product_equals_the_entry_lists(ba, model, cams, pts, lo, hi
     assert abs(s1.final_cost - s2.final_cost) <= 1e-12 * s2.final_cost
     assert np.abs(fp1.cam_params - fp2.cam_params).max() <= 1e-10
     assert np.abs(fp1.points - fp2.points).max() <= 1e-9
+    if cams == 40:
+        # the product in front of the launch-per-column Cholesky (which consumes the system: cleared, product, added to)
+        s4, fp4 = _solve_with_env(ba, sc, {"OSFM_BA_DENSE_SCHUR": "1", "OSFM_BA_CHOLESKY_STEPS": "1"})
+        assert (s4.num_iterations, s4.termination) == (s1.num_iterations, s1.termination)
+        assert abs(s4.final_cost - s1.final_cost) <= 1e-12 * s1.final_cost
     if cams == 150:
         # whichever of the two the cost model takes here: the oracle's solve
         s3, fp3 = _solve_with_env(ba, sc)
