@@ -61,6 +61,7 @@ def usable_cores():
 
 
 # the CPU oracle is OpenMP code: size its team before libgomp is loaded
+_OMP_SET_BY_CALLER = "OMP_NUM_THREADS" in os.environ
 os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))
 
 I8_MFMA_PEAK_TOPS = 5000.0      # dense int8 MFMA, MI355X_MICROARCH.md (2x the 2.5 PF bf16 figure)
@@ -94,6 +95,37 @@ def parse():
     ap.add_argument("--exchange", default="shm", choices=["shm", "rccl"],
                     help="how the match lists reach rank 0 for N > 1: shared host segment (one node) or RCCL gather")
     return ap.parse_args()
+
+
+def launch_plan(argv, environ, gpus, single_process, config):
+    """What `python bench.py <argv>` does about processes, decided from the arguments and the
+    environment alone (no HIP, no torch): None = this process is the bench (N = 1, a rank that
+    torchrun started, the one-process multi-device front, the plumbing run); otherwise the
+    command of the CHILD that runs it -- one rank per GPU under `torch.distributed.run`, which
+    is how the pair loop of bundler_matching.cc:74-136 is sharded -- so that a plain
+    `python bench.py --gpus N` is the N-rank run and not N = 1 with a flag."""
+    if gpus <= 1 or single_process or config == 1:
+        return None
+    if "WORLD_SIZE" in environ or "RANK" in environ:
+        return None                     # already a rank
+    port = environ.get("MASTER_PORT") or str(29500 + (os.getpid() % 2000))
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
+
+
+def run_child(cmd):
+    """Starts the rank launcher as a child (never exec: this process may not be replaced once a
+    GPU runtime could be live), relays its output as it comes and returns its exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not _OMP_SET_BY_CALLER:
+        env.pop("OMP_NUM_THREADS", None)     # each rank sizes its own team
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
+    for ln in proc.stdout:
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def normalised_positions(iset, v):
@@ -791,6 +823,9 @@ def config1_plumbing():
 
 def main():
     args = parse()
+    plan = launch_plan(sys.argv[1:], os.environ, args.gpus, args.single_process, args.config)
+    if plan is not None:
+        raise SystemExit(run_child(plan))
     if args.config == 1:
         config1_plumbing()
         return
@@ -1089,6 +1124,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_MFMA_PEAK_TOPS,
                          "unit": "TFLOP/s", "frac": achieved / I8_MFMA_PEAK_TOPS,
                          "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_over_algorithmic": (traffic / (st.algorithmic_bytes / max(st.tile_kernel_launches, 1)))
+                                                     if traffic else None,
                          "kernel": "match_tile_kernel<8, false, true, true>", "launches_per_step": kern_launches / args.steps,
                          "avg_launch_ms": avg_launch_s * 1e3,
                          # the clock the chip held under this kernel (shader cycles over 100 MHz ticks of sampled
@@ -1107,6 +1144,8 @@ def main():
             line["multi_gpu_note"] = ("one process, osfm_match_create_multi over devices %s: the bank on every device, pairs dealt "
                                       "longest-first, no data-path exchange" % front_devices)
         if world > 1:
+            line["rccl_ranks"] = int(dist.get_world_size())
+            line["backend"] = args.backend
             line["multi_gpu_note"] = "every rank holds the full descriptor bank; no data-path collective; exchange = " + args.exchange
         if cpu_base is not None:
             line["cpu_baseline"] = cpu_base
@@ -1140,6 +1179,11 @@ def main():
                 # the second half of the metric where the driver's record keeps it: BASELINE configs[3] (200 cameras,
                 # 100k tracks) -- LM iterations/s per call (SURVEY 8d's unit: upload, pair lists and write-back included)
                 # and inside the LM loop, the HBM fraction of the iteration's algorithmic bytes, one factorisation + solve
+                # scalars beside the nested form: the driver's record keeps the scalar keys of `roofline` only
+                line["roofline"]["ba_iterations_per_s"] = ba["iterations_per_s"]
+                line["roofline"]["ba_lm_loop_iterations_per_s"] = ba["lm_loop_iterations_per_s"]
+                line["roofline"]["ba_frac"] = ba["roofline"]["frac"]
+                line["roofline"]["ba_cholesky_ms"] = ba["kernel_ms"]["cholesky"] / max(ba["iterations"], 1)
                 line["roofline"]["ba"] = {"iterations_per_s": ba["iterations_per_s"],
                                           "lm_loop_iterations_per_s": ba["lm_loop_iterations_per_s"],
                                           "frac": ba["roofline"]["frac"],
