@@ -124,6 +124,7 @@ struct osfm_matcher {
     DeviceBuffer exact_items, exact_count, stage_in, flags;
     DeviceBuffer sp_parts, sp_col, d_spjobs;      // match_special_kernel: row results, column results, job list
     DeviceBuffer clock_probe;
+    DeviceBuffer zero_tile;               // kTileCols blank descriptors: filler tiles of the correction-free tile loop
     int special_max = 512;                // views with more special descriptors take the per-view operand forms
     int expect_pairs = 0;                 // osfm_match_expect_pairs: the largest call to come (work arrays sized for it)
     DeviceBuffer d_m12_off, d_len12, d_corr_off, d_keep_pair, d_corr;
@@ -252,6 +253,31 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
     int64_t macs = 0, alg_bytes = 0, macs_surf = 0;
     int64_t cas_queries[2] = {0, 0};
 
+    // Segment length of the correction-free problems: a workgroup walks seg_cols columns for its 256 rows.
+    // Every segment costs a prologue (A fragments, two tiles), a row merge and a set of row partials, so a
+    // launch with enough row blocks to fill the chip several times over takes one segment per row block (up to
+    // kSegColsMax columns); a small launch (the per-pair entries) is cut into more, shorter ones.
+    int64_t rb_estimate = 0;
+    for (int p = 0; p < num_pairs; ++p) {
+        const int v1 = pairs[p].view_1;
+        if (v1 >= 0 && v1 < (int)m->views.size())
+            rb_estimate += (std::max(m->views[v1].ns, m->views[v1].nu) + kRowsPerBlock - 1) / kRowsPerBlock;
+    }
+    static const int forced_seg_tiles = [] { const char *e = getenv("OSFM_SEG_TILES"); return e ? atoi(e) : 0; }();
+    auto choose_seg_cols = [&](int n2) {
+        const int ncyc = (n2 + kCycleCols - 1) / kCycleCols;
+        int cyc;                                                   // cycles per segment
+        if (forced_seg_tiles > 0) cyc = std::max(1, forced_seg_tiles / 16);     // measurements (tools/seg_intercept.sh)
+        else {
+            constexpr int64_t kWantBlocks = 2048;                  // four rounds of the 512 resident workgroups
+            const int64_t want = (kWantBlocks + std::max<int64_t>(rb_estimate, 1) - 1) / std::max<int64_t>(rb_estimate, 1);
+            const int nseg = (int)std::min<int64_t>(std::max<int64_t>(want, 1), ncyc);
+            cyc = (ncyc + nseg - 1) / nseg;
+        }
+        cyc = std::min(cyc, kSegColsMax / kCycleCols);
+        return cyc * kCycleCols;
+    };
+
     for (int p = 0; p < num_pairs; ++p) {
         PairPlan &pl = res->plans[p];
         pl.v1 = pairs[p].view_1; pl.v2 = pairs[p].view_2;
@@ -338,8 +364,11 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
             if (!empty && pr.n_special > 0) any_special[type] = true;
             pr.nrb_main = empty ? 0 : (pr.n1 + kRowsPerBlock - 1) / kRowsPerBlock;
             pr.nrb = pr.nrb_main + (empty ? 0 : (pr.n_special + kRowsPerBlock - 1) / kRowsPerBlock);
-            pr.nseg = empty ? 0 : (pr.n2 + kSegCols - 1) / kSegCols;
-            pr.n2stride = round_up(pr.n2, 64);
+            // (only the RAW row blocks of a c0 problem run the correction-free kernel; its special row blocks, if
+            //  any, run the keyed kernel, whose keys hold kSegCols / 32 fragment indices: such a problem keeps kSegCols)
+            pr.seg_cols = (pr.c0 && !limited && pr.n_special == 0 && !empty) ? choose_seg_cols(pr.n2) : kSegCols;
+            pr.nseg = empty ? 0 : (pr.n2 + pr.seg_cols - 1) / pr.seg_cols;
+            pr.n2stride = round_up(pr.n2, kCycleCols);
             pr.block_start = total_blocks[type];
             if (cascade) {
                 // no score tiles: the candidate search works on the hash data of the two views
@@ -490,9 +519,13 @@ int run_batch(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, const Batc
                 probe = m->clock_probe.as<unsigned long long>();
                 probed = true;
             }
+            if (!m->zero_tile.ptr) {
+                OSFM_RETURN_IF(m->zero_tile.reserve((size_t)kTileCols * 128));
+                OSFM_HIP_CHECK(hipMemsetAsync(m->zero_tile.ptr, 0, (size_t)kTileCols * 128, s));
+            }
             launch_match_tiles(type == 0 ? 8 : 4, needs_mask[type], any_special[type], any_c0[type],
                 any_corrected[type], dp, np, total_blocks[type],
-                m->rowparts.as<RowPart>(), m->colparts.as<ColPart>(), s, probe);
+                m->rowparts.as<RowPart>(), m->colparts.as<ColPart>(), s, probe, m->zero_tile.as<int8_t>());
             if (timed[type]) OSFM_HIP_CHECK(hipEventRecord(m->ev[type][1], s));
             if (type == 0 && !(spjobs.empty() && spjobs_wide.empty())) {
                 OSFM_HIP_CHECK(hipEventRecord(m->ev_sp[0], s));

@@ -8,6 +8,8 @@ namespace osfm {
 constexpr int kRowsPerBlock = 256;     // rows of set 1 per workgroup (4 waves x 64)
 constexpr int kTileCols = 64;          // columns of set 2 per LDS tile
 constexpr int kSegCols = 8192;         // columns per workgroup (256 frag tiles -> 8 index bits)
+constexpr int kSegColsMax = 32768;     // ... of a correction-free problem (512 tiles -> 9 index bits beside 21-bit products)
+constexpr int kCycleCols = 1024;       // one cycle of the correction-free tile loop: 16 tiles
 constexpr int kKeyNone = -(1 << 30);   // "no candidate" key
 
 // One two-way matching problem: rows = descriptors of set 1, columns = set 2.
@@ -18,7 +20,8 @@ struct MatchProblem {
     const int32_t *corrB;
     int32_t n1, n2;         // true counts (already limited for low-res matching)
     int32_t nrb, nseg;      // row blocks, column segments
-    int32_t n2stride;       // n2 rounded up to 64
+    int32_t n2stride;       // n2 rounded up to 1024 (a whole cycle of the correction-free tile loop)
+    int32_t seg_cols;       // columns per segment: kSegCols, or up to kSegColsMax for correction-free problems
     int32_t block_start;    // first workgroup of this problem in the launch
     int64_t rowpart_off;    // into RowPart[]: [nseg][nrb*256]
     int64_t colpart_off;    // into ColPart[]: [nrb][n2stride]
@@ -123,7 +126,8 @@ void launch_match_special_wide(const MatchProblem *d_problems, const SpecialJob 
 void launch_match_tiles(int ch, bool masked, bool any_special, bool any_c0, bool any_corrected,
     const MatchProblem *d_problems,
     int num_problems, int total_blocks, RowPart *rowparts, ColPart *colparts, hipStream_t s,
-    unsigned long long *clock_probe = nullptr);      // [2]: shader cycles / 100 MHz ticks, added up by sampled workgroups of the C0 kernel
+    unsigned long long *clock_probe = nullptr,       // [2]: shader cycles / 100 MHz ticks, added up by sampled workgroups of the C0 kernel
+    const int8_t *zero_tile = nullptr);              // kTileCols blank descriptors (the correction-free kernel's filler tiles)
 
 void launch_match_finish(const MatchProblem *d_problems, int num_problems,
     int max_n, const RowPart *rowparts, const ColPart *colparts, const RowPart *sp_parts, const int32_t *sp_col, LoweTable tab,

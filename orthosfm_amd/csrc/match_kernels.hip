@@ -98,6 +98,7 @@ constexpr int kGroupTiles = 8;          // tiles per row-direction group (16 col
 constexpr int kPipeGroupTiles = 16;     // ... of the correction-free kernel's staggered schedule: every close
                                         // is 3 vector + 2 LDS operations in a loop where ~1 % of the time hangs
                                         // on each vector operation per tile; 8-tile groups were 12 per tile
+constexpr int kPipeTileBits = 9;        // tile bits in the correction-free kernel's group keys (segments up to 512 tiles)
 constexpr int kValNone = -(1 << 28);    // "no candidate" for un-keyed column scores
 
 template <int V> struct IntC { static constexpr int value = V; };
@@ -111,7 +112,7 @@ template <int V> struct IntC { static constexpr int value = V; };
 template <int CH, bool MASKED, bool RAW, bool C0>
 __device__ __forceinline__ void
 tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowparts,
-    ColPart *__restrict__ colparts, char *smem)
+    ColPart *__restrict__ colparts, char *smem, const int8_t *__restrict__ zero_tile)
 {
     static_assert(!C0 || RAW, "the correction-free form needs the raw row operand");
     constexpr int D = CH * 16;
@@ -123,9 +124,11 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
     constexpr int BBUF_BYTES = 2 * TILE_BYTES > 16384 ? 2 * TILE_BYTES : 16384;
     // RAW group keys: running best << 7 | first tile of the group inside the segment
     // (|ip| < 2^22 for every operand form that takes this path, so the shift is safe)
-    constexpr int kRawShift = 7;
-    constexpr int kCurNone = RAW ? -(1 << 23) : kKeyNone;   // (-2^23 << 7) == kKeyNone
-    static_assert(kSegCols / kTileCols <= (1 << kRawShift), "tile index must fit the key");
+    // The correction-free form has products below 2^21 (127^2 * 128): nine tile bits fit beside them, so one
+    // segment may span 512 tiles (the host chooses seg_cols); the forms with a correction reach 2^23 and keep seven.
+    constexpr int kRawShift = C0 ? kPipeTileBits : 7;
+    constexpr int kCurNone = RAW ? -(1 << (30 - kRawShift)) : kKeyNone;   // (kCurNone << kRawShift) == kKeyNone
+    static_assert(kSegCols / kTileCols <= (1 << 7), "tile index must fit the key");
     // The correction-free kernel folds the group closes and the column merges into
     // the MFMA-paced phases (measured: a vector op between the phases costs about
     // twice what it costs inside one); the others keep them between phases.
@@ -193,8 +196,9 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
             rsecbuf[(rf * 16 + r) * 256 + tid] = kKeyNone;
         }
 
-    const int col_begin = seg * kSegCols;
-    const int col_lim = min(n2, col_begin + kSegCols);
+    const int seg_cols = pd.seg_cols;
+    const int col_begin = seg * seg_cols;
+    const int col_lim = min(n2, col_begin + seg_cols);
     const int ntiles = (col_lim - col_begin + kTileCols - 1) / kTileCols;
 
     // --- B tile staging: LDS-DMA (global_load_lds, 16 B per lane) ------------
@@ -218,6 +222,10 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
     auto dma_wait = [&]() { if (PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     auto stage_tile = [&](int t, int buf) {
         const int8_t *src = Bbase + (size_t)(col_begin + t * kTileCols) * D;      // uniform
+        // PIPE: the tile loop runs whole cycles; the tiles behind the segment's last one are blank
+        // (zero descriptors score 0 against everything, which changes nothing: the reference's
+        // running state starts at (0, 0) and the correction-free products are >= 0)
+        if (PIPE && t >= ntiles) src = zero_tile;
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
             const int q0 = (c * 4 + wave_s) * 64;         // first chunk of this wave-instruction
@@ -370,7 +378,7 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
 
     // --- prologue: tiles 0 and 1 into LDS, fragments of tile 0, first half of tile 0
     stage_tile(0, 0);
-    stage_tile(ntiles > 1 ? 1 : 0, 1);
+    stage_tile(PIPE || ntiles > 1 ? 1 : 0, 1);
     dma_wait();
     __syncthreads();
     load_b(0, 0);
@@ -388,7 +396,7 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
     auto tile_top = [&](int t) {
         // tile t+2 into the buffer tile t was read from (clamped: the extra
         // refills of the last tile are never consumed)
-        stage_tile(min(t + 2, ntiles - 1), t & 1);
+        stage_tile(PIPE ? t + 2 : min(t + 2, ntiles - 1), t & 1);
 #pragma unroll
         for (int cf = 0; cf < 2; ++cf) {
             if (!RAW) {
@@ -488,23 +496,25 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
             phase(IntC<1>(), IntC<u>(), IntC<0>(), IntC<u>(), acc1, acc0, bn, max(tt - 15, 0), 0);
             tile_bottom(tt);
         };
-        for (; t + 16 <= ntiles; t += 16) {
+        // (whole cycles only: blank tiles fill the last one, see stage_tile -- a tail of single tiles costs 2.5x
+        //  the vector instructions per tile and a close of all slots)
+        const int tcyc = (ntiles + 15) & ~15;
+        for (; t < tcyc; t += 16) {
             cycle_tile(IntC<0>(), t); cycle_tile(IntC<1>(), t); cycle_tile(IntC<2>(), t); cycle_tile(IntC<3>(), t);
             cycle_tile(IntC<4>(), t); cycle_tile(IntC<5>(), t); cycle_tile(IntC<6>(), t); cycle_tile(IntC<7>(), t);
             cycle_tile(IntC<8>(), t); cycle_tile(IntC<9>(), t); cycle_tile(IntC<10>(), t); cycle_tile(IntC<11>(), t);
             cycle_tile(IntC<12>(), t); cycle_tile(IntC<13>(), t); cycle_tile(IntC<14>(), t); cycle_tile(IntC<15>(), t);
         }
-        if (t > 0) {
-            merge_tile(t - 4 + wave);            // the batch of the last four tiles of the last cycle
-            rcur[0][15] = kCurNone;              // closed by the last phase, never restarted
-        }
+        merge_tile(t - 4 + wave);                // the batch of the last four tiles of the last cycle
+        rcur[0][15] = kCurNone;                  // closed by the last phase, never restarted
         // the open groups of all slots (staggered starts), before the remaining tiles
         // start one common group
         const int tc = t;
         close_all([&](int rf, int r) { return max(tc - (rf ? 16 : 15) + r, 0); });
     }
-    // tiles outside whole cycles (all tiles of the kernels without the staggered schedule)
+    // all tiles of the kernels without the staggered schedule
     const int t_tail = t;
+    if (!PIPE)
     for (; t < ntiles; ++t) {
         tile_top(t);
         phase(IntC<0>(), IntC<-1>(), IntC<0>(), IntC<-1>(), acc0, acc1, (t & 1) ^ 1, 0, 0);   // reduce (rf 0, t), produce (rf 1, t), fetch B(t+1)
@@ -569,7 +579,8 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
 template <int CH, bool MASKED, bool RAW, bool C0>
 __global__ __launch_bounds__(256, 2) void
 match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, int total_blocks,
-    RowPart *__restrict__ rowparts, ColPart *__restrict__ colparts, unsigned long long *__restrict__ clock_probe)
+    RowPart *__restrict__ rowparts, ColPart *__restrict__ colparts, unsigned long long *__restrict__ clock_probe,
+    const int8_t *__restrict__ zero_tile)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lin = xcd_remap(blockIdx.x, total_blocks);
@@ -591,17 +602,17 @@ match_tile_kernel(const MatchProblem *__restrict__ problems, int num_problems, i
     // roofline.frac_at_held_clock).  Both counters are scalar reads: no vector register is spent.
     if (C0 && clock_probe != nullptr && (blockIdx.x & 1023) == 0) {
         const unsigned long long c0 = (unsigned long long)clock64(), w0 = (unsigned long long)wall_clock64();
-        tile_body<CH, MASKED, RAW, C0>(pd, rb, seg, rowparts, colparts, smem);
+        tile_body<CH, MASKED, RAW, C0>(pd, rb, seg, rowparts, colparts, smem, zero_tile);
         const unsigned long long c1 = (unsigned long long)clock64(), w1 = (unsigned long long)wall_clock64();
         if (threadIdx.x == 0) { atomicAdd(clock_probe, c1 - c0); atomicAdd(clock_probe + 1, w1 - w0); }
         return;
     }
-    tile_body<CH, MASKED, RAW, C0>(pd, rb, seg, rowparts, colparts, smem);
+    tile_body<CH, MASKED, RAW, C0>(pd, rb, seg, rowparts, colparts, smem, zero_tile);
 }
 
 void launch_match_tiles(int ch, bool masked, bool any_special, bool any_c0, bool any_corrected,
     const MatchProblem *d_problems, int num_problems, int total_blocks, RowPart *rowparts,
-    ColPart *colparts, hipStream_t s, unsigned long long *clock_probe)
+    ColPart *colparts, hipStream_t s, unsigned long long *clock_probe, const int8_t *zero_tile)
 {
     if (total_blocks <= 0) return;
     const int d = ch * 16;
@@ -609,7 +620,7 @@ void launch_match_tiles(int ch, bool masked, bool any_special, bool any_c0, bool
     const dim3 grid(total_blocks), block(256);
 #define OSFM_LAUNCH_TILES(CHV, MASKEDV, RAWV, C0V) \
     for (unsigned long long *PROBE = ((C0V) ? clock_probe : nullptr), *once_ = (unsigned long long *)1; once_; once_ = nullptr) \
-    hipLaunchKernelGGL((match_tile_kernel<CHV, MASKEDV, RAWV, C0V>), grid, block, lds, s, d_problems, num_problems, total_blocks, rowparts, colparts, PROBE)
+    hipLaunchKernelGGL((match_tile_kernel<CHV, MASKEDV, RAWV, C0V>), grid, block, lds, s, d_problems, num_problems, total_blocks, rowparts, colparts, PROBE, zero_tile)
     if (masked) {
         if (ch == 8) OSFM_LAUNCH_TILES(8, true, false, false); else OSFM_LAUNCH_TILES(4, true, false, false);
         return;
