@@ -533,41 +533,69 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
     }
 
     // --- row direction: merge the 32 lanes that hold the same row -------------
-    // Through LDS (the tile buffers are free now): each of 32 threads per wave
-    // walks the 32 source lanes of one row.  (ip, column) composites keep
-    // "later column wins" across lanes.  RAW keys carry the tile group only:
-    // the column reported is the first one of the winning (lane, group) stream.
+    // Transposed through LDS (tile buffers and column ring are free now, 32 KB with the ring's neighbours):
+    // every lane takes ONE of the wave's 64 rows and reads the 32 (best key, second key) entries its
+    // source lanes hold for it, 8 + 8 ds_read_b128.  Lane L <-> (fragment L >> 5, half-wave (L >> 4) & 1,
+    // register L & 15); the 16-byte pieces are read rotated by the register number, which keeps every
+    // 16-lane service group of ds_read_b128 on distinct banks.  Key order is (inner product, tile) and
+    // the column is tile-major, so among equal keys the larger source lane is the later column.
+    // RAW keys carry the tile group only: the column reported is the first one of the winning
+    // (lane, group) stream.
     RowPart *rp = rowparts + pd.rowpart_off + (int64_t)seg * ((int64_t)pd.nrb * kRowsPerBlock);
-    int *bb = reinterpret_cast<int *>(bbuf);                        // [16][256]
+    int *bb = reinterpret_cast<int *>(smem);                        // [32][256], over bbuf / corrbuf / colbuf
+    static_assert(BBUF_BYTES + 2 * 64 * 4 + 8 * 4 * 64 * 8 >= 32 * 256 * 4, "the best keys of both fragments must fit in front of rsecbuf");
+    __syncthreads();
 #pragma unroll
-    for (int rf = 0; rf < 2; ++rf) {
-        __syncthreads();
+    for (int rf = 0; rf < 2; ++rf)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bb[r * 256 + tid] = rbest[rf][r];
-        __syncthreads();
-        if (lane < 32) {
-            const int r = lane & 15, h = lane >> 4;
-            int bip = INT_MIN, bcol = 0, sec = INT_MIN;
-            for (int i = 0; i < 32; ++i) {
-                const int l = (i + r) & 31;                          // skewed: bank-conflict free
-                const int src = wave * 64 + h * 32 + l;
-                const int kbest = bb[r * 256 + src];
-                const int ksec = rsecbuf[(rf * 16 + r) * 256 + src];
-                if (ksec != kKeyNone) sec = max(sec, RAW ? (ksec >> kRawShift) : (ksec >> 8));
-                if (kbest == kKeyNone) continue;
-                const int ip = RAW ? (kbest >> kRawShift) : (kbest >> 8);
-                const int col = RAW ? col_begin + (kbest & ((1 << kRawShift) - 1)) * kTileCols + l
-                                    : col_begin + (kbest & 255) * 32 + l;
-                if (ip > bip || (ip == bip && col > bcol)) { sec = max(sec, bip); bip = ip; bcol = col; }
-                else sec = max(sec, ip);
-            }
-            const int row = row0 + rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            RowPart out;
-            // pad = 1: idx_best is the first column of the winning (lane, group) stream,
-            // the group being the eight tiles from there; 0: the exact best column
-            out.ip_best = bip; out.idx_best = bcol; out.ip_second = sec; out.pad = RAW ? 1 : 0;
-            rp[row] = out;
+        for (int r = 0; r < 16; ++r) bb[(rf * 16 + r) * 256 + tid] = rbest[rf][r];
+    __syncthreads();
+    {
+        constexpr int SH = RAW ? kRawShift : 8;
+        const int r = lane & 15, h = (lane >> 4) & 1, rf = lane >> 5;
+        const int base = (rf * 16 + r) * 256 + wave * 64 + h * 32;
+        v4i kb[8], ks[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int jj = (j + r) & 7;
+            kb[j] = *reinterpret_cast<const v4i *>(bb + base + jj * 4);
+            ks[j] = *reinterpret_cast<const v4i *>(rsecbuf + base + jj * 4);
         }
+        // (best, second) over the 32 best keys -- med3 keeps a duplicate of the best as second --
+        // and the largest of the 32 second keys
+        int b1 = kKeyNone, b2 = kKeyNone, smax = kKeyNone;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                b2 = med3a(b1, b2, kb[j][e]);
+                b1 = max(b1, kb[j][e]);
+            }
+#pragma unroll
+        for (int j = 0; j < 8; j += 2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) smax = max3i(smax, ks[j][e], ks[j + 1][e]);
+        // the source lane of the best key, the largest one among equals: a bit per slot (slot 4j + e
+        // holds source lane (4j + e + 4r) & 31), rotated into lane order, highest set bit
+        unsigned hit = 0;
+#pragma unroll
+        for (int j = 7; j >= 0; --j)
+#pragma unroll
+            for (int e = 3; e >= 0; --e) hit = (hit << 1) | (kb[j][e] == b1 ? 1u : 0u);
+        const unsigned rot = __builtin_amdgcn_alignbit(hit, hit, (32 - 4 * r) & 31);      // rotate left by 4r
+        const int bl = 31 - __builtin_clz(rot | 1u);
+        const int sk = max(b2, smax);
+        const int row = row0 + rf * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        RowPart out;
+        out.ip_best = b1 == kKeyNone ? INT_MIN : (b1 >> SH);
+        out.ip_second = sk == kKeyNone ? INT_MIN : (sk >> SH);
+        // pad = 1: idx_best is the first column of the winning (lane, group) stream,
+        // the group being the tiles from there; 0: the exact best column
+        out.idx_best = b1 == kKeyNone ? 0
+                     : RAW ? col_begin + (b1 & ((1 << kRawShift) - 1)) * kTileCols + bl
+                           : col_begin + (b1 & 255) * 32 + bl;
+        out.pad = RAW ? 1 : 0;
+        rp[row] = out;
     }
 }
 
