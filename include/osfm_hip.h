@@ -35,6 +35,12 @@ typedef enum osfm_status {
 } osfm_status;
 
 OSFM_API const char *osfm_last_error(void);
+/* ABI version: OSFM_ABI_VERSION of the header the library was built from.  The library writes its public structs
+ * (osfm_match_stats, osfm_ba_summary, ...) in full, so a caller built against another header must not run: the
+ * adapters (the headers under orthosfm_amd/host) and the Python mirror compare this with their own OSFM_ABI_VERSION at load time.
+ * 100: rounds 1-3; 101: osfm_ba_summary.flow_fallbacks, osfm_match_stats.surf_*; 102: one observation per camera
+ * and point enforced, osfm_scene_set_cameras. */
+#define OSFM_ABI_VERSION 102
 OSFM_API int osfm_version(void);
 /* Number of visible HIP devices (0 when there is none). */
 OSFM_API int osfm_device_count(void);
@@ -363,7 +369,10 @@ enum {
  * points: num_points x 4 homogeneous (Track::m_point, track.h:103), in/out.
  * obs_*: one entry per residual block in the order of
  *   bundle_adjustment.cpp:103-123; obs_point MUST be non-decreasing
- *   (observations of a track are contiguous).
+ *   (observations of a track are contiguous) and a point is observed AT MOST
+ *   ONCE per camera (the reference's tracks hold one feature per view: a
+ *   track with two is a conflict and dropped, bundler_tracks.cc:120-145) --
+ *   a repeated (camera, point) is refused with OSFM_E_ARG.
  */
 typedef struct osfm_ba_problem {
     int32_t model;
@@ -502,15 +511,22 @@ typedef struct osfm_scene osfm_scene;
 
 /* track_offsets [num_tracks + 1] (features of track t: [offsets[t], offsets[t+1])), feat_view / feat_xy per feature
  * (Feature::viewID and the float pixel position Feature::x / y, track.h:26-27), image size per view.  Every flag
- * starts alive, no track has a point, no view has a camera. */
+ * starts alive, no track has a point, no view has a camera.  A track holds at most one feature per view (OSFM_E_ARG
+ * otherwise; bundler_tracks.cc:120-145 drops such tracks). */
 OSFM_API int osfm_scene_create(int device, int model, int num_views, const int32_t *img_width, const int32_t *img_height,
     int32_t num_tracks, const int64_t *track_offsets, const int32_t *feat_view, const float *feat_xy, osfm_scene **out);
 OSFM_API int osfm_scene_destroy(osfm_scene *s);
-/* alive flags from the caller's table (either may be NULL: unchanged) */
+/* alive flags from the caller's table (either may be NULL: unchanged).  Once the scene has dropped dead entries
+ * (it compacts its table when enough have died) a flag that would set one of THOSE alive is refused with
+ * OSFM_E_STATE and nothing changes: clearing flags always works. */
 OSFM_API int osfm_scene_set_flags(osfm_scene *s, const uint8_t *alive_track, const uint8_t *alive_feature);
 /* mergeIntoGlobal (reconstruct.cpp:236-247): the views get cameras (params [n][7], const masks [n][7] as in
  * osfm_ba_problem), appended to the aligned cameras in this order.  OSFM_E_STATE when a view has one already. */
 OSFM_API int osfm_scene_align_views(osfm_scene *s, int n, const int32_t *views, const double *params, const uint8_t *cam_const);
+/* Replaces the parameters (params [n][7]) of views that ARE aligned -- a caller's own change to alignedCameras, e.g.
+ * normalizeScene when camera 0 is not the identity -- so that the device copy follows; OSFM_E_STATE for a view without
+ * a camera.  The next osfm_scene_triangulate redoes every track, whatever new_views says. */
+OSFM_API int osfm_scene_set_cameras(osfm_scene *s, int n, const int32_t *views, const double *params);
 /* the aligned cameras in the order they joined (views / params may be NULL) */
 OSFM_API int osfm_scene_get_cameras(osfm_scene *s, int capacity, int32_t *views, double *params, int32_t *num_cameras);
 /* algorithm->triangulateTracks(alignedCameras, tracks, true) (triangulation.cpp:44-93): every alive track with two or

@@ -133,7 +133,7 @@ EXPORTS = [
     "osfm_ba_options_default", "osfm_ba_solve", "osfm_ba_reprojection_errors",
     "osfm_ba_triangulate",
     "osfm_nn_distances", "osfm_filter_outlier_tracks", "osfm_filter_reprojection",
-    "osfm_scene_create", "osfm_scene_destroy", "osfm_scene_set_flags", "osfm_scene_align_views", "osfm_scene_get_cameras",
+    "osfm_scene_create", "osfm_scene_destroy", "osfm_scene_set_flags", "osfm_scene_align_views", "osfm_scene_set_cameras", "osfm_scene_get_cameras",
     "osfm_scene_triangulate", "osfm_scene_filter_reprojection", "osfm_scene_local_adjustment", "osfm_scene_global_adjustment",
     "osfm_scene_filter_outliers", "osfm_scene_download",
     "osfm_tracks_compute", "osfm_tracks_compute_ranges", "osfm_build_groups",
@@ -151,6 +151,11 @@ TRACK_FEATURE = np.dtype([("view_id", "<u4"), ("local_feature_id", "<u4"), ("glo
 
 lib.osfm_last_error.restype = C.c_char_p
 lib.osfm_version.restype = C.c_int
+# include/osfm_hip.h OSFM_ABI_VERSION: the structs below mirror THAT header, and the library writes them in full
+ABI_VERSION = 102
+if lib.osfm_version() != ABI_VERSION and os.environ.get("OSFM_ALLOW_ABI_MISMATCH") != "1":
+    raise ImportError(f"libosfm_hip.so reports ABI version {lib.osfm_version()}, orthosfm_amd/capi.py mirrors {ABI_VERSION} "
+                      "(rebuild: make -C orthosfm_amd/csrc; experiments with an older build: OSFM_ALLOW_ABI_MISMATCH=1)")
 lib.osfm_device_count.restype = C.c_int
 
 

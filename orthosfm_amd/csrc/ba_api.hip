@@ -35,6 +35,10 @@ int validate_problem(const osfm_ba_problem *p, const char *what)
         set_error("%s: null array", what); return OSFM_E_ARG;
     }
     int prev = 0;
+    // A point is observed at most once per camera: the reference's tracks hold one feature per view (a track
+    // with two is a conflict and dropped, bundler_tracks.cc:120-145), and the Schur-complement fast paths
+    // (one slot per camera and track, ba_pairs.hip; the dense product, ba_dense.hip) rest on it.
+    std::vector<int> seen_in((size_t)p->num_cameras, -1);
     for (int k = 0; k < p->num_observations; ++k) {
         const int c = p->obs_camera[k], j = p->obs_point[k];
         if (c < 0 || c >= p->num_cameras || j < 0 || j >= p->num_points) {
@@ -45,6 +49,11 @@ int validate_problem(const osfm_ba_problem *p, const char *what)
             set_error("%s: obs_point must be non-decreasing (observation %d)", what, k);
             return OSFM_E_ARG;
         }
+        if (seen_in[c] == j) {
+            set_error("%s: point %d is observed twice by camera %d (observation %d); one observation per camera and point", what, j, c, k);
+            return OSFM_E_ARG;
+        }
+        seen_in[c] = j;
         prev = j;
     }
     return OSFM_OK;
@@ -291,7 +300,9 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
     init.radius = o.initial_trust_region_radius; init.decrease_factor = 2.0;
     init.update_diag = 1; init.want_gradient = 1; init.term = OSFM_BA_NO_CONVERGENCE;
     LmDev *lm = lmdev.as<LmDev>();
-    OSFM_RETURN_IF(sg.set->ensure_events((size_t)max_slots + (o.verbose ? 8 * (size_t)max_slots : 0)));
+    // verbose: up to 8 timing events per iteration slot, plus what a given-up Cholesky launch adds (one more
+    // linearisation and up to two iterations repeated launch by launch: 20 events) -- three slots of slack
+    OSFM_RETURN_IF(sg.set->ensure_events((size_t)max_slots + (o.verbose ? 8 * ((size_t)max_slots + 3) : 0)));
     memcpy(&h_state[0], &init, sizeof(init));
     OSFM_HIP_CHECK(hipMemcpyAsync(lm, &h_state[0], sizeof(LmDev), hipMemcpyHostToDevice, s));
     d.cams2[0] = D.cams[0].as<double>(); d.cams2[1] = D.cams[1].as<double>();
@@ -316,13 +327,13 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
     size_t ev_next = (size_t)max_slots;
     std::vector<std::pair<size_t, int>> ev_pairs;     // (first event of the pair, family)
     auto tic = [&](int family) -> int {
-        if (!o.verbose) return OSFM_OK;
+        if (!o.verbose || ev_next + 1 >= evs.size()) return OSFM_OK;      // out of events: the span goes untimed
         OSFM_HIP_CHECK(hipEventRecord(evs[ev_next], s));
         ev_pairs.push_back({ev_next, family});
         return OSFM_OK;
     };
     auto toc = [&]() -> int {
-        if (!o.verbose) return OSFM_OK;
+        if (!o.verbose || ev_next + 1 >= evs.size()) return OSFM_OK;
         OSFM_HIP_CHECK(hipEventRecord(evs[ev_next + 1], s));
         ev_next += 2;
         return OSFM_OK;

@@ -1031,7 +1031,7 @@ int multi_match_all(osfm_matcher *m, const osfm_pair *pairs, int num_pairs, osfm
 extern "C" {
 
 const char *osfm_last_error(void) { return g_last_error.c_str(); }
-int osfm_version(void) { return 100; }
+int osfm_version(void) { return OSFM_ABI_VERSION; }
 
 int osfm_device_count(void)
 {

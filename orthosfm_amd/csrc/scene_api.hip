@@ -46,6 +46,7 @@ struct osfm_scene {
     int T0 = 0;
     int64_t F0 = 0;
     bool compacted = false;
+    bool cams_moved = false;                              // osfm_scene_set_cameras since the last full triangulation
     DeviceBuffer orig_t, orig_f;                          // int32 [T], int32 [F] (valid when compacted)
     std::mutex mu;
 };
@@ -546,6 +547,15 @@ __global__ void scene_gather_u8_kernel(int64_t n, const int32_t *__restrict__ ma
     if (i < n) out[i] = in[map[i]];
 }
 
+// how many of the entries a compacted table still holds are alive in the caller's (uncompacted) flags
+__global__ void scene_count_mapped_u8_kernel(int64_t n, const int32_t *__restrict__ map, const uint8_t *__restrict__ in, int32_t *__restrict__ count)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool on = i < n && in[map[i]] != 0;
+    const unsigned long long b = __ballot(on);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (int32_t)__popcll(b));
+}
+
 // Drops the dead tracks and the dead features of the others (the caller has decided that it pays).
 int scene_compact(osfm_scene *sc, hipStream_t s)
 {
@@ -617,6 +627,19 @@ int osfm_scene_create(int device, int model, int num_views, const int32_t *img_w
         if (track_offsets[t + 1] < track_offsets[t]) { set_error("scene_create: track_offsets must be non-decreasing"); return OSFM_E_ARG; }
     for (int64_t f = 0; f < F; ++f)
         if (feat_view[f] < 0 || feat_view[f] >= num_views) { set_error("scene_create: feature %lld names view %d", (long long)f, feat_view[f]); return OSFM_E_ARG; }
+    {
+        // one feature per view and track (bundler_tracks.cc:120-145 drops tracks with two): the adjustments'
+        // pair lists and the analytic size bounds of the scene rest on it
+        std::vector<int32_t> seen_in((size_t)num_views, -1);
+        for (int t = 0; t < num_tracks; ++t)
+            for (int64_t f = track_offsets[t]; f < track_offsets[t + 1]; ++f) {
+                if (seen_in[feat_view[f]] == t) {
+                    set_error("scene_create: track %d holds two features of view %d; one feature per view and track", t, feat_view[f]);
+                    return OSFM_E_ARG;
+                }
+                seen_in[feat_view[f]] = t;
+            }
+    }
     OSFM_RETURN_IF(select_device(device));
     struct Owner { osfm_scene *p; ~Owner() { delete p; } } owner{new osfm_scene()};
     osfm_scene *sc = owner.p;
@@ -694,6 +717,30 @@ int osfm_scene_set_flags(osfm_scene *sc, const uint8_t *alive_track, const uint8
     hipStream_t s = sg.s;
     DevArray tmp;
     OSFM_RETURN_IF(tmp.alloc(std::max<size_t>(std::max((size_t)sc->F0, (size_t)sc->T0), 16)));
+    // A flag set for an entry the compaction dropped cannot be honoured (its data is gone): refuse the call
+    // before anything changes instead of leaving the caller's table and the scene's apart.
+    for (int kind = 0; kind < 2; ++kind) {
+        const uint8_t *flags = kind == 0 ? alive_track : alive_feature;
+        const int64_t n0 = kind == 0 ? (int64_t)sc->T0 : sc->F0, n = kind == 0 ? (int64_t)sc->T : sc->F;
+        if (!flags || n0 == 0) continue;
+        int64_t want = 0;
+        for (int64_t i = 0; i < n0; ++i) want += flags[i] != 0;
+        int32_t have = 0;
+        int32_t *c = sc->counters.as<int32_t>();
+        OSFM_HIP_CHECK(hipMemsetAsync(c, 0, 4, s));
+        if (n) {
+            OSFM_HIP_CHECK(hipMemcpyAsync(tmp.ptr, flags, (size_t)n0, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(scene_count_mapped_u8_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, s, n,
+                (kind == 0 ? sc->orig_t : sc->orig_f).as<int32_t>(), tmp.as<uint8_t>(), c);
+        }
+        OSFM_HIP_CHECK(hipMemcpyAsync(&have, c, 4, hipMemcpyDeviceToHost, s));
+        OSFM_HIP_CHECK(hipStreamSynchronize(s));
+        if (want != have) {
+            set_error("scene_set_flags: %lld %s flagged alive that the scene has dropped (a compacted scene cannot revive them)",
+                (long long)(want - have), kind == 0 ? "track(s)" : "feature(s)");
+            return OSFM_E_STATE;
+        }
+    }
     if (alive_track && sc->T) {
         OSFM_HIP_CHECK(hipMemcpyAsync(tmp.ptr, alive_track, (size_t)sc->T0, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(scene_gather_u8_kernel, dim3(blocks_for(sc->T)), dim3(kThreads), 0, s, (int64_t)sc->T, sc->orig_t.as<int32_t>(),
@@ -740,6 +787,27 @@ int osfm_scene_align_views(osfm_scene *sc, int n, const int32_t *views, const do
     return OSFM_OK;
 }
 
+int osfm_scene_set_cameras(osfm_scene *sc, int n, const int32_t *views, const double *params)
+{
+    if (!sc || n < 0 || (n > 0 && !params)) { set_error("scene_set_cameras: bad arguments"); return OSFM_E_ARG; }
+    OSFM_RETURN_IF(check_views(sc, views, n, "scene_set_cameras"));
+    std::lock_guard<std::mutex> lock(sc->mu);
+    OSFM_RETURN_IF(select_device(sc->device));
+    std::vector<int> slot_of(sc->V, -1);
+    for (size_t c = 0; c < sc->aligned.size(); ++c) slot_of[sc->aligned[c]] = (int)c;
+    for (int i = 0; i < n; ++i)
+        if (slot_of[views[i]] < 0) { set_error("scene_set_cameras: view %d has no camera yet (osfm_scene_align_views)", views[i]); return OSFM_E_STATE; }
+    if (n == 0) return OSFM_OK;
+    for (int i = 0; i < n; ++i) memcpy(&sc->h_cams[(size_t)slot_of[views[i]] * 7], params + (size_t)i * 7, 56);
+    StreamLease sg;
+    OSFM_RETURN_IF(sg.acquire());
+    OSFM_HIP_CHECK(hipMemcpyAsync(sc->cams.ptr, sc->h_cams.data(), sc->aligned.size() * 56, hipMemcpyHostToDevice, sg.s));
+    OSFM_HIP_CHECK(hipStreamSynchronize(sg.s));
+    // intersections made from the old parameters are stale: the next triangulation redoes every track
+    sc->cams_moved = true;
+    return OSFM_OK;
+}
+
 int osfm_scene_get_cameras(osfm_scene *sc, int capacity, int32_t *views, double *params, int32_t *num_cameras)
 {
     if (!sc) { set_error("scene_get_cameras: null scene"); return OSFM_E_ARG; }
@@ -765,7 +833,9 @@ int osfm_scene_triangulate(osfm_scene *sc, int num_new_views, const int32_t *new
     hipStream_t s = sg.s;
     if (mismatches) *mismatches = 0;
     if (sc->T == 0) return OSFM_OK;
-    const bool incremental = new_views != nullptr;
+    // cameras replaced from outside since the last pass (osfm_scene_set_cameras): nothing may be kept
+    const bool incremental = new_views != nullptr && !sc->cams_moved;
+    sc->cams_moved = false;
     uint8_t *tmask = nullptr;
     DevArray d_views;
     if (incremental) {

@@ -111,6 +111,9 @@ void runBundleAdjustment(std::vector<CameraPtr>& cameras, std::vector<Track>& tr
     p.num_cameras = (int32_t)C; p.num_points = (int32_t)owner.size(); p.num_observations = (int32_t)oc.size();
     p.cam_params = cam.data(); p.cam_const = cst.data(); p.img_width = w.data(); p.img_height = h.data();
     p.points = pts.data(); p.obs_xy = xy.data(); p.obs_camera = oc.data(); p.obs_point = op.data();
+    if (osfm_version() != OSFM_ABI_VERSION)      // osfm_ba_summary is written in full by the library
+        throw std::runtime_error("osfm: libosfm_hip.so has ABI version " + std::to_string(osfm_version()) +
+            ", this adapter was built against " + std::to_string(OSFM_ABI_VERSION));
     osfm_ba_options o;
     osfm_ba_options_default(&o);
     o.optimize_points = optimizePoints ? 1 : 0;

@@ -57,6 +57,10 @@ public:
             osfm_match_destroy(this->handle);
             this->handle = nullptr;
         }
+        // the library fills public structs in full: one built from another header must not run
+        if (osfm_version() != OSFM_ABI_VERSION)
+            throw std::runtime_error("osfm: libosfm_hip.so has ABI version " + std::to_string(osfm_version()) +
+                ", this adapter was built against " + std::to_string(OSFM_ABI_VERSION));
         osfm_match_options o;
         osfm_match_options_default(&o);
         o.sift_lowe_ratio = this->opts.sift_matching_opts.lowe_ratio_threshold;

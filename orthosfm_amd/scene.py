@@ -51,6 +51,13 @@ class Scene:
         capi.check(capi.lib.osfm_scene_align_views(self._h_scene, C.c_int(v.shape[0]), capi._ptr(v, C.c_int32),
                                                    capi._ptr(p, C.c_double), capi._ptr(c, C.c_uint8)))
 
+    def set_cameras(self, views, params):
+        """Replaces the parameters of views that are aligned already (the next triangulation is a full pass)."""
+        v = np.ascontiguousarray(views, dtype=np.int32)
+        p = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 7)
+        capi.check(capi.lib.osfm_scene_set_cameras(self._h_scene, C.c_int(v.shape[0]), capi._ptr(v, C.c_int32),
+                                                   capi._ptr(p, C.c_double)))
+
     def cameras(self):
         n = C.c_int32()
         capi.check(capi.lib.osfm_scene_get_cameras(self._h_scene, 0, None, None, C.byref(n)))

@@ -105,3 +105,37 @@ def test_m0_is_written_only_by_hand_in_the_pipe_kernels():
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("[hand-written m0]") >= 3 and "0 other than s_mov_b32 m0 [hand-written m0]" in out.stdout
     assert "match_special_wide_kernel" in out.stdout
+
+
+def test_a_point_observed_twice_by_one_camera_is_refused():
+    """the Schur fast paths keep one slot per camera and track, so a repeated (camera, point)
+    observation would drop entries silently.  The reference never builds one (a track with two features of a view
+    is a conflict and dropped, bundler_tracks.cc:120-145): the boundary refuses it, before any device work."""
+    from orthosfm_amd import ba, capi, synth
+    sc = synth.make_ba_scene(0, 3, 10, config_id=50)
+    fp = ba.FlatProblem.from_scene(sc)
+    k = int(np.flatnonzero(fp.obs_point == fp.obs_point[0])[1])       # second observation of the first track
+    fp.obs_camera[k] = fp.obs_camera[0]
+    with pytest.raises(capi.OsfmError) as e:
+        ba.solve(fp)
+    assert e.value.status == capi.E_ARG and "observed twice" in str(e.value)
+    # the scene entry: a track with two features of one view
+    scn = C.c_void_p()
+    offs = np.array([0, 2, 4], dtype=np.int64)
+    view = np.array([0, 1, 1, 1], dtype=np.int32)
+    xy = np.zeros((4, 2), dtype=np.float32)
+    wh = np.array([100, 100], dtype=np.int32)
+    st = capi.lib.osfm_scene_create(0, 0, 2, wh.ctypes.data_as(C.c_void_p), wh.ctypes.data_as(C.c_void_p), 2,
+                                    offs.ctypes.data_as(C.c_void_p), view.ctypes.data_as(C.c_void_p),
+                                    xy.ctypes.data_as(C.c_void_p), C.byref(scn))
+    assert st == capi.E_ARG and "two features of view 1" in capi.last_error()
+
+
+def test_abi_version_of_library_header_and_mirror_agree():
+    """public structs grew; a caller built against another header must be able to tell."""
+    from orthosfm_amd import capi
+    text = open(os.path.join(ROOT, "include", "osfm_hip.h")).read()
+    v = int(re.search(r"#define\s+OSFM_ABI_VERSION\s+(\d+)", text).group(1))
+    assert capi.lib.osfm_version() == v == capi.ABI_VERSION
+    for fn in ("ba_hip_adapter.h", "mve_hip_matching.h"):
+        assert "OSFM_ABI_VERSION" in open(os.path.join(ROOT, "orthosfm_amd", "host", fn)).read()

@@ -392,3 +392,61 @@ def test_cpp_caller_of_the_scene(iset, tmp_path):
     sc.close()
     assert len(lines) == len(exp) and int((at & hp).sum()) > 100
     assert lines == exp
+
+
+def _scene_from_ba_scene(sc, device=0):
+    """A device-resident scene whose track table is a synthetic BA problem's observation list."""
+    from orthosfm_amd.scene import Scene
+    M = sc.points.shape[0]
+    offs = np.zeros(M + 1, dtype=np.int64)
+    np.add.at(offs, sc.obs_point + 1, 1)
+    offs = np.cumsum(offs)
+    return Scene(sc.model, sc.img_w, sc.img_h, offs, sc.obs_camera, sc.obs_xy.astype(np.float32), device)
+
+
+def test_scene_cameras_replaced_from_outside_and_flags_of_dropped_entries(monkeypatch):
+    """(1) a caller's own change to aligned cameras (normalizeScene, reconstruct.cpp:266-270) reaches the
+    device copy through osfm_scene_set_cameras, and the next triangulation is a full pass even when the caller asks
+    for an incremental one; (2) a compacted scene refuses flags that would revive what it dropped (OSFM_E_STATE,
+    nothing changed) and still takes flags that only clear."""
+    from orthosfm_amd import capi, synth
+    sc = synth.make_ba_scene(0, 6, 400, config_id=61)
+    V = sc.cam_params.shape[0]
+    views = np.arange(V, dtype=np.int32)
+    moved = sc.cam_params.copy()
+    moved[2, 4] += 0.03                       # offsetX of view 2
+    a = _scene_from_ba_scene(sc)
+    a.align_views(views, sc.cam_params, sc.cam_const)
+    a.triangulate()
+    p0 = a.download()[3].copy()
+    with pytest.raises(capi.OsfmError) as e:
+        _scene_from_ba_scene(sc).set_cameras([1], moved[1:2])
+    assert e.value.status == capi.E_STATE
+    a.set_cameras([2], moved[2:3])
+    assert np.array_equal(a.cameras()[1], moved)
+    a.triangulate(new_views=[5])              # asked incremental: must be done in full
+    pa = a.download()[3]
+    b = _scene_from_ba_scene(sc)
+    b.align_views(views, moved, sc.cam_const)
+    b.triangulate()
+    pb = b.download()[3]
+    assert np.array_equal(pa, pb) and not np.array_equal(pa, p0)
+    b.close()
+    # (2)
+    monkeypatch.setenv("OSFM_SCENE_COMPACT", "2")
+    at, af, hp, _ = a.download()
+    kill = at.copy()
+    kill[::3] = False
+    a.set_flags(kill.astype(np.uint8), None)
+    a.filter_outliers()                       # compacts (policy 2): the cleared third is gone
+    at2, af2 = a.download()[:2]
+    assert not at2[::3].any()
+    with pytest.raises(capi.OsfmError) as e:
+        a.set_flags(np.ones_like(at, dtype=np.uint8), None)
+    assert e.value.status == capi.E_STATE and "dropped" in str(e.value)
+    assert np.array_equal(a.download()[0], at2)          # nothing changed
+    fewer = at2.copy()
+    fewer[np.flatnonzero(at2)[:5]] = False
+    a.set_flags(fewer.astype(np.uint8), None)
+    assert np.array_equal(a.download()[0], fewer)
+    a.close()
