@@ -39,7 +39,8 @@ OSFM_API const char *osfm_last_error(void);
  * (osfm_match_stats, osfm_ba_summary, ...) in full, so a caller built against another header must not run: the
  * adapters (the headers under orthosfm_amd/host) and the Python mirror compare this with their own OSFM_ABI_VERSION at load time.
  * 100: rounds 1-3; 101: osfm_ba_summary.flow_fallbacks, osfm_match_stats.surf_*; 102: one observation per camera
- * and point enforced, osfm_scene_set_cameras. */
+ * and point enforced, osfm_scene_set_cameras,
+ * osfm_ba_summary.order_arcs / chain_blocks*. */
 #define OSFM_ABI_VERSION 102
 OSFM_API int osfm_version(void);
 /* Number of visible HIP devices (0 when there is none). */
@@ -448,7 +449,11 @@ typedef struct osfm_ba_summary {
     int32_t flow_fallbacks;           /* factorisations whose one-launch form gave its launch up (its workgroups
                                        * were not all resident: the device was shared) and that were repeated in
                                        * the launch-per-column form; the results do not depend on it */
-    int32_t reserved0;
+    int32_t order_arcs;               /* 0: the reduced camera system was factored in the cameras' own order; K > 0: the
+                                       * cameras form a ring / strip (every track spans a short run of views) and the
+                                       * system was laid out as K arcs + K separators, factored side by side */
+    int32_t chain_blocks_natural;     /* longest chain of dependent 32-unknown diagonal blocks in the cameras' order ... */
+    int32_t chain_blocks;             /* ... and in the order used */
 } osfm_ba_summary;
 
 OSFM_API int osfm_ba_options_default(osfm_ba_options *opts);

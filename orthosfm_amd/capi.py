@@ -118,7 +118,8 @@ class BaSummary(C.Structure):
                 ("back_pass_ms", C.c_double),
                 ("linearizations", C.c_int32), ("num_pair_entries", C.c_int32),
                 ("lm_loop_ms", C.c_double),
-                ("flow_fallbacks", C.c_int32), ("reserved0", C.c_int32)]
+                ("flow_fallbacks", C.c_int32), ("order_arcs", C.c_int32),
+                ("chain_blocks_natural", C.c_int32), ("chain_blocks", C.c_int32)]
 
 
 # every symbol include/osfm_hip.h declares (checked by tests/test_capi_symbols.py)

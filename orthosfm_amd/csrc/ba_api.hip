@@ -177,7 +177,8 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
     };
     hipStream_t s = sg.s;
     BaDev &d = D.dev;
-    const int C = d.C, M = d.M, nc = d.nc, pdim = d.pdim;
+    const int C = d.C, M = d.M, pdim = d.pdim;
+    int nc = d.nc;
     // observation windows of the per-point passes (ba_kernels.h): one workgroup, one partial slot each.  Laid out
     // by a kernel queued in front of the pair lists; the count of windows that need the other kernels comes back
     // with the pair lists' own synchronisation
@@ -194,10 +195,20 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
     OSFM_RETURN_IF(win_count.alloc(16));
     OSFM_RETURN_IF(obs_lay.alloc((size_t)std::max(d.O, 1) * 4));
     OSFM_HIP_CHECK(hipMemsetAsync(win_count.ptr, 0, 16, s));
-    launch_obs_windows(d, win.num, win_desc.as<WinDesc>(), win_over.as<int32_t>(), win_ok.as<int32_t>(), win_count.as<int32_t>(),
-        obs_lay.as<int32_t>(), s);
     int32_t *h_over = reinterpret_cast<int32_t *>(&h_state[max_slots - 1]);
-    OSFM_HIP_CHECK(hipMemcpyAsync(h_over, win_count.ptr, 4, hipMemcpyDeviceToHost, s));
+    auto lay_out_windows = [&]() -> int {
+        // (obs_lay holds the cameras' offsets: behind the choice of the elimination order where there is one)
+        launch_obs_windows(d, win.num, win_desc.as<WinDesc>(), win_over.as<int32_t>(), win_ok.as<int32_t>(), win_count.as<int32_t>(),
+            obs_lay.as<int32_t>(), s);
+        OSFM_HIP_CHECK(hipMemcpyAsync(h_over, win_count.ptr, 4, hipMemcpyDeviceToHost, s));
+        return OSFM_OK;
+    };
+    // An elimination order for the reduced camera system is looked for where the system has at least eight block
+    // columns (ba_order.hip; OSFM_BA_ORDER=0: never): it needs the camera pairs, so the pair lists come first then.
+    const int order_policy = getenv("OSFM_BA_ORDER") ? atoi(getenv("OSFM_BA_ORDER")) : 1;        // (read per solve: A/B runs and tests)
+    const bool may_order = order_policy != 0 && pdim != 0 && cholesky_padded_dim(std::max(nc, 1)) / 32 >= 8 &&
+        getenv("OSFM_BA_CHOLESKY_STEPS") == nullptr;
+    if (!may_order) OSFM_RETURN_IF(lay_out_windows());
     win.desc = win_desc.as<WinDesc>(); win.over_list = win_over.as<int32_t>(); win.ok_list = win_ok.as<int32_t>();
     win.obs_lay = obs_lay.as<int32_t>();
     // camera-pair lists of the Schur complement, built on the device
@@ -206,6 +217,42 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
     OSFM_RETURN_IF(pair_lists_build(d, pdim != 0, std::max<int64_t>(pair_bound, 1), &PL, s, dense_policy));
     const int num_pairs = PL.num_pairs;
     sum->num_pair_entries = PL.dense ? PL.num_entries_all : PL.num_entries;
+    ReducedOrder ord;
+    DevArray ord_nz, ord_ptiles, ord_pad;
+    std::vector<uint32_t> h_keys;
+    std::vector<int32_t> h_ldim;
+    if (may_order) {
+        if (!PL.dense && num_pairs > 0) {
+            // the camera pairs that share a track (the unique keys of the lists) and the cameras' block sizes
+            h_keys.resize((size_t)num_pairs); h_ldim.resize((size_t)C);
+            OSFM_HIP_CHECK(hipMemcpyAsync(h_keys.data(), PL.unique.ptr, (size_t)num_pairs * 4, hipMemcpyDeviceToHost, s));
+            OSFM_HIP_CHECK(hipMemcpyAsync(h_ldim.data(), d.cam_ldim, (size_t)C * 4, hipMemcpyDeviceToHost, s));
+            OSFM_HIP_CHECK(hipStreamSynchronize(s));
+            std::vector<std::pair<int, int>> cpairs((size_t)num_pairs);
+            const uint32_t g = (uint32_t)PL.group, Cu = (uint32_t)C;
+            for (int i = 0; i < num_pairs; ++i) {
+                const uint32_t key = h_keys[i];
+                cpairs[i] = {(int)((key / (Cu * g)) * g + key % g), (int)((key / g) % Cu)};
+            }
+            if (choose_reduced_order(C, h_ldim.data(), cpairs, &ord)) {
+                OSFM_HIP_CHECK(hipMemcpyAsync(const_cast<int32_t *>(d.cam_off), ord.cam_off.data(), (size_t)C * 4, hipMemcpyHostToDevice, s));
+                nc = ord.span;
+                d.nc = nc;
+                OSFM_RETURN_IF(D.scale_c.alloc((size_t)nc * 8));
+                launch_fill(D.scale_c.as<double>(), (size_t)nc, 1.0, s);
+                d.scale_c = D.scale_c.as<double>();
+                OSFM_RETURN_IF(upload(ord_nz, ord.nz.data(), ord.nz.size(), s));
+                OSFM_RETURN_IF(upload(ord_ptiles, ord.ptiles.data(), ord.ptiles.size(), s));
+                OSFM_RETURN_IF(upload(ord_pad, ord.pad.data(), ord.pad.size(), s));
+            }
+        }
+        OSFM_RETURN_IF(lay_out_windows());
+    }
+    sum->order_arcs = ord.active ? ord.arcs : 0;
+    sum->chain_blocks_natural = ord.chain_natural;
+    sum->chain_blocks = ord.active ? ord.chain_ordered : ord.chain_natural;
+    FlowPattern pattern;
+    if (ord.active) { pattern.nz = ord_nz.as<unsigned long long>(); pattern.ptiles = ord_ptiles.as<int32_t>(); pattern.num_ptiles = (int)ord.ptiles.size(); }
     // dense visibility: the point part of the Schur complement is a product of two dense matrices (ba_dense.hip)
     DevArray dense_z, dense_w, dense_partial;
     bool dense_first = true;
@@ -351,7 +398,10 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
         OSFM_RETURN_IF(tic(0));
         launch_point_pass(d, pa, win, s);
         OSFM_RETURN_IF(toc());
-        if (reset) launch_reset_system(S.as<double>(), s_elems, N, nc, N, s);
+        if (reset) {
+            launch_reset_system(S.as<double>(), s_elems, N, nc, N, s);
+            if (ord.active) launch_padding_diagonal(S.as<double>(), N, ord_pad.as<int32_t>(), (int)ord.pad.size(), s);
+        }
         if (PL.dense) {
             launch_schur_dense(d, obsrec.as<double>(), win.obs_lay, dense_z.as<double>(), dense_w.as<double>(), dense_partial.as<double>(),
                 S.as<double>(), N, dense_first, s);
@@ -405,7 +455,7 @@ int ba_solve_core(DeviceProblem &D, const osfm_ba_options &o, StreamLease &sg, i
         bool consumed = false;
         if (small) launch_small_solve(S.as<double>(), nc, Ldiag.as<double>(), y_c.as<double>(), info.as<int>(), d, part_cam.as<double>(), s);
         else if (nc > 0) consumed = launch_cholesky_solve(S.as<double>(), Lmat.as<double>(), nc, Ldiag.as<double>(), y_c.as<double>(), info.as<int>(), lm, s,
-            flow_now ? flow_flags.as<int>() : nullptr, ++flow_epoch, flow_now ? flow_mailbox.as<double>() : nullptr) == 0;
+            flow_now ? flow_flags.as<int>() : nullptr, ++flow_epoch, flow_now ? flow_mailbox.as<double>() : nullptr, pattern) == 0;
         OSFM_RETURN_IF(toc());
         OSFM_RETURN_IF(tic(3));
         BackPassArgs ba;

@@ -474,7 +474,34 @@ struct CholFlow {
     int num_tiles;        // P tiles
     int spin_limit;
     long long *trace;     // diagnostics (tools/chol_flow_trace.py): [nblk + 1][16] wall_clock64 stamps of the D's, or null
+    // block pattern of the factor (ba_order.hip; null: dense).  A tile that is structurally zero is never waited
+    // for, multiplied or published: skipping it changes no value (its products are exact zeros), it removes the
+    // WAIT -- the arcs of an ordered ring are chains of their own.
+    const unsigned long long *nz;     // [(nblk + 1)][kNzWords]
+    const int32_t *ptiles;            // the P tiles as i << 16 | j, column-major (null: all of them, enumerated)
 };
+
+static_assert(160 + 1 <= 64 * kNzWords, "a row of the block pattern must hold every column");
+// row i of the block pattern (all ones without one); bit k of a row
+struct FlowRow { unsigned long long w0, w1, w2; };
+__device__ __forceinline__ FlowRow flow_row(const CholFlow &f, int i)
+{
+    FlowRow r = {~0ull, ~0ull, ~0ull};
+    if (f.nz) { r.w0 = f.nz[(size_t)i * kNzWords]; r.w1 = f.nz[(size_t)i * kNzWords + 1]; r.w2 = f.nz[(size_t)i * kNzWords + 2]; }
+    return r;
+}
+// tile (i, k) of the factor exists -- read where it is asked for: rows kept in registers cost the D part 18 scalar
+// registers it does not have (the kernel then spilled scalars into scratch memory, and its hand-offs raced)
+__device__ __forceinline__ bool flow_nz(const CholFlow &f, int i, int k)
+{
+    return f.nz == nullptr || ((f.nz[(size_t)i * kNzWords + (k >> 6)] >> (k & 63)) & 1ull) != 0;
+}
+__device__ __forceinline__ FlowRow flow_row_and(const FlowRow &a, const FlowRow &b) { return FlowRow{a.w0 & b.w0, a.w1 & b.w1, a.w2 & b.w2}; }
+__device__ __forceinline__ bool flow_bit(const FlowRow &r, int k)
+{
+    const unsigned long long w = k < 64 ? r.w0 : k < 128 ? r.w1 : r.w2;
+    return (w >> (k & 63)) & 1ull;
+}
 
 // flag words: sc1 copy of tile (i, k) final | sc1 copy of inverse k | mailbox copies (r, slot) | abort
 __device__ __forceinline__ int flow_tile_flag(const CholFlow &f, int i, int k) { return i * f.nblk + k; }
@@ -640,14 +667,17 @@ flow_p_tile(const CholFlow &f, FlowWaiter &w, const FlowPos &p, int i, int j, Fl
     const double *Aij = f.A + (size_t)(i * NB) * ld + j * NB;
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = Aij[(size_t)(p.tr0 + 4 * e) * ld + p.tc];
+    // the steps that have both operands: L(i, k) and L(j, k) structurally nonzero
+    const FlowRow need = flow_row_and(flow_row(f, i), flow_row(f, j));
     int k = 0;
     while (k < j) {
+        if (!flow_bit(need, k)) { ++k; continue; }
         // how many of the steps k, k + 1, ... have both their operands -- L(i, .) and L(j, .) -- published already?
         // (lane 2 m: tile (i, k + m), lane 2 m + 1: tile (j, k + m); one load per lane, no waiting)
         if (tid < 64) {
             const int m = tid >> 1, kk = k + m;
             bool missing = false;
-            if (m < kFlowProbe && kk < j)
+            if (m < kFlowProbe && kk < j && flow_bit(need, kk))
                 missing = __hip_atomic_load(f.flags + flow_tile_flag(f, (tid & 1) ? j : i, kk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != f.epoch;
             const unsigned long long mm = __ballot(missing);
             const int ready = mm ? (int)(__builtin_ctzll(mm) >> 1) : min(kFlowProbe, j - k);
@@ -660,13 +690,21 @@ flow_p_tile(const CholFlow &f, FlowWaiter &w, const FlowPos &p, int i, int j, Fl
             if (!flow_wait_lanes(f, w, tid == 0 ? flow_tile_flag(f, i, k) : tid == 1 ? flow_tile_flag(f, j, k) : -1, -1)) return false;
             ready = 1;
         }
-        for (int m = 0; m < ready; m += 2) {
-            const bool two = m + 1 < ready;
-            const FlowTile t0 = flow_fetch_tile(f.Lmat + (size_t)(i * NB) * ld + (k + m) * NB, ld, p);
-            const FlowTile t1 = flow_fetch_tile(f.Lmat + (size_t)(j * NB) * ld + (k + m) * NB, ld, p);
+        for (int m = 0; m < ready;) {
+            // the next one or two steps that exist (uniform: the pattern is the launch's)
+            while (m < ready && !flow_bit(need, k + m)) ++m;
+            if (m >= ready) break;
+            const int ka = k + m;
+            ++m;
+            while (m < ready && !flow_bit(need, k + m)) ++m;
+            const bool two = m < ready;
+            const int kb = k + m;
+            if (two) ++m;
+            const FlowTile t0 = flow_fetch_tile(f.Lmat + (size_t)(i * NB) * ld + ka * NB, ld, p);
+            const FlowTile t1 = flow_fetch_tile(f.Lmat + (size_t)(j * NB) * ld + ka * NB, ld, p);
             if (two) {
-                const FlowTile t2 = flow_fetch_tile(f.Lmat + (size_t)(i * NB) * ld + (k + m + 1) * NB, ld, p);
-                const FlowTile t3 = flow_fetch_tile(f.Lmat + (size_t)(j * NB) * ld + (k + m + 1) * NB, ld, p);
+                const FlowTile t2 = flow_fetch_tile(f.Lmat + (size_t)(i * NB) * ld + kb * NB, ld, p);
+                const FlowTile t3 = flow_fetch_tile(f.Lmat + (size_t)(j * NB) * ld + kb * NB, ld, p);
                 flow_put_tile(t0, Xr, p); flow_put_tile(t1, Xc, p); flow_put_tile(t2, Li, p); flow_put_tile(t3, Mt, p);
             } else {
                 flow_put_tile(t0, Xr, p); flow_put_tile(t1, Xc, p);
@@ -721,11 +759,16 @@ flow_d_forward(const CholFlow &f, FlowWaiter &w, const FlowPos &p, int row, Flow
     // ---- columns left of the band: L(row, k) is a P tile, L(c, k) of the own columns c != row a P tile or a
     //      neighbour's band tile; all of a step's flags are polled side by side and its tiles fetched together ----
     for (int k = 0; k < lo; ++k) {
+        if (!flow_nz(f, row, k)) continue;        // L(row, k) = 0: column k changes none of the own tiles
+        bool has[kFlowW];
+#pragma unroll
+        for (int t = 0; t < kFlowW; ++t) has[t] = lo + t <= hi && lo + t != row && flow_nz(f, lo + t, k);
         int slow = -1, box = -1;
         if (tid == 0) slow = flow_tile_flag(f, row, k);
         else if (tid <= kFlowW) {
             const int c = lo + (int)tid - 1;
-            if (c <= hi && c != row) {
+            const bool hc = tid == 1 ? has[0] : tid == 2 ? has[1] : has[2];
+            if (hc) {
                 slow = flow_tile_flag(f, c, k);
                 if (c - k <= kFlowW) box = flow_box_flag(f, c, c - k);
             }
@@ -736,27 +779,28 @@ flow_d_forward(const CholFlow &f, FlowWaiter &w, const FlowPos &p, int row, Flow
 #pragma unroll
         for (int t = 0; t < kFlowW; ++t) {
             const int c = lo + t;
-            if (c <= hi && c != row) {
+            if (has[t]) {
                 if (flow_how(w, t + 1) == 2) tc[t] = flow_fetch_tile(flow_box(f, c, c - k), NB, p);
                 else tc[t] = flow_fetch_tile(f.Lmat + (size_t)(c * NB) * ld + k * NB, ld, p);
             }
         }
         flow_put_tile(tr, Xr, p);
 #pragma unroll
-        for (int t = 0; t < kFlowW; ++t) {
-            const int c = lo + t;
-            if (c <= hi && c != row) flow_put_tile(tc[t], t == 0 ? Xc : t == 1 ? Li : Mt, p);
-        }
+        for (int t = 0; t < kFlowW; ++t)
+            if (has[t]) flow_put_tile(tc[t], t == 0 ? Xc : t == 1 ? Li : Mt, p);
         lds_barrier();
 #pragma unroll
         for (int t = 0; t <= kFlowW; ++t) {
             const int c = lo + t;
-            if (c <= hi) flow_mma<true>(acc[t], Xr, c == row ? Xr : t == 0 ? Xc : t == 1 ? Li : Mt, p);
+            if (c <= hi && (c == row || (t < kFlowW && has[t < kFlowW ? t : 0])))
+                flow_mma<true>(acc[t], Xr, c == row ? Xr : t == 0 ? Xc : t == 1 ? Li : Mt, p);
         }
         lds_barrier();
     }
     // ---- the band: columns lo .. row - 1, the critical path ----
     for (int k = lo; k < row; ++k) {
+        // L(row, k) = 0 (another arc's column): nothing to solve, publish or apply -- and nothing to wait for
+        if (!flow_nz(f, row, k)) continue;
         {
             const int how = flow_wait(f, w, flow_inv_flag(f, k), flow_box_flag(f, k, 0));
             if (!how) return false;
@@ -790,6 +834,7 @@ flow_d_forward(const CholFlow &f, FlowWaiter &w, const FlowPos &p, int row, Flow
         }
         // ---- apply column k to the own tiles right of it ----
         for (int c = max(k + 1, lo); c <= hi; ++c) {
+            if (c != row && !flow_nz(f, c, k)) continue;       // L(c, k) = 0
             if (c == row) {
                 lds_barrier();
             } else {
@@ -932,12 +977,14 @@ flow_d_backward(const CholFlow &f, FlowWaiter &w, const FlowPos &p, int row, boo
         if (!how) return false;
         if (tid < NB) sv[tid] = load_sc1(how == 2 ? flow_box(f, nblk, nblk - row) + tid : f.Lmat + (size_t)(nblk * NB) * ld + row * NB + tid);
     }
-    const bool linked = row + 1 < nblk;
+    // column `row` of the block pattern: bit i = tile (i, row) exists (gathered from the rows' words)
+    auto in_col = [&](int i) { return f.nz == nullptr || ((f.nz[(size_t)i * kNzWords + (row >> 6)] >> (row & 63)) & 1ull) != 0; };
+    const bool linked = row + 1 < nblk && in_col(row + 1);
     // every tile of the column is final by the time the first block of the solution exists; their flags are looked
     // at once, 64 per poll (the sc1 copies: no mailbox verdicts), and the tiles then fetched without waiting
     for (int i0 = row + 1; i0 < nblk; i0 += 64) {
         const int i = i0 + tid;
-        if (!flow_wait_lanes(f, w, tid < 64 && i < nblk ? flow_tile_flag(f, i, row) : -1, -1)) return false;
+        if (!flow_wait_lanes(f, w, tid < 64 && i < nblk && in_col(i) ? flow_tile_flag(f, i, row) : -1, -1)) return false;
     }
     auto fetch = [&](int i) { return flow_fetch_tile(f.Lmat + (size_t)(i * NB) * ld + row * NB, ld, p); };
     if (linked) {
@@ -961,12 +1008,17 @@ flow_d_backward(const CholFlow &f, FlowWaiter &w, const FlowPos &p, int row, boo
     // the tiles above the link, as their blocks of the solution come in: the next tile is on its way while this one's
     // x is awaited
     int cur = 0;
-    if (nblk - 1 > row + 1) flow_put_tile(fetch(nblk - 1), Xr, p);
-    for (int i = nblk - 1; i > row + 1; --i) {
+    // (the tiles of the column that exist, from the bottom up; -1: none left above the link)
+    auto below = [&](int i) { for (--i; i > row + 1; --i) if (in_col(i)) return i; return -1; };
+    int inext = below(nblk);
+    if (inext >= 0) flow_put_tile(fetch(inext), Xr, p);
+    while (inext >= 0) {
+        const int i = inext;
+        inext = below(i);
         FlowLds T = cur ? Xc : Xr;
         FlowTile next;
-        const bool more = i - 1 > row + 1;
-        if (more) next = fetch(i - 1);
+        const bool more = inext >= 0;
+        if (more) next = fetch(inext);
         flow_wait_x(f, w, i, xv, true);
         if (!flow_how(w, 0)) return false;
         if (tid < 64) {
@@ -1058,8 +1110,13 @@ chol_flow_kernel(CholFlow f)
         // column j of the list holds rows j + kFlowW + 1 .. nblk: nblk - kFlowW - j tiles
         int j = 0, base = 0;
         for (int t = pidx; t < f.num_tiles; t += f.num_p) {
-            while (t - base >= nblk - kFlowW - j) { base += nblk - kFlowW - j; ++j; }
-            if (!flow_p_tile(f, w, p, j + kFlowW + 1 + (t - base), j, Xr, Xc, Li, Mt)) return;
+            int ti, tj;
+            if (f.ptiles) { const int32_t e = f.ptiles[t]; ti = e >> 16; tj = e & 0xffff; }
+            else {
+                while (t - base >= nblk - kFlowW - j) { base += nblk - kFlowW - j; ++j; }
+                ti = j + kFlowW + 1 + (t - base); tj = j;
+            }
+            if (!flow_p_tile(f, w, p, ti, tj, Xr, Xc, Li, Mt)) return;
             lds_barrier();
         }
         return;
@@ -1206,6 +1263,18 @@ chol_backsolve_kernel(const double *A, int ld, int nblk, int n, const double *Ld
 
 int cholesky_padded_dim(int n) { return (n + NB - 1) / NB * NB; }
 
+__global__ void
+chol_padding_diagonal_kernel(double *S, int ld, const int32_t *__restrict__ pad, int npad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npad) S[(size_t)pad[i] * ld + pad[i]] = 1.0;
+}
+
+void launch_padding_diagonal(double *S, int ld, const int32_t *pad, int npad, hipStream_t s)
+{
+    if (npad > 0) hipLaunchKernelGGL(chol_padding_diagonal_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, S, ld, pad, npad);
+}
+
 void launch_small_solve(const double *A, int n, double *Ldiag, double *x, int *info, const BaDev &d,
     double *partials_cam, hipStream_t s)
 {
@@ -1216,8 +1285,9 @@ void launch_small_solve(const double *A, int n, double *Ldiag, double *x, int *i
 // Ldiag: N * 32 doubles of scratch for the inverses of the factored diagonal blocks.
 // Returns the form that was launched: 1 the one-launch flow form, 0 launch per block column.
 int launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double *x, int *info, const LmDev *lm, hipStream_t s,
-    int *flow_flags, int flow_epoch, double *flow_mailbox)
+    int *flow_flags, int flow_epoch, double *flow_mailbox, FlowPattern pattern)
 {
+    static_assert(kFlowBand == kFlowW && kFlowOrderMaxBlocks == kFlowMaxBlocks, "ba_kernels.h mirrors these");
     const int N = cholesky_padded_dim(n);
     const int nblk = N / NB;
     // The D's sit at the blocks 0, 8, 16, ...; the P workgroups fill the blocks between and behind them.  One P
@@ -1225,6 +1295,7 @@ int launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double 
     // fits the device, else the tiles are dealt round robin to as many as do fit.
     int num_tiles = 0;
     for (int j = 0; j < nblk; ++j) num_tiles += std::max(nblk - kFlowW - j, 0);
+    if (pattern.ptiles) num_tiles = pattern.num_ptiles;
     static const int exp_max_d = getenv("OSFM_FLOW_MAX_D") ? atoi(getenv("OSFM_FLOW_MAX_D")) : kFlowMaxD;
     static const int exp_max_groups = getenv("OSFM_FLOW_MAX_GROUPS") ? atoi(getenv("OSFM_FLOW_MAX_GROUPS")) : 1 << 30;
     const int num_d = std::min(nblk + 1, exp_max_d);
@@ -1241,6 +1312,7 @@ int launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double 
         f.A = A; f.Lmat = Lmat; f.Ldiag = Ldiag; f.flags = flow_flags; f.info = info; f.lm = lm;
         f.ld = N; f.nblk = nblk; f.epoch = flow_epoch; f.trace = g_flow_trace;
         f.num_d = num_d; f.num_p = std::max(num_p, 1); f.num_tiles = num_tiles;
+        f.nz = pattern.nz; f.ptiles = pattern.ptiles;
         f.spin_limit = g_flow_spin_limit.load();
         // the backward substitution runs inside the same launch; x has room for the padded system (N entries)
         f.x = getenv("OSFM_BA_FLOW_FACTOR_ONLY") ? nullptr : x;

@@ -177,6 +177,7 @@ struct PairListsDev {
     int num_entries = 0;
     int max_chunks = 0;
     int chunk = kPairChunk;
+    int group = 1;               // the unique keys are pair_key_of(ca, cb, C, group)
     ~PairListsDev()
     {
         PooledBuffer *b[] = {&counts, &offsets, &keys_in, &keys, &vals_in, &entries, &unique, &runs, &starts, &scalars, &temp,
@@ -197,8 +198,17 @@ int cholesky_padded_dim(int n);
 // Returns 1 when the one-launch form ran, 0 for the launch-per-column form.  The one-launch form reports a launch it
 // had to give up (a wait that outlasted its spin limit: not all workgroups were resident) as info >= kFlowAborted.
 constexpr int kFlowAborted = 1 << 20;
+// Block pattern of the factor for the one-launch form (ba_order.hip): nz[(nblk + 1)][kNzWords] bit k of row i = tile
+// (i, k) of L is structurally nonzero (fill included; row nblk: the right-hand side); ptiles: the nonzero tiles more
+// than kFlowBand below the diagonal as i << 16 | j, column-major.  Null: every tile is taken as nonzero.
+constexpr int kNzWords = 3;
+constexpr int kFlowBand = 3;
+constexpr int kFlowOrderMaxBlocks = 160;
+struct FlowPattern { const unsigned long long *nz = nullptr; const int32_t *ptiles = nullptr; int num_ptiles = 0; };
 int launch_cholesky_solve(double *A, double *Lmat, int n, double *Ldiag, double *x, int *info, const LmDev *lm, hipStream_t s,
-    int *flow_flags = nullptr, int flow_epoch = 0, double *flow_mailbox = nullptr);
+    int *flow_flags = nullptr, int flow_epoch = 0, double *flow_mailbox = nullptr, FlowPattern pattern = FlowPattern());
+// S[i][i] = 1 for the listed unknowns (interior padding of an ordered layout: identity rows)
+void launch_padding_diagonal(double *S, int ld, const int32_t *pad, int npad, hipStream_t s);
 void chol_flow_set_spin_limit(int limit);   // test hook: polls before a wait gives the launch up (<= 0: default)
 int chol_flow_flag_count(int n);
 long long *chol_flow_trace_buffer(int enable);     // diagnostics, see osfm_ba_debug_chol_trace

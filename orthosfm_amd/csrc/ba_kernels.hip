@@ -691,7 +691,9 @@ pair_finish(const BaDev &d, const PairPassArgs &a, int c1, int c2, int n1, int n
 #pragma unroll
         for (int y = 0; y < 6; ++y)
             if (x < n1 && y < n2) {
-                double *dst = a.S + (size_t)(o1 + x) * a.ldS + (o2 + y);
+                // (an ordered layout -- ba_order.hip -- can put camera c1 >= c2 in front of c2: the block then lies
+                //  above the diagonal and is stored transposed; the factorisation reads the lower triangle)
+                double *dst = o1 >= o2 ? a.S + (size_t)(o1 + x) * a.ldS + (o2 + y) : a.S + (size_t)(o2 + y) * a.ldS + (o1 + x);
                 *dst = a.dense ? *dst + acc[x][y] : acc[x][y];
             }
     if (diag_pair && a.gmax_out && a.want_gradient) {

@@ -268,6 +268,7 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
     int32_t *counts = out->counts.as<int32_t>(), *offsets = out->offsets.as<int32_t>();
     int bits = 1;
     static const int group = getenv("OSFM_BA_PAIR_GROUP") ? std::max(1, atoi(getenv("OSFM_BA_PAIR_GROUP"))) : 8;
+    out->group = group;
     if (((unsigned long long)d.C + group) * (unsigned long long)d.C >= (1ull << 32)) { set_error("ba_solve: too many cameras for 32-bit pair keys"); return OSFM_E_RANGE; }
     while ((1ull << bits) < ((unsigned long long)d.C + group) * (unsigned long long)d.C) ++bits;
     OSFM_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, t1, counts, offsets, M, s));

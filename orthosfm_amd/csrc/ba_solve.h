@@ -3,6 +3,7 @@
 #pragma once
 #include <algorithm>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "ba_kernels.h"
@@ -39,6 +40,22 @@ struct Layout {
     std::vector<int8_t> colmap;
     int nc = 0;
 };
+
+// An elimination order of the reduced camera system for banded (ring / strip) visibility: ba_order.hip
+struct ReducedOrder {
+    bool active = false;
+    int span = 0;                             // unknowns of the laid-out system, interior padding included
+    int nblk = 0;                             // blocks of 32 of it
+    int arcs = 0, sep_cams = 0;               // K arcs, separators of that many cameras
+    int chain_natural = 0, chain_ordered = 0; // longest chain of dependent diagonal blocks, before / after
+    std::vector<int32_t> cam_off;             // [C]
+    std::vector<int32_t> pad;                 // padding unknowns below span (identity rows)
+    std::vector<unsigned long long> nz;       // FlowPattern::nz
+    std::vector<int32_t> ptiles;              // FlowPattern::ptiles
+};
+// pairs: the camera pairs (a >= b, a == b included or not) that share a track; ldim: unknowns per camera.  False
+// (out->active == false, chain_natural filled in): the natural order stands.
+bool choose_reduced_order(int C, const int32_t *ldim, const std::vector<std::pair<int, int>> &pairs, ReducedOrder *out);
 
 struct DeviceProblem {
     DevArray cams[2], points[2], obs_xy, obs_cam, obs_pt, pt_start, img_w, img_h;

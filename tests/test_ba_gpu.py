@@ -233,13 +233,17 @@ def test_global_ba_properties_config4_full_size(ba):
 def test_pair_list_bound_is_refused(ba):
     """The Schur pair lists are 32-bit: a problem whose sum of squared track lengths
     passes 2^31 - 1 is refused with OSFM_E_RANGE before anything is allocated
-    (one track seen 46341 times is enough: 46341^2 = 2^31 + 4633)."""
+    (2100 tracks seen by each of 1024 cameras: 2100 * 1024^2 = 2^31 + 54.5 M; a point is
+    observed at most once per camera, so long tracks need as many cameras)."""
     from orthosfm_amd import capi
-    sc = synth.make_ba_scene(0, 12, 4, config_id=47)
-    n = 46341
-    cam = (np.arange(n) % 11 + 1).astype(np.int32)
-    fp = ba.FlatProblem(0, sc.cam_params, sc.cam_const, sc.img_w, sc.img_h, sc.points[:1],
-                        np.zeros((n, 2)), cam, np.zeros(n, np.int32))
+    C, M = 1024, 2100
+    cams = np.zeros((C, 7)); cams[:, 3] = 1.0; cams[:, 6] = 1.0
+    const = np.zeros((C, 7), np.uint8); const[0] = 1; const[:, 6] = 1
+    wh = np.full(C, 2048, np.int32)
+    pts = np.zeros((M, 4)); pts[:, 3] = 1.0
+    cam = np.tile(np.arange(C, dtype=np.int32), M)
+    pt = np.repeat(np.arange(M, dtype=np.int32), C)
+    fp = ba.FlatProblem(0, cams, const, wh, wh, pts, np.zeros((C * M, 2)), cam, pt)
     with pytest.raises(capi.OsfmError) as e:
         ba.solve(fp)
     assert e.value.status == capi.E_RANGE
@@ -450,7 +454,9 @@ def test_a_cholesky_launch_given_up_is_repeated_launch_by_launch(ba, cams, pts):
     s_ref, fp_ref = _solve_with_env(ba, sc, {"OSFM_BA_CHOLESKY_STEPS": "1"})
     capi.check(capi.lib.osfm_ba_debug_flow_spin_limit(1))
     try:
-        s, fp = _solve_with_env(ba, sc)
+        # (the cameras' own order, as the launch-per-column reference has it: bits are compared; the ordered layout
+        #  through a given-up launch is test_ordered_elimination_survives_a_given_up_launch)
+        s, fp = _solve_with_env(ba, sc, {"OSFM_BA_ORDER": "0"})
     finally:
         capi.check(capi.lib.osfm_ba_debug_flow_spin_limit(0))
     assert s.flow_fallbacks == 1
@@ -461,3 +467,44 @@ def test_a_cholesky_launch_given_up_is_repeated_launch_by_launch(ba, cams, pts):
     # and the next solve is back on the one-launch form
     s2, _ = _solve_with_env(ba, sc)
     assert s2.flow_fallbacks == 0 and s2.num_iterations == s_ref.num_iterations
+
+
+@pytest.mark.parametrize("model,cams,pts,maxlen,arcs", [(0, 200, 20000, 12, True), (1, 120, 8000, 12, True), (0, 500, 20000, 12, True),
+                                                        (0, 64, 4000, 30, False), (0, 60, 3000, 6, True)])
+def test_ordered_elimination_of_a_ring_equals_the_natural_order(ba, model, cams, pts, maxlen, arcs):
+    """The reference factors the reduced camera system behind a fill-reducing ordering (SPARSE_SCHUR + SUITE_SPARSE,
+    bundle_adjustment.cpp:126-133).  Where every track spans a short run of neighbouring views the cameras are laid
+    out as K arcs + K separators (ba_order.hip) and the arcs are factored side by side: same LM trajectory as in the
+    cameras' own order, costs and parameters to rounding, a shorter chain of dependent blocks; a set whose tracks
+    span half the ring keeps its order; both forms repeat bit for bit."""
+    sc = synth.make_ba_scene(model, cams, pts, config_id=81, max_len=maxlen)
+    s1, fp1 = _solve_with_env(ba, sc, {"OSFM_BA_ORDER": "1"})
+    s0, fp0 = _solve_with_env(ba, sc, {"OSFM_BA_ORDER": "0"})
+    s2, fp2 = _solve_with_env(ba, sc, {"OSFM_BA_ORDER": "1"})
+    assert (s1.order_arcs > 0) == arcs and s0.order_arcs == 0
+    if arcs:
+        assert s1.chain_blocks * 4 <= s1.chain_blocks_natural * 3 and s1.chain_blocks_natural >= 8
+    assert (s1.num_iterations, s1.num_successful_steps, s1.num_unsuccessful_steps, s1.termination) == \
+        (s0.num_iterations, s0.num_successful_steps, s0.num_unsuccessful_steps, s0.termination)
+    assert s1.num_iterations >= 3 and s1.flow_fallbacks == 0
+    assert abs(s1.final_cost - s0.final_cost) <= 1e-11 * s0.final_cost
+    assert np.abs(fp1.cam_params - fp0.cam_params).max() <= 1e-9
+    assert np.abs(fp1.points - fp0.points).max() <= 1e-8
+    assert s1.final_cost == s2.final_cost and np.array_equal(fp1.cam_params, fp2.cam_params) and np.array_equal(fp1.points, fp2.points)
+
+
+def test_ordered_elimination_survives_a_given_up_launch(ba):
+    """The launch-per-column fallback works on the same laid-out system (interior padding rows are identity rows that
+    it clears and sets like the tail's): a Cholesky launch given up in the ordered form is repeated there."""
+    from orthosfm_amd import capi
+    sc = synth.make_ba_scene(0, 200, 20000, config_id=82)
+    s0, fp0 = _solve_with_env(ba, sc, {})
+    assert s0.order_arcs > 0
+    capi.check(capi.lib.osfm_ba_debug_flow_spin_limit(1))
+    try:
+        s1, fp1 = _solve_with_env(ba, sc, {})
+    finally:
+        capi.check(capi.lib.osfm_ba_debug_flow_spin_limit(0))
+    assert s1.flow_fallbacks == 1 and s1.order_arcs > 0
+    assert (s1.num_iterations, s1.termination) == (s0.num_iterations, s0.termination)
+    assert abs(s1.final_cost - s0.final_cost) <= 1e-10 * s0.final_cost

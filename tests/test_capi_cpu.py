@@ -139,3 +139,18 @@ def test_abi_version_of_library_header_and_mirror_agree():
     assert capi.lib.osfm_version() == v == capi.ABI_VERSION
     for fn in ("ba_hip_adapter.h", "mve_hip_matching.h"):
         assert "OSFM_ABI_VERSION" in open(os.path.join(ROOT, "orthosfm_amd", "host", fn)).read()
+
+
+def test_handoff_order_of_the_ba_kernels_in_the_isa():
+    """The tickets of the pair / back passes and the flags of the one-launch Cholesky are relaxed agent-scope
+    atomics ordered by the instruction sequence (sc1 stores, drained vmcnt, barrier, signal; sc1 loads behind the
+    poll).  tools/check_handoff.sh disassembles ba_kernels.hip / ba_cholesky.hip for gfx950 and checks that
+    sequence -- and that chol_flow_kernel spills nothing into scratch memory, which once made its hand-offs race."""
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc on this machine")
+    out = subprocess.run([os.path.join(ROOT, "tools", "check_handoff.sh")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "chol_flow_kernel             scratch bytes 0" in out.stdout
+    assert out.stdout.count("0 not behind a drained vmcnt") == 4 and "FAIL" not in out.stdout
