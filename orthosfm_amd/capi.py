@@ -185,14 +185,14 @@ def ransac_selfcheck(mode: int):
     return int(c[0]), int(c[1]), int(c[2])
 
 
-_pinned_blocks = []
+_pinned_blocks = {}        # address -> the ctypes view that keeps the block reachable
 
 
 def pinned_rows(rows: int):
     """A (rows, 2) int32 array in page-locked host memory (hipHostMalloc of the HIP runtime the
     library is linked against), e.g. as the result buffer of HipExhaustiveMatching.compute: the
     match lists then leave the device at full PCIe rate instead of through pageable staging.
-    Lives as long as the process."""
+    Lives until pinned_free (or as long as the process)."""
     hip = C.CDLL("libamdhip64.so")
     p = C.c_void_p()
     nbytes = max(int(rows), 1) * 8
@@ -200,8 +200,17 @@ def pinned_rows(rows: int):
     if rc != 0 or not p.value:
         raise OsfmError(E_DEVICE, f"hipHostMalloc({nbytes}) failed with {rc}")
     buf = (C.c_int32 * (max(int(rows), 1) * 2)).from_address(p.value)
-    _pinned_blocks.append(buf)
+    _pinned_blocks[p.value] = buf
     return np.frombuffer(buf, dtype=np.int32).reshape(-1, 2)[:rows]
+
+
+def pinned_free(arr) -> bool:
+    """Gives a pinned_rows block back (the caller drops its views of it); False when it is not one."""
+    addr = int(arr.ctypes.data)
+    if _pinned_blocks.pop(addr, None) is None:
+        return False
+    C.CDLL("libamdhip64.so").hipHostFree(C.c_void_p(addr))
+    return True
 
 
 def trim_device_memory(device: int = -1) -> int:

@@ -33,6 +33,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 import time
 from dataclasses import dataclass, field
 
@@ -358,18 +359,41 @@ def _problem(model, cams, const, width, height, points, xy, obs_cam, obs_pt):
                          np.full(cams.shape[0], height, np.int32), points, xy, obs_cam, obs_pt)
 
 
-_LIST_BUFFERS = []
+class _ListBufferPool:
+    """Page-locked (rows, 2) int32 list buffers, kept between jobs (page-locked memory is expensive to allocate --
+    0.1 to 0.5 s for the 200 MB of a 200-view job, depending on the host).  A job CHECKS its buffers OUT and hands
+    them back when it is done, so two reconstruct() calls on two threads never share one; an idle buffer that is too
+    small for the job that asks is freed before the larger one is made."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._idle = []
+
+    def acquire(self, rows):
+        stale = None
+        with self._lock:
+            fit = [b for b in self._idle if b.shape[0] >= rows]
+            if fit:
+                b = min(fit, key=lambda x: x.shape[0])
+                self._idle = [x for x in self._idle if x is not b]
+                return b
+            if self._idle:
+                stale = max(self._idle, key=lambda x: x.shape[0])
+                self._idle = [x for x in self._idle if x is not stale]
+        if stale is not None:
+            capi.pinned_free(stale)
+        return capi.pinned_rows(rows)
+
+    def release(self, buf):
+        with self._lock:
+            self._idle.append(buf)
+
+    def idle_rows(self):
+        with self._lock:
+            return sorted(int(b.shape[0]) for b in self._idle)
 
 
-def _list_buffer(k, rows):
-    """Page-locked (rows, 2) int32 list buffer number k, kept for the process (page-locked memory is
-    expensive to allocate -- 0.1 to 0.5 s for the 200 MB of a 200-view job, depending on the host -- and
-    capi.pinned_rows never frees): grown when a job needs more."""
-    while len(_LIST_BUFFERS) <= k:
-        _LIST_BUFFERS.append(None)
-    if _LIST_BUFFERS[k] is None or _LIST_BUFFERS[k].shape[0] < rows:
-        _LIST_BUFFERS[k] = capi.pinned_rows(rows)
-    return _LIST_BUFFERS[k][:rows]
+_list_buffers = _ListBufferPool()
 
 
 def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, timings=None, pairs=None):
@@ -448,14 +472,19 @@ def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, ti
     # are (the uploads run meanwhile), the second while the first batch is matched.
     free = queue.Queue()
 
+    checked_out = []
+
     def buffer_worker():
         for k in range(2 if n_batches > 1 else 1):
             try:
-                free.put(_list_buffer(k, max_cap))
+                b = _list_buffers.acquire(max_cap)
+                checked_out.append(b)
+                free.put(b[:max_cap])
             except Exception as e:      # raised by the main thread when it takes the item
                 free.put(e)
 
-    threading.Thread(target=buffer_worker, daemon=True).start()
+    buf_thread = threading.Thread(target=buffer_worker, daemon=True)
+    buf_thread.start()
     work = queue.Queue()
     tracks_busy = [0.0]
     err = []
@@ -506,6 +535,11 @@ def match_and_build_tracks(iset, matcher="exhaustive", device=0, verify=True, ti
     th.join()
     if err:
         raise err[0]
+    # every batch is merged and the matcher is idle: the list buffers go back to the pool (on an error they do not --
+    # a copy into one of them may still be under way)
+    buf_thread.join()
+    for b in checked_out:
+        _list_buffers.release(b)
     ids, toff, tfeat, tcol, summary = builder.finish(want_track_ids=False)      # Viewport::track_ids are not used downstream
     # tracks_s: what the job waited for after the last batch was matched (the merge of the earlier
     # batches ran beside the matching: tracks_busy_s of it in all)

@@ -7,6 +7,8 @@ from __future__ import annotations
 import ctypes as C
 from dataclasses import dataclass, field
 
+import threading
+
 import numpy as np
 
 from . import capi
@@ -131,7 +133,7 @@ def feature_table(track_offsets, track_features, norm_positions, image_width, wa
     return view, feat, xy, track_of, by_view, view_start
 
 
-_SELECT_BUFFERS = {}
+_SELECT_BUFFERS = threading.local()      # per thread: the slices a call returns are valid until the SAME thread's next call
 
 
 def select_observations(track_of, cam_f, live, xy, track_mask=None, track_slot=None, want_features=False, track_offsets=None):
@@ -143,7 +145,9 @@ def select_observations(track_of, cam_f, live, xy, track_mask=None, track_slot=N
     # the pass itself); the slices returned are overwritten by the next call -- callers copy what they keep
     # (FlatProblem does)
     cap = n
-    buf = _SELECT_BUFFERS
+    if not hasattr(_SELECT_BUFFERS, "buf"):
+        _SELECT_BUFFERS.buf = {}
+    buf = _SELECT_BUFFERS.buf
     if buf.get("cap", -1) < cap:
         buf["cap"] = cap
         buf["xy"] = np.empty((cap, 2), dtype=np.float64)

@@ -547,7 +547,8 @@ print("OK")
 
 def test_full_size_bit_parity_20k(hm):
     """BASELINE cfg2's per-pair shape at its stated size -- 20000 x 20000 SIFT, 79 row
-    blocks x 3 column segments, the correction-free kernel every bench number comes
+    blocks x 20 column segments of one 16-tile cycle (a single pair is cut short so that
+    it fills the chip), the correction-free kernel every bench number comes
     from -- compared with the oracle list by list (two-way lists, then the
     cross-checked ones), and once more with a few hundred rows holding values > 127
     in both views (special-row blocks + the corrected column operand)."""
@@ -834,3 +835,51 @@ def test_multi_device_matcher_logical_shards(hm):
         single.close()
     with pytest.raises(capi.OsfmError):
         hm(2, device=[0, 99])
+
+
+
+def test_bench_batch_at_full_size_equals_the_oracle(hm):
+    """What bench.py times, as a test: a batch of full-size pairs (9 views x 20000 SIFT descriptors, 36
+    pairs in one osfm_match_all -- enough row blocks that every pair runs ONE column segment of 313 tiles per row
+    block, 320 with the blank filler tiles of the last cycle) through low-res gate, two-way match, cross-check and
+    list compaction, eight of its pairs compared list by list with the CPU oracle (nearest_neighbor.cc:60-129,
+    matching.cc:18-88, exhaustive_matching.cc:114-180)."""
+    from orthosfm_amd import capi
+    V, F = 9, 20000
+    iset = synth.make_image_set(V, F, config_id=2)
+    m = hm(V)
+    for v in range(V):
+        m.set_view(v, iset.sift[v])
+    pairs = [capi.pair_from_index(i) for i in range(V * (V - 1) // 2)]
+    out = m.compute(pairs, capacity=F * len(pairs))
+    assert m.stats().tile_kernel_launches >= 1
+    om = oracle_lib.oracle_matcher()
+    empty = np.zeros((0, 64), np.int16)
+    checked = 0
+    for k in np.linspace(0, len(pairs) - 1, 8).astype(int):
+        a, b = pairs[k]
+        tv = out[k]
+        assert (tv.view_1_id, tv.view_2_id) == (a, b)
+        gate = oracle_lib.oracle_pairwise_match_lowres(iset.sift[a], empty, iset.sift[b], empty, 500)
+        if gate < 5:
+            assert tv.status != capi.PAIR_MATCHED
+            continue
+        e12, _ = oracle_lib.oracle_pairwise_match(iset.sift[a], empty, iset.sift[b], empty)
+        idx = np.nonzero(e12 >= 0)[0]
+        if idx.size < 50:
+            assert tv.status != capi.PAIR_MATCHED
+            continue
+        assert tv.status == capi.PAIR_MATCHED
+        assert np.array_equal(np.asarray(tv.matches), np.stack([idx, e12[idx]], 1)), (a, b)
+        checked += 1
+    assert checked >= 6
+    # and against the reference's own matcher, compiled from /root/reference into oracle/_ref, where it travelled
+    rm = oracle_lib.ref_matcher()
+    if rm is not None:
+        for k in (3, len(pairs) - 2):
+            a, b = pairs[k]
+            e12, e21 = rm.twoway(iset.sift[a], iset.sift[b], 0.8)
+            c12 = rm.remove_inconsistent(e12, e21)[0]
+            idx = np.nonzero(c12 >= 0)[0]
+            if out[k].status == capi.PAIR_MATCHED:
+                assert np.array_equal(np.asarray(out[k].matches), np.stack([idx, c12[idx]], 1)), (a, b)
