@@ -11,7 +11,9 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <future>
 #include <limits>
+#include <string>
 #include <vector>
 
 #include "ba_solve.h"
@@ -20,7 +22,10 @@ using namespace osfm;
 
 namespace {
 
-int validate_problem(const osfm_ba_problem *p, const char *what)
+int validate_observations(const osfm_ba_problem *p, const char *what, int32_t *pt_start);
+
+// sizes, model, null pointers: what has to hold before any array is touched
+int validate_header(const osfm_ba_problem *p, const char *what)
 {
     if (!p) { set_error("%s: null problem", what); return OSFM_E_ARG; }
     if (p->model != OSFM_BA_MODEL_QUATERNION && p->model != OSFM_BA_MODEL_EULER) {
@@ -34,6 +39,19 @@ int validate_problem(const osfm_ba_problem *p, const char *what)
         (p->num_observations && (!p->obs_xy || !p->obs_camera || !p->obs_point))) {
         set_error("%s: null array", what); return OSFM_E_ARG;
     }
+    return OSFM_OK;
+}
+
+int validate_problem(const osfm_ba_problem *p, const char *what)
+{
+    OSFM_RETURN_IF(validate_header(p, what));
+    return validate_observations(p, what, nullptr);
+}
+
+// The per-observation half of the checks; pt_start (when given, sized M + 2, zeroed) takes the observation count of
+// point j in entry j + 1 -- the counting pass of build_layout, in the same sweep over the caller's arrays.
+int validate_observations(const osfm_ba_problem *p, const char *what, int32_t *pt_start)
+{
     int prev = 0;
     // A point is observed at most once per camera: the reference's tracks hold one feature per view (a track
     // with two is a conflict and dropped, bundler_tracks.cc:120-145), and the Schur-complement fast paths
@@ -55,6 +73,7 @@ int validate_problem(const osfm_ba_problem *p, const char *what)
         }
         seen_in[c] = j;
         prev = j;
+        if (pt_start) pt_start[j + 1]++;
     }
     return OSFM_OK;
 }
@@ -589,13 +608,35 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
 {
     if (!sum) { set_error("ba_solve: null summary"); return OSFM_E_ARG; }
     memset(sum, 0, sizeof(*sum));
-    OSFM_RETURN_IF(validate_problem(p, "ba_solve"));
+    const auto t_begin = std::chrono::steady_clock::now();
+    OSFM_RETURN_IF(validate_header(p, "ba_solve"));
     osfm_ba_options o;
     if (opt) o = *opt; else osfm_ba_options_default(&o);
-    OSFM_RETURN_IF(select_device(o.device));
-    const auto t_begin = std::chrono::steady_clock::now();
-
+    // The sweep over the caller's observations (range / order / one-observation-per-camera checks, the points'
+    // observation counts, the copy of the start points) takes as long as queueing the uploads does (0.4 ms each for
+    // BASELINE config 4: pageable arrays are staged by the calling thread): for problems of that size it runs on a
+    // thread of its own beside them.  What it finds is looked at before anything is computed.
+    Layout L;
     const int C = p->num_cameras, M = p->num_points;
+    std::vector<double> pts0;
+    std::string sweep_error;
+    auto sweep = [&]() -> int {
+        L.pt_start.assign((size_t)M + 2, 0);
+        const int rc = validate_observations(p, "ba_solve", L.pt_start.data());
+        if (rc != OSFM_OK) { sweep_error = osfm_last_error(); return rc; }      // (the message is per thread)
+        for (int j = 0; j < M; ++j) L.pt_start[j + 1] += L.pt_start[j];
+        // the points the optimisation starts from (tracksBackup, bundle_adjustment.cpp:99)
+        pts0.resize((size_t)4 * M);
+        if (M) memcpy(pts0.data(), p->points, (size_t)4 * M * 8);
+        return OSFM_OK;
+    };
+    const bool beside = p->num_observations >= 100000;
+    std::future<int> swept;
+    if (beside) swept = std::async(std::launch::async, sweep);
+    else OSFM_RETURN_IF(sweep());
+    struct Joiner { std::future<int> &f; ~Joiner() { if (f.valid()) f.wait(); } } joiner{swept};     // never leave it running
+    OSFM_RETURN_IF(select_device(o.device));
+
     auto lap = [&](const char *what) {
         if (o.verbose >= 2)
             fprintf(stderr, "[osfm ba] %-18s %8.3f ms\n", what,
@@ -609,15 +650,19 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
     DeviceProblem D;
     OSFM_RETURN_IF(upload_caller_arrays(p, s, &D));
     lap("caller arrays queued");
-    Layout L;
-    build_layout(p, &L);
+    if (beside) {
+        const int rc = swept.get();
+        if (rc != OSFM_OK) {
+            OSFM_HIP_CHECK(hipStreamSynchronize(s));       // the queued uploads, before their buffers go back to the pool
+            set_error("%s", sweep_error.c_str());
+            return rc;
+        }
+    }
+    build_camera_layout(p->model, C, p->cam_const, &L);
     const int pdim = o.optimize_points ? 3 : 0;
     lap("layout");
     OSFM_RETURN_IF(upload_problem(p, L, o.huber_delta, pdim, s, &D, true));
     BaDev &d = D.dev;
-    // the points the optimisation starts from (tracksBackup, bundle_adjustment.cpp:99)
-    std::vector<double> pts0((size_t)4 * M);
-    if (M) memcpy(pts0.data(), p->points, (size_t)4 * M * 8);
     if (o.retriangulate_points && M > 0) {
         // triangulateTracks(cameras, localTracks, true) in front of the solve (bundle_adjustment.cpp:77-83)
         OSFM_HIP_CHECK(hipMemcpyAsync(D.points[1].ptr, D.points[0].ptr, (size_t)4 * M * 8, hipMemcpyDeviceToDevice, s));

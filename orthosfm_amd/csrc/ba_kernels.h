@@ -95,6 +95,8 @@ struct LmTail {
 constexpr int kPairChunk = 512;   // entries of a camera pair's list per pair-pass wave; kPairChunkSmall below
 constexpr int kPairChunkSmall = 256;       // kPairChunkSmallLimit entries (few cameras: more, shorter waves)
 constexpr int kPairChunkSmallLimit = 1 << 20;
+constexpr int kPairChunkTiny = 256;        // below kPairChunkTinyLimit entries (the 3-camera adjustments)
+constexpr int kPairChunkTinyLimit = 1 << 16;
 constexpr int kPairSums = 54;     // sums a pair-pass wave leaves per chunk: 6x6 block, 6 diagonal, 6 rhs, 6 gradient
 
 // What a wave of the pair pass needs before its first entry: found through chunk_pair -> chunk_start /

@@ -112,6 +112,14 @@ pair_chunk_fill_kernel(const int32_t *chunk_start, int num_pairs, int32_t *chunk
 // position of every entry in the sorted lists (pairs in key order, tracks in order inside a pair: the same lists
 // to the byte); the per-pair totals come back in one copy and the chunk descriptors are made on the host.
 // ---------------------------------------------------------------------------
+// entries of a camera pair's list per pair-pass wave (OSFM_BA_PAIR_CHUNK: experiments)
+static int pair_chunk_for(int64_t entries)
+{
+    static const int forced = getenv("OSFM_BA_PAIR_CHUNK") ? atoi(getenv("OSFM_BA_PAIR_CHUNK")) : 0;
+    if (forced >= 64) return forced / 64 * 64;
+    return entries < kPairChunkTinyLimit ? kPairChunkTiny : entries < kPairChunkSmallLimit ? kPairChunkSmall : kPairChunk;
+}
+
 constexpr int kSmallCams = 8;
 constexpr int kSmallPairs = kSmallCams * (kSmallCams + 1) / 2;
 
@@ -202,7 +210,7 @@ static int pair_lists_build_small(const BaDev &d, int64_t max_entries, PairLists
     OSFM_RETURN_IF(out->entries.reserve((size_t)E * 8));
     hipLaunchKernelGGL(pair_small_fill_kernel, dim3((M + 255) / 256), dim3(256), 0, s, d, P, flags, scan, out->entries.as<uint64_t>());
     // chunk descriptors of the pairs that have entries, on the host
-    out->chunk = E < kPairChunkSmallLimit ? kPairChunkSmall : kPairChunk;
+    out->chunk = pair_chunk_for(E);
     std::vector<PairChunkDesc> desc;
     int np = 0;
     for (int p = 0; p < P; ++p) {
@@ -327,7 +335,7 @@ int pair_lists_build(const BaDev &d, bool with_points, int64_t max_entries, Pair
         out->starts.as<int32_t>(), h_runs + 1, s));
     // chunks of the pair pass: chunk_start = exclusive scan of ceil(run / kPairChunk); the number
     // of waves to launch is bounded without reading anything back
-    out->chunk = E < kPairChunkSmallLimit ? kPairChunkSmall : kPairChunk;
+    out->chunk = pair_chunk_for(E);
     out->max_chunks = h_runs + E / out->chunk;
     OSFM_RETURN_IF(out->chunk_start.reserve((size_t)(h_runs + 1) * 4));
     OSFM_RETURN_IF(out->chunk_partials.reserve((size_t)out->max_chunks * kPairSums * sizeof(double)));
