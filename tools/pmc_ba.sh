@@ -19,11 +19,12 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCP_GATE_EN1_sum TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $set --kernel-include-regex "ba_pair_pass|ba_point_win|ba_back_win" --output-format csv -d $R/gpurun_out/pmcba_$i -- python3 /tmp/ba_once.py > $R/gpurun_out/pmcba_$i.log 2>&1 || echo "set $i failed" >> $out
+  timeout -k 10 300 rocprofv3 --pmc $set --kernel-include-regex "ba_pair_pass|ba_point_win|ba_back_win|chol_flow" --output-format csv -d $R/gpurun_out/pmcba_$i -- python3 /tmp/ba_once.py > $R/gpurun_out/pmcba_$i.log 2>&1 || echo "set $i failed" >> $out
   f=$(find $R/gpurun_out/pmcba_$i -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then
-    for k in ba_pair_pass_kernel ba_point_win_kernel ba_back_win_kernel; do python3 $R/tools/pmc_summary.py $f "$k" >> $out 2>&1; done
+    for k in ba_pair_pass_kernel ba_point_win_kernel ba_back_win_kernel chol_flow_kernel; do python3 $R/tools/pmc_summary.py $f "$k" >> $out 2>&1; done
   fi
   rm -rf $R/gpurun_out/pmcba_$i
 done
+python3 $R/tools/pmc_ba_traffic.py $out $R/gpurun_out/${1:-r02}_ba_traffic_pmc.json
 cat $out
