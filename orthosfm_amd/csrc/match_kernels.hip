@@ -103,6 +103,18 @@ constexpr int kValNone = -(1 << 28);    // "no candidate" for un-keyed column sc
 
 template <int V> struct IntC { static constexpr int value = V; };
 
+// A column partial is written once and read once, by the finish kernel, after 5 GB of its kind: stored non-temporally
+// it does not push the column bank of the pair out of the XCD's L2 on its way (the 64 workgroups an XCD runs side by
+// side all stream the same 2.5 MB of descriptors).
+__device__ __forceinline__ void store_colpart(ColPart *dst, const ColPart &v)
+{
+#ifdef OSFM_COLPART_PLAIN_STORE
+    *dst = v;
+#else
+    __builtin_nontemporal_store(*reinterpret_cast<const unsigned long long *>(&v), reinterpret_cast<unsigned long long *>(dst));
+#endif
+}
+
 // RAW = true: row operand in raw form (see MatchProblem): the accumulator IS
 // the inner product, no key is built per score in either direction (group keys
 // only), and the best column is recovered by the group rescan of the finish
@@ -369,7 +381,7 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
                     }
                     cpm[0].key_best = k1; cpm[0].key_second = k2;
                 } else {
-                    colout[col_begin + tm * kTileCols + lane] = cpm[0];
+                    store_colpart(colout + col_begin + tm * kTileCols + lane, cpm[0]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -464,7 +476,7 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
             ColPart out;
             out.key_best = k1;
             out.key_second = k2;
-            colout[col] = out;
+            store_colpart(colout + col, out);
         }
     };
 

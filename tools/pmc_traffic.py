@@ -25,9 +25,10 @@ GRID = {}
 
 def pairs_of_last_launch(features=20000):
     """Pairs in the launch the counters come from, from its grid: a pair of two `features`-descriptor views
-    is ceil(n / 256) row blocks x ceil(n / 8192) column segments of 256 threads (osfm_match_all cuts a large
+    is ceil(n / 256) row blocks of 256 threads, one column segment each (osfm_match_all cuts a large
     call into three launches, so this is not the pair count of the call)."""
-    nrb, nseg = (features + 255) // 256, (features + 8191) // 8192
+    # (round 5: a launch with this many row blocks runs ONE column segment per row block, match_api.hip::choose_seg_cols)
+    nrb, nseg = (features + 255) // 256, 1
     return round(GRID[max(GRID)] / 256 / (nrb * nseg)) if GRID else 0
 
 
