@@ -231,7 +231,16 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
         const int ch = (q % CH) ^ ((col / RPB) % CH);
         lane_off[c] = (unsigned)(col * D + ch * 16);
     }
-    auto dma_wait = [&]() { if (PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    // (vector-memory operations complete in issue order: behind a tile whose phase stored a merged column partial --
+    //  issued after the tile's two DMA pieces -- waiting for all but the youngest is waiting for the pieces; the
+    //  store's acknowledgement is not something the next tile needs)
+    auto dma_wait = [&](bool store_behind = false) {
+        if (!PIPE) return;
+#ifndef OSFM_TILE_WAIT_ALL
+        if (store_behind) { asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); return; }
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     auto stage_tile = [&](int t, int buf) {
         const int8_t *src = Bbase + (size_t)(col_begin + t * kTileCols) * D;      // uniform
         // PIPE: the tile loop runs whole cycles; the tiles behind the segment's last one are blank
@@ -425,7 +434,7 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
     // half-waves of a column are exchanged with one v_permlane32_swap so that
     // lane == column within the tile, then the wave's (best, second) goes to LDS.
     // group code = wave * 2 + half-wave (32 rows: both fragments of the half-wave)
-    auto tile_bottom = [&](int t) {
+    auto tile_bottom = [&](int t, bool store_behind = false) {
         int kk[2];
 #pragma unroll
         for (int cf = 0; cf < 2; ++cf) {
@@ -438,7 +447,7 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
         cp.key_best = max(x0, x1);
         cp.key_second = min(x0, x1);
         colbuf[((t & 7) * 4 + wave) * 64 + lane] = cp;
-        dma_wait();
+        dma_wait(store_behind);
         __syncthreads();
     };
     // close the open row-direction group of every slot: fold the group bests into
@@ -506,7 +515,7 @@ tile_body(const MatchProblem &pd, int rb, int seg, RowPart *__restrict__ rowpart
             phase(IntC<0>(), IntC<u>(), IntC<(u & 3) == 1 ? 1 : 0>(), IntC<(u + 15) & 15>(), acc0, acc1, bn,
                 max(tt - 16, 0), tm);
             phase(IntC<1>(), IntC<u>(), IntC<0>(), IntC<u>(), acc1, acc0, bn, max(tt - 15, 0), 0);
-            tile_bottom(tt);
+            tile_bottom(tt, (u & 3) == 1);       // phase (u, 0) of these tiles stores a merged partial
         };
         // (whole cycles only: blank tiles fill the last one, see stage_tile -- a tail of single tiles costs 2.5x
         //  the vector instructions per tile and a close of all slots)
