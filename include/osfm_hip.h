@@ -85,6 +85,14 @@ OSFM_API int osfm_ba_debug_chol_trace(int enable, int64_t *stamps);
  * form and counted in osfm_ba_summary.flow_fallbacks; set small, every wait that is not satisfied at
  * once takes that path. */
 OSFM_API int osfm_ba_debug_flow_spin_limit(int limit);
+/* Diagnostic (host code only, no device): the elimination order osfm_ba_solve would choose for a reduced camera
+ * system (ba_order.hip) -- cam_ldim[C] unknowns per camera, pairs[num_pairs][2] the camera pairs that share a track.
+ * cam_off[C]: the cameras' offsets in the order chosen (the natural ones when none is); blocks (may be NULL) [nblk + 1]
+ * rows of 3 x 64 bits: bit k of row i = tile (i, k) of the factor exists; info[8] = { ordered (0 / 1), arcs K,
+ * cameras per separator, unknowns incl. interior padding, blocks of 32, chain of dependent diagonal blocks in the
+ * cameras' own order, chain in the order chosen, padding unknowns }.  blocks_capacity: rows `blocks` has room for. */
+OSFM_API int osfm_ba_debug_order(int num_cameras, const int32_t *cam_ldim, int num_pairs, const int32_t *pairs,
+    int32_t *cam_off, uint64_t *blocks, int blocks_capacity, int32_t *info);
 
 /* Diagnostic of the RANSAC-F scoring loop.  Its Sampson tests are pre-classified in packed
  * single precision; a test only counts when the float result is out of reach of its error

@@ -124,7 +124,7 @@ class BaSummary(C.Structure):
 
 # every symbol include/osfm_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = [
-    "osfm_last_error", "osfm_version", "osfm_device_count", "osfm_device_memory", "osfm_library_memory", "osfm_trim_device_memory", "osfm_ransac_selfcheck", "osfm_ba_debug_chol_trace", "osfm_ba_debug_flow_spin_limit",
+    "osfm_last_error", "osfm_version", "osfm_device_count", "osfm_device_memory", "osfm_library_memory", "osfm_trim_device_memory", "osfm_ransac_selfcheck", "osfm_ba_debug_chol_trace", "osfm_ba_debug_flow_spin_limit", "osfm_ba_debug_order",
     "osfm_match_options_default", "osfm_match_create", "osfm_match_create_multi", "osfm_match_get_devices", "osfm_match_destroy",
     "osfm_quantize_sift", "osfm_quantize_surf",
     "osfm_match_set_view", "osfm_match_set_view_float", "osfm_match_view_size", "osfm_match_expect_pairs", "osfm_match_set_positions",

@@ -580,6 +580,30 @@ int osfm_ba_debug_flow_spin_limit(int limit)
     return OSFM_OK;
 }
 
+int osfm_ba_debug_order(int num_cameras, const int32_t *cam_ldim, int num_pairs, const int32_t *pairs, int32_t *cam_off,
+    uint64_t *blocks, int blocks_capacity, int32_t *info)
+{
+    if (num_cameras <= 0 || !cam_ldim || num_pairs < 0 || (num_pairs && !pairs) || !cam_off || !info) { set_error("ba_debug_order: bad arguments"); return OSFM_E_ARG; }
+    std::vector<std::pair<int, int>> cp((size_t)num_pairs);
+    for (int i = 0; i < num_pairs; ++i) {
+        const int a = pairs[2 * i], b = pairs[2 * i + 1];
+        if (a < 0 || a >= num_cameras || b < 0 || b >= num_cameras) { set_error("ba_debug_order: pair %d names camera %d / %d", i, a, b); return OSFM_E_ARG; }
+        cp[i] = {std::max(a, b), std::min(a, b)};
+    }
+    ReducedOrder ord;
+    const bool on = choose_reduced_order(num_cameras, cam_ldim, cp, &ord);
+    int tot = 0;
+    for (int c = 0; c < num_cameras; ++c) { cam_off[c] = on ? ord.cam_off[c] : tot; tot += cam_ldim[c]; }
+    info[0] = on ? 1 : 0; info[1] = on ? ord.arcs : 0; info[2] = on ? ord.sep_cams : 0; info[3] = on ? ord.span : tot;
+    info[4] = on ? ord.nblk : (tot + 31) / 32; info[5] = ord.chain_natural; info[6] = on ? ord.chain_ordered : ord.chain_natural;
+    info[7] = on ? (int)ord.pad.size() : 0;
+    if (blocks && on) {
+        if (blocks_capacity < ord.nblk + 1) { set_error("ba_debug_order: %d rows of blocks, room for %d", ord.nblk + 1, blocks_capacity); return OSFM_E_CAPACITY; }
+        for (size_t i = 0; i < ord.nz.size(); ++i) blocks[i] = ord.nz[i];
+    }
+    return OSFM_OK;
+}
+
 int osfm_ba_options_default(osfm_ba_options *o)
 {
     if (!o) { set_error("ba_options_default: null"); return OSFM_E_ARG; }

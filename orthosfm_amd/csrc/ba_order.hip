@@ -93,7 +93,9 @@ bool choose_reduced_order(int C, const int32_t *ldim, const std::vector<std::pai
         out->chain_natural = chain_length(P);
     }
     ReducedOrder best;
+    const int forced = getenv("OSFM_BA_ORDER_ARCS") ? atoi(getenv("OSFM_BA_ORDER_ARCS")) : 0;     // experiments: this K or none
     for (int K = 2; K <= 8; ++K) {
+        if (forced && K != forced) continue;
         if ((C - K * w) / K < w) break;                    // arcs shorter than a separator: no use
         ReducedOrder o;
         o.cam_off.assign(C, 0);
