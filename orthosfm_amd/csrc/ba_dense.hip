@@ -16,6 +16,8 @@
 //   ba_dense_reduce_kernel   S = -(sum of the K ranges' partials), fixed order (split-K only)
 #include <algorithm>
 
+#include <cstdlib>
+
 #include "ba_kernels.h"
 #include "osfm_common.h"
 
@@ -70,7 +72,7 @@ ba_dense_build_kernel(BaDev d, const double *obsrec, const int32_t *obs_lay, dou
 
 // Tile (ti, tj), tj <= ti, K range `split` of `splits`: P = Zm[ti rows] Wm[tj rows]^T over that range.
 // splits == 1: S = -P written in place (rows / columns < nc); else P into partial[split] (a dense rows x rows matrix).
-__global__ __launch_bounds__(256, 1) void
+__global__ __launch_bounds__(256, 2) void
 ba_dense_gemm_kernel(const double *Zm, const double *Wm, int ldk, int ksteps_total, int splits, int ntile, double *S, int ldS, int nc,
     double *partial, int rows, const LmDev *lm)
 {
@@ -167,7 +169,11 @@ int schur_dense_splits(int nc, int M)
     const int ksteps = schur_dense_cols(M) / kDenseK;
     int splits = std::max(1, std::min(16, (512 + tiles - 1) / tiles));
     splits = std::min(splits, std::max(1, ksteps / 8));
-    return tiles >= 192 ? 1 : splits;
+    // 192 .. 511 tiles (the 500-view job's last adjustments: 210): as one workgroup per CU nothing covers a workgroup's
+    // barriers and its waits for the next tiles; split in two over K, two workgroups share a CU (OSFM_BA_DENSE_SPLIT2=0: off)
+    static const bool split2 = !(getenv("OSFM_BA_DENSE_SPLIT2") && atoi(getenv("OSFM_BA_DENSE_SPLIT2")) == 0);
+    if (tiles >= 192) return (split2 && tiles < 512 && ksteps >= 64) ? 2 : 1;
+    return splits;
 }
 
 size_t schur_dense_partial_bytes(int nc, int M)
