@@ -654,10 +654,13 @@ int osfm_ba_solve(const osfm_ba_problem *p, const osfm_ba_options *opt, osfm_ba_
         if (M) memcpy(pts0.data(), p->points, (size_t)4 * M * 8);
         return OSFM_OK;
     };
-    const bool beside = p->num_observations >= 100000;
+    bool beside = p->num_observations >= 100000;
     std::future<int> swept;
-    if (beside) swept = std::async(std::launch::async, sweep);
-    else OSFM_RETURN_IF(sweep());
+    if (beside) {
+        // (no thread to be had: the sweep runs here, in front of the uploads, as for small problems)
+        try { swept = std::async(std::launch::async, sweep); } catch (const std::exception &) { beside = false; }
+    }
+    if (!beside) OSFM_RETURN_IF(sweep());
     struct Joiner { std::future<int> &f; ~Joiner() { if (f.valid()) f.wait(); } } joiner{swept};     // never leave it running
     OSFM_RETURN_IF(select_device(o.device));
 
