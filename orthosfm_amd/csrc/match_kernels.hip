@@ -984,7 +984,13 @@ match_finish_kernel(const MatchProblem *__restrict__ problems, const RowPart *__
                 ColPart p[kBatch];
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u)
-                    p[u] = cp0[(int64_t)min(rb0 + u, nrb - 1) * stride];     // clamped repeats are not folded
+                {
+                    // (read once, 5 GB of them per launch: non-temporal, so that they do not push the descriptors the
+                    //  rescans gather out of the L2)
+                    const unsigned long long raw = __builtin_nontemporal_load(
+                        reinterpret_cast<const unsigned long long *>(cp0 + (int64_t)min(rb0 + u, nrb - 1) * stride));     // clamped repeats are not folded
+                    p[u].key_best = (int)(raw & 0xffffffffu); p[u].key_second = (int)(raw >> 32);
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < kBatch; ++u) {
