@@ -883,3 +883,45 @@ def test_bench_batch_at_full_size_equals_the_oracle(hm):
             idx = np.nonzero(c12 >= 0)[0]
             if out[k].status == capi.PAIR_MATCHED:
                 assert np.array_equal(np.asarray(out[k].matches), np.stack([idx, c12[idx]], 1)), (a, b)
+
+
+def test_ragged_views_in_one_batch_each_with_its_own_segments(hm):
+    """Round 5: a correction-free problem's column segment length is chosen per problem and launch (`seg_cols`: as few
+    16-tile cycles' worth of segments as still fill the chip), and the tile loop runs whole cycles with blank filler
+    tiles behind a segment's last real one.  One batch over views of 1 .. 9000 descriptors -- a single column (fifteen
+    and a half filler tiles), sizes just below / at / above a tile, a cycle and a row block, several cycles -- every
+    pair, both directions and the cross-check, against the oracle; then the same views pair by pair through the
+    per-pair entry, which cuts a pair into many short segments."""
+    from orthosfm_amd import capi
+    sizes = [1, 63, 64, 65, 255, 257, 1023, 1024, 1025, 2049, 5000, 9000]
+    base = synth.make_image_set(len(sizes), 9000, config_id=14, twin_frac=0.3)
+    sift = [base.sift[v][:n].copy() for v, n in enumerate(sizes)]
+    o = capi.default_match_options()
+    o.use_lowres_matching = 0
+    o.min_feature_matches = 0
+    m = hm(len(sizes), options=o)
+    for v, s in enumerate(sift):
+        m.set_view(v, s)
+    out = m.compute()
+    assert len(out) == len(sizes) * (len(sizes) - 1) // 2
+    empty = np.zeros((0, 64), np.int16)
+    expect = {}
+    for tv in out:
+        a, b = tv.view_1_id, tv.view_2_id
+        e12, _ = oracle_lib.oracle_pairwise_match(sift[a], empty, sift[b], empty)
+        idx = np.nonzero(e12 >= 0)[0]
+        expect[(a, b)] = np.stack([idx, e12[idx]], axis=1).astype(np.int32)
+        if expect[(a, b)].shape[0] < 8:            # bundler_matching.cc:150-153: fewer than eight matches are no pair
+            assert tv.status != capi.PAIR_MATCHED, (a, b)
+            continue
+        assert tv.status == capi.PAIR_MATCHED and np.array_equal(np.asarray(tv.matches).reshape(-1, 2), expect[(a, b)]), \
+            (a, b, sizes[a], sizes[b])
+    assert sum(1 for e in expect.values() if e.shape[0] >= 8) >= 30
+    # the per-pair entry returns the lists whatever their length: every pair with a small view, and some large ones
+    small = [(a, b) for (a, b) in expect if min(sizes[a], sizes[b]) <= 257]
+    for a, b in small + [(11, 10), (9, 5), (10, 8)]:
+        got = m.pairwise_match(a, b)
+        c12 = np.full(sizes[a], -1, np.int32)
+        c12[expect[(a, b)][:, 0]] = expect[(a, b)][:, 1]
+        assert np.array_equal(got.matches_1_2, c12), (a, b)
+    m.close()
